@@ -1,0 +1,166 @@
+/*
+ * m4depth_hip.h -- C ABI of libm4depth_hip.so: the MI355X (gfx950) native
+ * implementation of M4Depth's per-frame parallax-cost-volume inference path.
+ *
+ * This is the drop-in boundary.  The reference's only native interface is the
+ * TensorFlow custom op pair BackProject / BackProjectGrad
+ * (cuda_backproject/backproject_op.cc:32-42, launchers declared at
+ * cuda_backproject/backproject_op_gpu.h:17-22); m4d_backproject_fwd/_bwd
+ * replace those launchers one for one.  Every other entry point replaces a
+ * piece of TF graph code of utils/depth_operations.py, utils/dense_image_warp.py
+ * or m4depth_network.py:167-262 that the reference runs as dozens of unfused TF
+ * ops; each declaration cites the lines it replaces.
+ *
+ * Conventions
+ *   - all tensors are dense row-major NHWC float32 in device (HBM) memory unless
+ *     a stride argument says otherwise; i = column (x), j = row (y);
+ *   - the caller allocates every buffer; kernels never allocate, never retain
+ *     pointers, write every output element (no memset dependency) and are
+ *     enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream).  No host synchronisation, no global state: the calls
+ *     are re-entrant and hipGraph-capturable;
+ *   - return value: 0 on success, otherwise a hipError_t code (1 =
+ *     hipErrorInvalidValue for bad arguments).  Never exits the process (the
+ *     reference launcher does `exit(-1)`, backproject_op_gpu.cu.cc:95-100);
+ *   - `rot` is [b, rot_c] with rot_c = 4 (quaternion w,x,y,z, not renormalised)
+ *     or 3 (small-angle x,y,z) as in get_rot_mat (utils/depth_operations.py:18-53);
+ *     `trans` is [b,3]; `cam_f`, `cam_c` are the level-local intrinsics [b,2]
+ *     (fx,fy) / (cx,cy) (m4depth_network.py:300-302);
+ *   - arithmetic is IEEE float32 with one rounding per operation (the library is
+ *     built with -ffp-contract=off) in the operand order of oracle/m4depth_oracle.py,
+ *     so integer index grids are bit-exact against the oracle.
+ */
+#ifndef M4DEPTH_HIP_H_
+#define M4DEPTH_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M4D_ABI_VERSION 1
+
+/* Library / device introspection (no GPU work). */
+int m4d_abi_version(void);
+const char* m4d_build_info(void);
+
+/* ---- the reference's native op ------------------------------------------------ */
+
+/* BackProjectForwardLauncher (backproject_op_gpu.cu.cc:83-103; kernel :19-79).
+ * dims = {B,H,W,S,F,C} as built by BackProjectOp::Compute (backproject_op.cc:67-80).
+ * input [B,H,W,F,C], coords [B,H,W,S,F,2] as (x,y), out [B,H,W,S,F,C].
+ * Coordinates outside [0,W-1]x[0,H-1] produce zeros. */
+int m4d_backproject_fwd(const float* input, const float* coords, const int dims[6],
+                        float* out, void* stream);
+
+/* BackProjectBackwardLauncher (backproject_op_gpu.cu.cc:201-223; kernel :108-197).
+ * grad [B,H,W,S,F,C] -> input_grad [B,H,W,F,C] (fp32 atomic scatter, zero-filled by
+ * the call itself), coords_grad [B,H,W,S,F,2]. */
+int m4d_backproject_bwd(const float* grad, const float* input, const float* coords,
+                        const int dims[6], float* input_grad, float* coords_grad, void* stream);
+
+/* ---- utils/dense_image_warp.py -------------------------------------------------- */
+
+/* dense_image_warp (:195-268) on its TF-CPU branch (_interpolate_bilinear, :61-192):
+ * query = (j,i) + flow[(row,col)], floor clamped to [0,size-2], alpha to [0,1],
+ * lerp form a*(r-l)+l.  image [B,H,W,C], flow [B,H,W,2] -> out [B,H,W,C].
+ * index_out (may be NULL): int32 [B,H,W,2] = (y0,x0) -- the bit-exact index grid. */
+int m4d_dense_image_warp(const float* image, const float* flow, int B, int H, int W, int C,
+                         float* out, int32_t* index_out, void* stream);
+
+/* _interpolate_bilinear (:61-192) with indexing='ij': grid [B,H,W,C], query [B,N,2] as
+ * (row, col) -> out [B,N,C]; index_out (may be NULL) int32 [B,N,2] = (y0,x0). */
+int m4d_interpolate_bilinear(const float* grid, const float* query, int B, int H, int W, int C,
+                             int N, float* out, int32_t* index_out, void* stream);
+
+/* ---- utils/depth_operations.py: converters -------------------------------------- */
+
+/* parallax2depth (:141-166): depth = (s/disp - tz)/alpha.  disp,out [b,h,w,1]. */
+int m4d_parallax2depth(const float* disp, const float* rot, int rot_c, const float* trans,
+                       const float* cam_f, const float* cam_c, int b, int h, int w,
+                       float* out, void* stream);
+/* depth2parallax (:169-194): disp = s/(depth*alpha + tz). */
+int m4d_depth2parallax(const float* depth, const float* rot, int rot_c, const float* trans,
+                       const float* cam_f, const float* cam_c, int b, int h, int w,
+                       float* out, void* stream);
+/* prev_d2para (:197-215); rot is accepted for signature parity and ignored. */
+int m4d_prev_d2para(const float* prev_d, const float* rot, int rot_c, const float* trans,
+                    const float* cam_f, const float* cam_c, int b, int h, int w,
+                    float* out, void* stream);
+/* The flow field reproject (:72-105) hands to dense_image_warp plus its two auxiliary
+ * outputs.  depth [b,h,w,1] -> flow [b,h,w,2] (row,col), proj_minus_rot [b,h,w,2],
+ * rot_coord [b,h,w,2] (either aux pointer may be NULL). */
+int m4d_reproject_flow(const float* depth, const float* rot, int rot_c, const float* trans,
+                       const float* cam_f, const float* cam_c, int b, int h, int w,
+                       float* flow, float* proj_minus_rot, float* rot_coord, void* stream);
+/* recompute_depth (:109-137). */
+int m4d_recompute_depth(const float* depth, const float* rot, int rot_c, const float* trans,
+                        const float* cam_f, const float* cam_c, int b, int h, int w,
+                        float* out, void* stream);
+
+/* ---- utils/depth_operations.py: cost volumes ------------------------------------ */
+
+/* get_parallax_sweeping_cv, the DSCV (:224-281).
+ * c1, c2 [b,h,w,C]; disp_prev_t, disp [b,h,w,1]; nbre_cuts divides C.
+ * cv: channel kk*(2r+1)+(n+r) of pixel p is written at cv[p*cv_stride + kk*(2r+1)+(n+r)]
+ *     (cv_stride >= k*(2r+1); pass k*(2r+1) for a dense [b,h,w,k*(2r+1)] tensor, or the
+ *     refiner-input width to write straight into f_input).  Products are formed in
+ *     float16 and averaged per cut (cv_accum: 0 = float32 sum, one rounding to half;
+ *     1 = sequential half adds) as at :276-277.
+ * prev_disp (may be NULL) [b,h,w,2r+1]: the warped disp_prev_t channel (:273,:280).
+ * log_center (may be NULL): writes log(prev_disp[...,r] * log_scale) at
+ *     log_center[p*log_stride] -- the time-recurrence feature of m4depth_network.py:238.
+ * index_out (may be NULL): int32 [b,h,w,2r+1,2] = (y0,x0) of every hypothesis. */
+int m4d_dscv_fwd(const float* c1, const float* c2, const float* disp_prev_t, const float* disp,
+                 const float* rot, int rot_c, const float* trans, const float* cam_f,
+                 const float* cam_c, int b, int h, int w, int C, int search_range, int nbre_cuts,
+                 int cv_accum, float* cv, int cv_stride, float* prev_disp,
+                 float* log_center, int log_stride, float log_scale,
+                 int32_t* index_out, void* stream);
+
+/* cost_volume, the SNCV (:284-313): out channel ((y*(2r+1)+x)*k + kk) =
+ * leaky_relu(mean_c c1[j,i,c] * c2pad[j+y*d, i+x*d, c], 0.1), written at
+ * out[p*out_stride + channel]. */
+int m4d_sncv_fwd(const float* c1, const float* c2, int b, int h, int w, int C, int search_range,
+                 int dilation_rate, int nbre_cuts, float* out, int out_stride, void* stream);
+
+/* ---- m4depth_network.py: DepthEstimatorLevel glue -------------------------------- */
+
+/* Per-cut L2 normalisation (:179-189, tf.linalg.normalize, no epsilon). */
+int m4d_normalize_cuts(const float* x, int b, int h, int w, int C, int nbre_cuts,
+                       float* out, void* stream);
+
+/* tf.compat.v1.image.resize_bilinear defaults (:202-204): x [b,ih,iw,c] -> out
+ * [b,oh,ow,c], multiplied by `mul` (2.0 for the parallax map, :203). */
+int m4d_resize_bilinear_v1(const float* x, int b, int ih, int iw, int c, int oh, int ow,
+                           float mul, float* out, void* stream);
+/* tf.image.resize(NEAREST_NEIGHBOR) (:368). */
+int m4d_resize_nearest(const float* x, int b, int ih, int iw, int c, int oh, int ow,
+                       float* out, void* stream);
+
+/* Fused "preprocessor" glue of one level (:196-204, :218, :224-227):
+ *   prev_l_* (coarser level estimate at [b,ph,pw,.]; all NULL at the coarsest level ->
+ *   parallax 1, depth 1000, other 0) are x2-upsampled to para_prev_l [b,h,w,1] (x2),
+ *   depth_prev_l [b,h,w,1], other_prev_l [b,h,w,4];
+ *   para_prev_t [b,h,w,1] = prev_d2para(depth_prev_t) (skipped when depth_prev_t NULL);
+ *   if f_input != NULL: f_input[p*f_stride + log_off] = log(para_prev_l * log_scale) and,
+ *   when other_off >= 0, f_input[p*f_stride + other_off + 0..3] = other_prev_l. */
+int m4d_level_pre(const float* prev_l_depth, const float* prev_l_parallax, const float* prev_l_other,
+                  int ph, int pw, const float* depth_prev_t, const float* trans,
+                  const float* cam_f, const float* cam_c, int b, int h, int w,
+                  float* para_prev_l, float* depth_prev_l, float* other_prev_l, float* para_prev_t,
+                  float* f_input, int f_stride, int log_off, int other_off, float log_scale,
+                  void* stream);
+
+/* Fused "depth_estimator" tail of one level (:247-260): refiner_out [b,h,w,5] ->
+ * parallax = exp(clip(out0,-7,7)) / scale, other = out[1:5], depth =
+ * parallax2depth(parallax); depth is also stored into depth_state (may be NULL). */
+int m4d_level_post(const float* refiner_out, const float* rot, int rot_c, const float* trans,
+                   const float* cam_f, const float* cam_c, int b, int h, int w, float scale,
+                   float* parallax, float* depth, float* other, float* depth_state, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M4DEPTH_HIP_H_ */

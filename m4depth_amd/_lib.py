@@ -1,0 +1,108 @@
+"""ctypes binding to libm4depth_hip.so (the C ABI of include/m4depth_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call
+returns a HIP error, this raises.  PyTorch is used only as the owner of device
+memory and streams (``tensor.data_ptr()``, ``torch.cuda.current_stream()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm4depth_hip.so")
+
+_c_fp = ctypes.c_void_p       # device pointers travel as void*
+_c_int = ctypes.c_int
+_c_f = ctypes.c_float
+
+# name -> argtypes; mirrors include/m4depth_hip.h one for one.
+_SIGNATURES = {
+    "m4d_backproject_fwd": [_c_fp, _c_fp, ctypes.POINTER(_c_int), _c_fp, _c_fp],
+    "m4d_backproject_bwd": [_c_fp, _c_fp, _c_fp, ctypes.POINTER(_c_int), _c_fp, _c_fp, _c_fp],
+    "m4d_dense_image_warp": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
+    "m4d_interpolate_bilinear": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
+    "m4d_parallax2depth": [_c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_depth2parallax": [_c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_prev_d2para": [_c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_recompute_depth": [_c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_reproject_flow": [_c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp],
+    "m4d_dscv_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
+                     _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                     _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_f, _c_fp, _c_fp],
+    "m4d_sncv_fwd": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp],
+    "m4d_normalize_cuts": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_resize_bilinear_v1": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
+    "m4d_resize_nearest": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_level_pre": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int,
+                      _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp],
+    "m4d_level_post": [_c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
+                       _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+}
+
+EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES)
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"m4depth_amd: native library not found at {LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C m4depth_amd/csrc`. "
+            "There is no CPU / PyTorch fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.m4d_abi_version.restype = _c_int
+    lib.m4d_abi_version.argtypes = []
+    lib.m4d_build_info.restype = ctypes.c_char_p
+    lib.m4d_build_info.argtypes = []
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale: loud by design
+        fn.restype = _c_int
+        fn.argtypes = args
+    if lib.m4d_abi_version() != 1:
+        raise ImportError(f"m4depth_amd: ABI mismatch, library reports {lib.m4d_abi_version()}, binding expects 1")
+    return lib
+
+
+lib = _load()
+
+
+def build_info() -> str:
+    return lib.m4d_build_info().decode()
+
+
+def stream_ptr():
+    """The current PyTorch HIP stream as a void* for the C ABI."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t, name="tensor", dtype=torch.float32):
+    """Device pointer of a dense CUDA(ROCm) tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: m4depth_amd ops run on the MI355X only (tensor is on {t.device}); "
+                           "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a dense row-major (NHWC) tensor, got strides {t.stride()}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"m4depth_amd: {what} failed with HIP error {rc}"
+                           + (" (hipErrorInvalidValue: bad argument)" if rc == 1 else ""))
+
+
+def as_f32(t, name):
+    """Dense float32 device tensor (copies only when a conversion is needed)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,9 @@
+// Library introspection entry points (no GPU work).
+#include <hip/hip_runtime.h>
+#include "../../include/m4depth_hip.h"
+
+extern "C" int m4d_abi_version(void) { return M4D_ABI_VERSION; }
+
+extern "C" const char* m4d_build_info(void) {
+  return "libm4depth_hip gfx950 (CDNA4) -ffp-contract=off abi=1 built " __DATE__ " " __TIME__;
+}

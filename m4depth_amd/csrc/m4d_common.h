@@ -1,0 +1,98 @@
+// Shared device helpers for libm4depth_hip.so (gfx950 / CDNA4 only).
+//
+// Numerics contract: built with -ffp-contract=off; every expression below has
+// one IEEE float32 rounding per operation in the operand order of
+// oracle/m4depth_oracle.py (which cites the reference lines), so query points
+// and therefore the int32 bilinear index grid are bit-identical to the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define M4D_CHECK_ARG(cond) do { if (!(cond)) return (int)hipErrorInvalidValue; } while (0)
+#define M4D_LAUNCH_RESULT() ((int)hipGetLastError())
+
+static inline int m4d_blocks(long long n, int threads) { return (int)((n + threads - 1) / threads); }
+
+// Per-sample camera motion: rotation matrix (get_rot_mat, utils/depth_operations.py:18-53),
+// translation scaled by the focal lengths, level-local intrinsics.
+struct M4dMotion {
+  float r00, r01, r02, r10, r11, r12, r20, r21, r22;
+  float fx, fy, cx, cy;
+  float tx, ty, tz;      // raw translation
+  float stx, sty;        // t * f  (scaled_t, :157)
+};
+
+__device__ __forceinline__ M4dMotion m4d_load_motion(const float* __restrict__ rot, int rot_c,
+                                                     const float* __restrict__ trans,
+                                                     const float* __restrict__ cam_f,
+                                                     const float* __restrict__ cam_c, int bi) {
+  M4dMotion m;
+  if (rot == nullptr) {
+    m.r00 = 1.f; m.r01 = 0.f; m.r02 = 0.f; m.r10 = 0.f; m.r11 = 1.f; m.r12 = 0.f; m.r20 = 0.f; m.r21 = 0.f; m.r22 = 1.f;
+  } else if (rot_c == 3) {
+    const float r0 = rot[bi * 3 + 0], r1 = rot[bi * 3 + 1], r2 = rot[bi * 3 + 2];
+    m.r00 = 1.f; m.r01 = -r2; m.r02 = r1;
+    m.r10 = r2;  m.r11 = 1.f; m.r12 = -r0;
+    m.r20 = -r1; m.r21 = r0;  m.r22 = 1.f;
+  } else {
+    const float w = rot[bi * 4 + 0], x = rot[bi * 4 + 1], y = rot[bi * 4 + 2], z = rot[bi * 4 + 3];
+    const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    m.r00 = 1.0f - (tyy + tzz); m.r01 = txy - twz;          m.r02 = txz + twy;
+    m.r10 = txy + twz;          m.r11 = 1.0f - (txx + tzz); m.r12 = tyz - twx;
+    m.r20 = txz - twy;          m.r21 = tyz + twx;          m.r22 = 1.0f - (txx + tyy);
+  }
+  m.fx = cam_f[bi * 2 + 0]; m.fy = cam_f[bi * 2 + 1];
+  m.cx = cam_c[bi * 2 + 0]; m.cy = cam_c[bi * 2 + 1];
+  m.tx = trans[bi * 3 + 0]; m.ty = trans[bi * 3 + 1]; m.tz = trans[bi * 3 + 2];
+  m.stx = m.tx * m.fx; m.sty = m.ty * m.fy;
+  return m;
+}
+
+// The per-pixel factors shared by parallax2depth / depth2parallax / DSCV
+// (utils/depth_operations.py:146-162, 174-190, 239-261).
+struct M4dPixel {
+  float x, y;            // coords2d = mesh / f
+  float alpha, proj_x, proj_y, delta_x, delta_y, s;
+};
+
+__device__ __forceinline__ M4dPixel m4d_pixel_factors(const M4dMotion& m, int i, int j) {
+  M4dPixel p;
+  const float mx = ((float)i + 0.5f) - m.cx;
+  const float my = ((float)j + 0.5f) - m.cy;
+  p.x = mx / m.fx;
+  p.y = my / m.fy;
+  const float rcx = (m.r00 * p.x + m.r01 * p.y) + m.r02;
+  const float rcy = (m.r10 * p.x + m.r11 * p.y) + m.r12;
+  const float rcz = (m.r20 * p.x + m.r21 * p.y) + m.r22;
+  p.alpha = rcz;
+  p.proj_x = (rcx * m.fx) / p.alpha;
+  p.proj_y = (rcy * m.fy) / p.alpha;
+  p.delta_x = m.stx - m.tz * p.proj_x;
+  p.delta_y = m.sty - m.tz * p.proj_y;
+  p.s = sqrtf(p.delta_x * p.delta_x + p.delta_y * p.delta_y);
+  return p;
+}
+
+// One dimension of _interpolate_bilinear (utils/dense_image_warp.py:127-154):
+// floor clamped to [0,size-2], alpha clamped to [0,1].  fmaxf/fminf return the
+// non-NaN operand, so a NaN query (t = 0 is 0/0 in the reference) yields index 0
+// instead of an out-of-bounds read.
+__device__ __forceinline__ void m4d_bilinear_axis(float q, int size, int& i0, float& a) {
+  const float fl = fminf(fmaxf(0.0f, floorf(q)), (float)(size - 2));
+  i0 = (int)fl;
+  a = fminf(fmaxf(0.0f, q - fl), 1.0f);
+}
+
+// a*(r-l)+l twice, then across rows (utils/dense_image_warp.py:188-190).
+__device__ __forceinline__ float m4d_lerp2(float tl, float tr, float bl, float br, float ax, float ay) {
+  const float top = ax * (tr - tl) + tl;
+  const float bot = ax * (br - bl) + bl;
+  return ay * (bot - top) + top;
+}
+
+// float -> half -> float (round-to-nearest-even), the cast at depth_operations.py:276.
+__device__ __forceinline__ float m4d_round_half(float v) { return __half2float(__float2half_rn(v)); }

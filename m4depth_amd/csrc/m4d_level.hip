@@ -1,0 +1,245 @@
+// DepthEstimatorLevel glue (m4depth_network.py:179-204, 218, 224-227, 247-260):
+// per-cut L2 normalisation, the TF-v1 / nearest resizes, and the two fused
+// elementwise stages on either side of the refiner convolutions.  All of these are
+// one-pass, one-lane-per-pixel (or per element) streaming kernels: HBM-bound by
+// construction, no re-reads.
+#include "m4d_common.h"
+#include "../../include/m4depth_hip.h"
+
+namespace {
+
+// ---- per-cut normalisation (:179-189) -------------------------------------------
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+normalize_cuts_kernel(const float* __restrict__ x, long long items, int C, int k, int nc,
+                      float* __restrict__ out) {
+  for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items;
+       it += (long long)gridDim.x * blockDim.x) {
+    const float* p = x + it * nc;             // (pixel, cut) runs are contiguous: it = pix*k + kk
+    float* o = out + it * nc;
+    float acc = 0.f;
+    if (VEC4) {
+      for (int c = 0; c < nc; c += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + c);
+        if (c == 0) acc = v.x * v.x; else acc = acc + v.x * v.x;
+        acc = acc + v.y * v.y; acc = acc + v.z * v.z; acc = acc + v.w * v.w;
+      }
+      const float nrm = sqrtf(acc);
+      for (int c = 0; c < nc; c += 4) {
+        float4 v = *reinterpret_cast<const float4*>(p + c);
+        v.x = v.x / nrm; v.y = v.y / nrm; v.z = v.z / nrm; v.w = v.w / nrm;
+        *reinterpret_cast<float4*>(o + c) = v;
+      }
+    } else {
+      for (int c = 0; c < nc; ++c) { const float v = p[c]; if (c == 0) acc = v * v; else acc = acc + v * v; }
+      const float nrm = sqrtf(acc);
+      for (int c = 0; c < nc; ++c) o[c] = p[c] / nrm;
+    }
+  }
+}
+
+// ---- tf.compat.v1.image.resize_bilinear, legacy coordinates (:202-204) ----------
+struct ResizeAxis { int lo, hi; float lerp; };
+__device__ __forceinline__ ResizeAxis resize_axis(int o, float scale, int in_n) {
+  const float src = (float)o * scale;
+  const float fl = floorf(src);
+  ResizeAxis a;
+  a.lo = max((int)fl, 0);
+  a.hi = min((int)ceilf(src), in_n - 1);
+  a.lerp = src - fl;
+  return a;
+}
+__device__ __forceinline__ float resize_sample(const float* __restrict__ img, int iw, int c, int cc,
+                                               const ResizeAxis& ya, const ResizeAxis& xa) {
+  const float tl = img[((long long)ya.lo * iw + xa.lo) * c + cc];
+  const float tr = img[((long long)ya.lo * iw + xa.hi) * c + cc];
+  const float bl = img[((long long)ya.hi * iw + xa.lo) * c + cc];
+  const float br = img[((long long)ya.hi * iw + xa.hi) * c + cc];
+  const float top = tl + (tr - tl) * xa.lerp;
+  const float bot = bl + (br - bl) * xa.lerp;
+  return top + (bot - top) * ya.lerp;
+}
+
+__global__ void __launch_bounds__(256)
+resize_bilinear_v1_kernel(const float* __restrict__ x, int ih, int iw, int c, int oh, int ow,
+                          float mul, long long total, float* __restrict__ out) {
+  const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(idx % c);
+    long long r = idx / c;
+    const int ox = (int)(r % ow); r /= ow;
+    const int oy = (int)(r % oh);
+    const long long bi = r / oh;
+    const ResizeAxis ya = resize_axis(oy, sy, ih), xa = resize_axis(ox, sx, iw);
+    out[idx] = resize_sample(x + bi * ih * iw * c, iw, c, cc, ya, xa) * mul;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+resize_nearest_kernel(const float* __restrict__ x, int ih, int iw, int c, int oh, int ow,
+                      long long total, float* __restrict__ out) {
+  const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(idx % c);
+    long long r = idx / c;
+    const int ox = (int)(r % ow); r /= ow;
+    const int oy = (int)(r % oh);
+    const long long bi = r / oh;
+    const int iy = min((int)floorf(((float)oy + 0.5f) * sy), ih - 1);
+    const int ix = min((int)floorf(((float)ox + 0.5f) * sx), iw - 1);
+    out[idx] = x[((bi * ih + iy) * iw + ix) * c + cc];
+  }
+}
+
+// ---- fused "preprocessor" glue ---------------------------------------------------
+struct LevelPreArgs {
+  const float* pl_depth; const float* pl_para; const float* pl_other; int ph, pw;
+  const float* depth_prev_t; const float* trans; const float* cam_f; const float* cam_c;
+  int h, w;
+  float* para_prev_l; float* depth_prev_l; float* other_prev_l; float* para_prev_t;
+  float* f_input; int f_stride, log_off, other_off; float log_scale;
+};
+
+__global__ void __launch_bounds__(256)
+level_pre_kernel(const LevelPreArgs a) {
+  const int bi = blockIdx.y;
+  const int hw = a.h * a.w;
+  const bool has_prev = a.pl_depth != nullptr;
+  const float sy = has_prev ? (float)a.ph / (float)a.h : 0.f;
+  const float sx = has_prev ? (float)a.pw / (float)a.w : 0.f;
+  float fx = 0.f, fy = 0.f, cx = 0.f, cy = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+  if (a.depth_prev_t) {
+    fx = a.cam_f[bi * 2]; fy = a.cam_f[bi * 2 + 1];
+    cx = a.cam_c[bi * 2]; cy = a.cam_c[bi * 2 + 1];
+    tx = a.trans[bi * 3]; ty = a.trans[bi * 3 + 1]; tz = a.trans[bi * 3 + 2];
+  }
+  const float stx = tx * fx, sty = ty * fy;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
+    const int i = p % a.w, j = p / a.w;
+    const long long gp = (long long)bi * hw + p;
+    float para = 1.0f, depth = 1000.0f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;   // :198-200
+    if (has_prev) {
+      const ResizeAxis ya = resize_axis(j, sy, a.ph), xa = resize_axis(i, sx, a.pw);
+      const long long pb = (long long)bi * a.ph * a.pw;
+      para = resize_sample(a.pl_para + pb, a.pw, 1, 0, ya, xa) * 2.0f;             // :203
+      depth = resize_sample(a.pl_depth + pb, a.pw, 1, 0, ya, xa);                  // :204
+      const float* ob = a.pl_other + pb * 4;
+      o0 = resize_sample(ob, a.pw, 4, 0, ya, xa); o1 = resize_sample(ob, a.pw, 4, 1, ya, xa);
+      o2 = resize_sample(ob, a.pw, 4, 2, ya, xa); o3 = resize_sample(ob, a.pw, 4, 3, ya, xa);
+    }
+    if (a.para_prev_l) a.para_prev_l[gp] = para;
+    if (a.depth_prev_l) a.depth_prev_l[gp] = depth;
+    if (a.other_prev_l) *reinterpret_cast<float4*>(a.other_prev_l + gp * 4) = make_float4(o0, o1, o2, o3);
+    if (a.depth_prev_t && a.para_prev_t) {                                           // prev_d2para, :218
+      const float mx = ((float)i + 0.5f) - cx, my = ((float)j + 0.5f) - cy;
+      const float ccx = (mx / fx) * fx, ccy = (my / fy) * fy;
+      const float den = a.depth_prev_t[gp] - tz;
+      const float dx = (stx - tz * ccx) / den, dy = (sty - tz * ccy) / den;
+      a.para_prev_t[gp] = sqrtf(dx * dx + dy * dy);
+    }
+    if (a.f_input) {
+      float* f = a.f_input + gp * a.f_stride;
+      f[a.log_off] = logf(para * a.log_scale);                                       // :224
+      if (a.other_off >= 0) { f[a.other_off] = o0; f[a.other_off + 1] = o1; f[a.other_off + 2] = o2; f[a.other_off + 3] = o3; }
+    }
+  }
+}
+
+// ---- fused "depth_estimator" tail (:247-260) --------------------------------------
+__global__ void __launch_bounds__(256)
+level_post_kernel(const float* __restrict__ ro, const float* __restrict__ rot, int rot_c,
+                  const float* __restrict__ trans, const float* __restrict__ cam_f,
+                  const float* __restrict__ cam_c, int h, int w, float scale,
+                  float* __restrict__ parallax, float* __restrict__ depth, float* __restrict__ other,
+                  float* __restrict__ depth_state) {
+  const int bi = blockIdx.y;
+  const M4dMotion m = m4d_load_motion(rot, rot_c, trans, cam_f, cam_c, bi);
+  const int hw = h * w;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
+    const int i = p % w, j = p / w;
+    const long long gp = (long long)bi * hw + p;
+    const float* r = ro + gp * 5;
+    const float para = expf(fminf(fmaxf(r[0], -7.0f), 7.0f)) / scale;                 // :250
+    const M4dPixel px = m4d_pixel_factors(m, i, j);
+    const float d = (px.s / para - m.tz) / px.alpha;                                  // :251
+    parallax[gp] = para;
+    depth[gp] = d;
+    if (depth_state) depth_state[gp] = d;
+    *reinterpret_cast<float4*>(other + gp * 4) = make_float4(r[1], r[2], r[3], r[4]);
+  }
+}
+
+inline int grid1d(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 32) g = 256 * 32;
+  return (int)(g > 0 ? g : 1);
+}
+
+}  // namespace
+
+extern "C" int m4d_normalize_cuts(const float* x, int b, int h, int w, int C, int nbre_cuts,
+                                  float* out, void* stream) {
+  M4D_CHECK_ARG(x && out && b > 0 && h > 0 && w > 0 && C > 0 && nbre_cuts > 0 && C % nbre_cuts == 0);
+  const int nc = C / nbre_cuts;
+  const long long items = (long long)b * h * w * nbre_cuts;
+  const bool vec = (nc % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out) & 15u) == 0);
+  if (vec) hipLaunchKernelGGL(normalize_cuts_kernel<true>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, items, C, nbre_cuts, nc, out);
+  else hipLaunchKernelGGL(normalize_cuts_kernel<false>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, items, C, nbre_cuts, nc, out);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_resize_bilinear_v1(const float* x, int b, int ih, int iw, int c, int oh, int ow,
+                                      float mul, float* out, void* stream) {
+  M4D_CHECK_ARG(x && out && b > 0 && ih > 0 && iw > 0 && c > 0 && oh > 0 && ow > 0);
+  const long long total = (long long)b * oh * ow * c;
+  hipLaunchKernelGGL(resize_bilinear_v1_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
+                     x, ih, iw, c, oh, ow, mul, total, out);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_resize_nearest(const float* x, int b, int ih, int iw, int c, int oh, int ow,
+                                  float* out, void* stream) {
+  M4D_CHECK_ARG(x && out && b > 0 && ih > 0 && iw > 0 && c > 0 && oh > 0 && ow > 0);
+  const long long total = (long long)b * oh * ow * c;
+  hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
+                     x, ih, iw, c, oh, ow, total, out);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_level_pre(const float* prev_l_depth, const float* prev_l_parallax, const float* prev_l_other,
+                             int ph, int pw, const float* depth_prev_t, const float* trans,
+                             const float* cam_f, const float* cam_c, int b, int h, int w,
+                             float* para_prev_l, float* depth_prev_l, float* other_prev_l, float* para_prev_t,
+                             float* f_input, int f_stride, int log_off, int other_off, float log_scale,
+                             void* stream) {
+  M4D_CHECK_ARG(b > 0 && h > 0 && w > 0);
+  const bool any_prev = prev_l_depth || prev_l_parallax || prev_l_other;
+  if (any_prev) M4D_CHECK_ARG(prev_l_depth && prev_l_parallax && prev_l_other && ph > 0 && pw > 0);
+  if (depth_prev_t) M4D_CHECK_ARG(trans && cam_f && cam_c && para_prev_t);
+  if (f_input) M4D_CHECK_ARG(f_stride > 0 && log_off >= 0 && log_off < f_stride && other_off + 4 <= f_stride);
+  if (other_prev_l) M4D_CHECK_ARG((((uintptr_t)other_prev_l) & 15u) == 0);
+  LevelPreArgs a;
+  a.pl_depth = prev_l_depth; a.pl_para = prev_l_parallax; a.pl_other = prev_l_other; a.ph = ph; a.pw = pw;
+  a.depth_prev_t = depth_prev_t; a.trans = trans; a.cam_f = cam_f; a.cam_c = cam_c; a.h = h; a.w = w;
+  a.para_prev_l = para_prev_l; a.depth_prev_l = depth_prev_l; a.other_prev_l = other_prev_l; a.para_prev_t = para_prev_t;
+  a.f_input = f_input; a.f_stride = f_stride; a.log_off = log_off; a.other_off = other_off; a.log_scale = log_scale;
+  int gx = m4d_blocks((long long)h * w, 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(level_pre_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, a);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_level_post(const float* refiner_out, const float* rot, int rot_c, const float* trans,
+                              const float* cam_f, const float* cam_c, int b, int h, int w, float scale,
+                              float* parallax, float* depth, float* other, float* depth_state, void* stream) {
+  M4D_CHECK_ARG(refiner_out && rot && trans && cam_f && cam_c && parallax && depth && other);
+  M4D_CHECK_ARG(b > 0 && h > 0 && w > 0 && (rot_c == 3 || rot_c == 4));
+  M4D_CHECK_ARG((((uintptr_t)other) & 15u) == 0);
+  int gx = m4d_blocks((long long)h * w, 256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(level_post_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream,
+                     refiner_out, rot, rot_c, trans, cam_f, cam_c, h, w, scale, parallax, depth, other, depth_state);
+  return M4D_LAUNCH_RESULT();
+}

@@ -1,0 +1,77 @@
+"""Data-parallel evaluation across the GPUs of one MI355X node.
+
+The reference is single-GPU (main.py:44-46).  Trajectories are independent and
+the recurrent state is per sample, so the path shards along the batch with NO
+collective on the data path: rank r evaluates sequences [r*B/N, (r+1)*B/N) with
+replicated weights.  The only exchange is one all-gather of each rank's Keras
+``Mean`` accumulators -- (total, count) x 7 metrics = 14 floats / rank -- over
+RCCL (``backend="nccl"`` is RCCL on ROCm; xGMI) at the end of the evaluation.
+On CPU (tests) the same code runs over ``gloo``.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """One process per GPU, launched by torch.distributed.run.  Returns
+    (rank, world_size, local_rank, device).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    device = torch.device(f"cuda:{local_rank}") if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+    return rank, world, local_rank, device
+
+
+def shard_range(global_batch, rank, world):
+    """Contiguous shard of sequences owned by ``rank``."""
+    if global_batch % world != 0:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def all_gather_metric_states(metrics, device):
+    """All-gather every rank's (total, count) pairs; returns [world, n_metrics, 2].
+    One small collective; launched after the last batch."""
+    local = torch.stack([m.state(device) for m in metrics]).to(torch.float32).contiguous()   # [n,2]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local.unsqueeze(0)
+    world = dist.get_world_size()
+    out = torch.empty((world,) + tuple(local.shape), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out.view(-1), local.view(-1)) if device.type == "cuda" else \
+        dist.all_gather(list(out.unbind(0)), local)
+    return out
+
+
+def reduce_metric_states(gathered):
+    """Global Keras-``Mean`` result: sum of totals / sum of counts per metric."""
+    total = gathered[..., 0].sum(dim=0)
+    count = gathered[..., 1].sum(dim=0).clamp_min(1.0)
+    return total / count
+
+
+def max_over_ranks(value, device):
+    """MAX-reduce a python float over ranks (bench timing contract)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier(device):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if device.type == "cuda":
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()

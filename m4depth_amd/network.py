@@ -1,0 +1,433 @@
+"""M4Depth network, inference path -- same layer names and call signatures as
+the reference ``m4depth_network.py``.
+
+Host code is Python on PyTorch-ROCm: the encoder (``FeaturePyramid``) and
+decoder (``DispRefiner``) 3x3 convolutions run on MIOpen with TF ``SAME``
+padding semantics; everything else inside ``DepthEstimatorLevel`` -- per-cut
+normalisation, x2 upsampling of the coarser estimate, prev_d2para, the DSCV
+and SNCV cost volumes, the log-parallax features, exp/clip and parallax2depth --
+is hand-written HIP (libm4depth_hip.so) writing straight into the refiner's
+input tensor.  Activations are NHWC float32 (``[b,h,w,c]``), exactly the
+reference's layout; for the convolutions they are viewed as channels-last NCHW
+without a copy.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import network_ops as nops
+from ._lib import lib, dptr, stream_ptr, check, as_f32
+from .synthetic import ENCODER_CHANNELS, REFINER_CHANNELS, f_input_channels, nbre_cuts_for
+
+# m4depth_network.py:21-22
+M4depthAblationParameters = namedtuple('M4depthAblationParameters',
+                                       ('DINL', 'SNCV', 'time_recurr', 'normalize_features',
+                                        'subdivide_features', 'level_memory'),
+                                       defaults=(True, True, True, True, True, True))
+
+_CV_ACCUM = {"fp32_round": 0, "fp16_seq": 1}
+
+# bench.py installs an object with ``run(name, level, thunk)`` here to bracket the
+# hand-written kernels with HIP events on the launch stream; None = no overhead.
+kernel_timer = None
+
+
+def _timed(name, level, thunk):
+    kt = kernel_timer
+    return thunk() if kt is None else kt.run(name, level, thunk)
+
+
+def _to_device_f32(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float32)
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32, device=device)
+
+
+class _Conv3x3SameTF(torch.nn.Module):
+    """Keras Conv2D(filters, 3, strides, padding='same') on NHWC tensors.
+
+    TF 'SAME': out = ceil(in/stride), total pad = max((out-1)*stride + 3 - in, 0),
+    pad_before = total // 2 -- so stride 2 on an even size pads bottom/right only,
+    which torch's symmetric ``padding=1`` does not reproduce."""
+
+    def __init__(self, out_channels, stride, in_channels=None):
+        super().__init__()
+        self.out_channels = out_channels
+        self.stride = stride
+        self.weight = None
+        self.bias = None
+        if in_channels is not None:
+            self._build(in_channels, None)
+
+    def _build(self, in_channels, device):
+        w = torch.empty(self.out_channels, in_channels, 3, 3, device=device)
+        torch.nn.init.kaiming_normal_(w, nonlinearity='relu')       # ks.initializers.HeNormal (:61,:100)
+        self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
+        self.bias = torch.nn.Parameter(torch.zeros(self.out_channels, device=device), requires_grad=False)
+
+    def load_hwio(self, kernel, bias, device):
+        """Load a TF-layout [3,3,Cin,Cout] kernel."""
+        w = _to_device_f32(kernel, device).permute(3, 2, 0, 1)
+        self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
+        self.bias = torch.nn.Parameter(_to_device_f32(bias, device).contiguous(), requires_grad=False)
+
+    def forward(self, x_nhwc):
+        if self.weight is None:
+            self._build(x_nhwc.shape[-1], x_nhwc.device)
+        x = x_nhwc.permute(0, 3, 1, 2)                   # channels-last NCHW view, no copy
+        h, w = x.shape[2:]
+        s = self.stride
+        if s == 1:
+            y = F.conv2d(x, self.weight, self.bias, 1, 1)
+        else:
+            ph = max((-(-h // s) - 1) * s + 3 - h, 0)
+            pw = max((-(-w // s) - 1) * s + 3 - w, 0)
+            x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+            y = F.conv2d(x, self.weight, self.bias, s, 0)
+        y = y.permute(0, 2, 3, 1)
+        return y if y.is_contiguous() else y.contiguous()
+
+
+class DomainNormalization(torch.nn.Module):
+    """m4depth_network.py:24-48 (Zhang et al., domain-invariant stereo matching):
+    (x - mean_hw) / (var_hw + 1e-12) -- var, not std -- then l2-normalise over
+    channels, scale and bias."""
+
+    def __init__(self, regularizer_weight=0.0004):
+        super().__init__()
+        self.regularizer_weight = regularizer_weight
+        self.scale = None
+        self.bias = None
+
+    def _build(self, channels, device):
+        self.scale = torch.nn.Parameter(torch.ones(1, 1, 1, channels, device=device), requires_grad=False)
+        self.bias = torch.nn.Parameter(torch.zeros(1, 1, 1, channels, device=device), requires_grad=False)
+
+    def forward(self, f_map):
+        if self.scale is None:
+            self._build(f_map.shape[-1], f_map.device)
+        mean = f_map.mean(dim=(1, 2), keepdim=True)
+        centred = f_map - mean
+        var = (centred * centred).mean(dim=(1, 2), keepdim=True)
+        n = centred / (var + 1e-12)
+        ss = (n * n).sum(dim=-1, keepdim=True)
+        n = n * torch.rsqrt(torch.clamp_min(ss, 1e-12))               # tf.math.l2_normalize
+        return self.scale * n + self.bias
+
+
+class FeaturePyramid(torch.nn.Module):
+    """Encoder of the network (m4depth_network.py:51-90): per level conv s1 ->
+    [DINL on level 0] -> leaky_relu(0.1) -> conv s2 -> leaky_relu(0.1)."""
+
+    def __init__(self, settings, regularizer_weight=0.0004, trainable=True):
+        super().__init__()
+        self.use_dinl = settings["ablation"].DINL
+        self.out_sizes = ENCODER_CHANNELS[:settings["nbre_lvls"]]
+        cin = [3] + self.out_sizes[:-1]
+        self.conv_layers_s1 = torch.nn.ModuleList([_Conv3x3SameTF(n, 1, ci) for n, ci in zip(self.out_sizes, cin)])
+        self.conv_layers_s2 = torch.nn.ModuleList([_Conv3x3SameTF(n, 2, n) for n in self.out_sizes])
+        self.dn_layers = torch.nn.ModuleList([DomainNormalization(regularizer_weight) for _ in self.out_sizes])
+
+    def forward(self, images):
+        feature_maps = as_f32(images, "images")
+        outputs = []
+        for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):
+            tmp = conv_s1(feature_maps)
+            if self.use_dinl and i == 0:
+                tmp = dn_layer(tmp)
+            tmp = F.leaky_relu(tmp, 0.1)
+            tmp = conv_s2(tmp)
+            feature_maps = F.leaky_relu(tmp, 0.1)
+            outputs.append(feature_maps)
+        return outputs
+
+
+class DispRefiner(torch.nn.Module):
+    """Sub-network refining an input parallax estimate (m4depth_network.py:93-135):
+    convs (128,128,96) then (64,32,16,5), leaky_relu(0.1) after all but the last.
+    Returns ``[out5, prep96]`` like the reference (its ``zip`` quirk, :125-135)."""
+
+    def __init__(self, regularizer_weight=0.0004, in_channels=None):
+        super().__init__()
+        chans = REFINER_CHANNELS
+        cin = [in_channels] + chans[:-1]
+        self.prep_conv_layers = torch.nn.ModuleList([_Conv3x3SameTF(n, 1, ci) for n, ci in zip(chans[:3], cin[:3])])
+        self.est_d_conv_layers = torch.nn.ModuleList([_Conv3x3SameTF(n, 1, ci) for n, ci in zip(chans[3:], cin[3:])])
+
+    def forward(self, feature_map):
+        prev_out = feature_map
+        for conv in self.prep_conv_layers:
+            prev_out = F.leaky_relu(conv(prev_out), 0.1)
+        prep = prev_out
+        n = len(self.est_d_conv_layers)
+        for i, conv in enumerate(self.est_d_conv_layers):
+            prev_out = conv(prev_out)
+            if i < n - 1:                                  # don't activate the last convolution output
+                prev_out = F.leaky_relu(prev_out, 0.1)
+        return [prev_out, prep]
+
+
+class DepthEstimatorLevel(torch.nn.Module):
+    """Stackable decoder level (m4depth_network.py:138-262): outputs a depth and
+    a parallax map.  In inference mode the level owns its temporal memory
+    (``prev_f_maps``, ``depth_prev_t``, :159-163).
+
+    ``settings`` may carry two build extensions next to the reference's keys:
+    ``dscv_range`` (default 4, hard-coded at :221) and ``sncv_range`` (default 3,
+    :232), plus ``cv_accum`` (see oracle [UNPINNED] note on the fp16 mean)."""
+
+    def __init__(self, settings, depth, regularizer_weight=0.0004):
+        super().__init__()
+        self.is_training = settings["is_training"]
+        self.ablation = settings["ablation"]
+        self.dscv_range = int(settings.get("dscv_range", 4))
+        self.sncv_range = int(settings.get("sncv_range", 3))
+        self.cv_accum = settings.get("cv_accum", "fp32_round")
+        self.lvl_depth = depth
+        self.lvl_mul = depth - 3
+        self.nbre_cuts = nbre_cuts_for(depth, self.ablation.subdivide_features)       # :173-176
+        self.f_in = f_input_channels(self.nbre_cuts, self.dscv_range, self.sncv_range,
+                                     self.ablation.level_memory, self.ablation.SNCV, self.ablation.time_recurr)
+        self.disp_refiner = DispRefiner(regularizer_weight=regularizer_weight, in_channels=self.f_in)
+        self.prev_f_maps = None
+        self.depth_prev_t = None
+        self._spare_f = None
+        self.last_f_input = None          # kept for inspection / parity tests
+
+    # -- temporal memory (build(), :153-165) ------------------------------------------
+    def _ensure_state(self, shape, device):
+        if self.prev_f_maps is None or tuple(self.prev_f_maps.shape) != tuple(shape):
+            b, h, w, c = shape
+            self.prev_f_maps = torch.zeros(shape, dtype=torch.float32, device=device)
+            self._spare_f = torch.empty(shape, dtype=torch.float32, device=device)
+            self.depth_prev_t = torch.ones((b, h, w, 1), dtype=torch.float32, device=device)
+
+    def reset_state(self):
+        self.prev_f_maps = None
+        self.depth_prev_t = None
+        self._spare_f = None
+
+    def _vector_processing(self, f_map, out=None):
+        if self.ablation.normalize_features:                                          # :179-182
+            return nops.normalize_cuts(f_map, self.nbre_cuts, out=out)
+        if out is not None:
+            out.copy_(f_map)
+            return out
+        return f_map
+
+    def forward(self, curr_f_maps, prev_l_est, rot, trans, camera, new_traj, prev_f_maps=None, prev_t_depth=None):
+        curr_f_maps = as_f32(curr_f_maps, "curr_f_maps")
+        b, h, w, c = curr_f_maps.shape
+        dev = curr_f_maps.device
+        k = self.nbre_cuts
+        use_state = (not self.is_training) and prev_f_maps is None and prev_t_depth is None    # :192
+        if not self.is_training:
+            self._ensure_state((b, h, w, c), dev)
+        # normalised current features land in the spare state buffer: after the level
+        # ran they ARE the new prev_f_maps (:211, :259) -- a pointer swap, not a copy.
+        curr_f = self._vector_processing(curr_f_maps, out=self._spare_f if not self.is_training else None)
+        if prev_f_maps is not None:
+            prev_f_maps = self._vector_processing(as_f32(prev_f_maps, "prev_f_maps"))
+        if use_state:
+            prev_t_depth = self.depth_prev_t
+            prev_f_maps = self.prev_f_maps
+
+        nt = new_traj
+        if isinstance(nt, torch.Tensor):
+            nt = bool(nt.reshape(-1)[0].item())       # "sequences are synchronized over the batch" (:207)
+        elif not isinstance(nt, bool):
+            nt = bool(np.asarray(nt).reshape(-1)[0])
+
+        if prev_t_depth is None or nt:                                                 # :208-214
+            para_prev_l, depth_prev_l, other_prev_l, _ = nops.level_pre(prev_l_est, None, None, None, b, h, w, dev)
+            if not self.is_training:
+                self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
+                self.depth_prev_t.fill_(1000.)
+            return {"depth": depth_prev_l, "parallax": para_prev_l, "other": other_prev_l}
+
+        r = self.dscv_range
+        ncp = 2 * r + 1
+        F_in = self.f_in
+        f_input = torch.empty((b, h, w, F_in), dtype=torch.float32, device=dev)
+        log_off = ncp * k
+        other_off = log_off + 1 if self.ablation.level_memory else -1
+        sncv_off = log_off + 1 + (4 if self.ablation.level_memory else 0)
+        scale = float(2.0 ** self.lvl_mul)
+        # "preprocessor" (:216-242): upsample coarser estimate, prev_d2para, log / memory features
+        para_prev_l, depth_prev_l, other_prev_l, para_prev_t = nops.level_pre(
+            prev_l_est, as_f32(prev_t_depth, "prev_t_depth"), trans, camera, b, h, w, dev,
+            f_input=f_input, log_off=log_off, other_off=other_off, log_scale=scale)
+        rot_t = as_f32(rot, "rot")
+        tr = as_f32(trans, "trans").reshape(b, 3)
+        cf = as_f32(camera["f"], "camera['f']").reshape(b, 2)
+        cc = as_f32(camera["c"], "camera['c']").reshape(b, 2)
+        if rot_t.dim() != 2 or rot_t.shape[1] not in (3, 4):
+            raise ValueError('Rotation must be expressed as a small angle (x,y,z) or a quaternion (w,x,y,z)')
+        fin_ptr = f_input.data_ptr()
+        time_recurr = self.ablation.time_recurr
+        log_ptr = ctypes.c_void_p(fin_ptr + 4 * (F_in - 1)) if time_recurr else None
+        # DSCV (:220-221) -> f_input[..., 0:9k]; time-recurrence feature (:238) -> f_input[..., -1]
+        prev_f = as_f32(prev_f_maps, "prev_f_maps")
+        check(_timed("dscv", self.lvl_depth, lambda: lib.m4d_dscv_fwd(
+            dptr(curr_f), dptr(prev_f), dptr(para_prev_t), dptr(para_prev_l), dptr(rot_t), rot_t.shape[1],
+            dptr(tr), dptr(cf), dptr(cc), b, h, w, c, r, k, _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr),
+            F_in, None, log_ptr, F_in, scale, None, stream_ptr())), "m4d_dscv_fwd")
+        if self.ablation.SNCV:                                                         # :231-233
+            check(_timed("sncv", self.lvl_depth, lambda: lib.m4d_sncv_fwd(
+                dptr(curr_f), dptr(curr_f), b, h, w, c, self.sncv_range, 1, k,
+                ctypes.c_void_p(fin_ptr + 4 * sncv_off), F_in, stream_ptr())), "m4d_sncv_fwd")
+        self.last_f_input = f_input
+        # "depth_estimator" (:244-260)
+        prev_out = self.disp_refiner(f_input)
+        para_curr_l, depth, other = nops.level_post(prev_out[0], rot_t, tr, {"f": cf, "c": cc}, scale,
+                                                    depth_state=self.depth_prev_t if not self.is_training else None)
+        if not self.is_training:
+            self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
+        return {"other": other, "depth": depth, "parallax": para_curr_l}
+
+
+class DepthEstimatorPyramid(torch.nn.Module):
+    """Decoder (m4depth_network.py:265-323): coarse -> fine loop over levels for
+    every sequence step; level of depth l sees intrinsics / 2**l (:300-302)."""
+
+    def __init__(self, settings, regularizer_weight=0.0004, trainable=True):
+        super().__init__()
+        self.levels = torch.nn.ModuleList(
+            [DepthEstimatorLevel(settings, i + 1, regularizer_weight=regularizer_weight)
+             for i in range(settings["nbre_lvls"])])
+        self.is_training = settings["is_training"]
+        self.is_unsupervised = False
+
+    def forward(self, f_maps_pyrs, traj_samples, camera, training=False):
+        d_est_seq = []
+        n_lvls = len(self.levels)
+        for seq_i, (f_pyr_curr, sample) in enumerate(zip(f_maps_pyrs, traj_samples)):
+            rot = sample['rot']
+            trans = sample['trans']
+            cnter = float(n_lvls)
+            d_est_curr = None
+            for l in range(n_lvls):
+                lvl = n_lvls - 1 - l
+                f_maps_curr, level = f_pyr_curr[lvl], self.levels[lvl]
+                f_maps_prev = None
+                d_est_prev = None
+                if self.is_training and seq_i != 0:
+                    f_maps_prev = f_maps_pyrs[seq_i - 1][-l - 1]
+                    d_est_prev = d_est_seq[-1][-l - 1]["depth"]
+                local_camera = {"f": camera["f"] / 2. ** cnter, "c": camera["c"] / 2. ** cnter}
+                d_est = None if d_est_curr is None else dict(d_est_curr[-1])
+                est = level(f_maps_curr, d_est, rot, trans, local_camera, sample["new_traj"],
+                            prev_f_maps=f_maps_prev, prev_t_depth=d_est_prev)
+                d_est_curr = [est] if d_est_curr is None else d_est_curr + [est]
+                cnter -= 1.
+            d_est_seq.append(d_est_curr[::-1])
+        return d_est_seq
+
+
+class M4Depth(torch.nn.Module):
+    """MI355X-native model of M4Depth (m4depth_network.py:325-369, 433-489).
+
+    ``model([traj_samples, camera])`` -> ``{"depth": [b,H,W,1]}`` (nearest x2
+    upsample of the finest level); ``test_step`` / ``predict_step`` /
+    ``compile`` / ``evaluate`` mirror the Keras harness used by ``main.py``."""
+
+    def __init__(self, depth_type="map", nbre_levels=6, is_training=False, ablation_settings=None,
+                 dscv_range=4, sncv_range=3, cv_accum="fp32_round"):
+        super().__init__()
+        self.ablation_settings = M4depthAblationParameters() if ablation_settings is None else ablation_settings
+        self.model_settings = {
+            "nbre_lvls": nbre_levels,
+            "is_training": is_training,
+            "ablation": self.ablation_settings,
+            "dscv_range": dscv_range,
+            "sncv_range": sncv_range,
+            "cv_accum": cv_accum,
+        }
+        self.depth_type = depth_type
+        self.encoder = FeaturePyramid(self.model_settings, regularizer_weight=0.)
+        self.d_estimator = DepthEstimatorPyramid(self.model_settings, regularizer_weight=0.)
+        self.step_counter = 0
+        self.compiled_metrics = []
+        self.last_estimates = None
+
+    # -- weights -----------------------------------------------------------------------
+    def load_numpy_weights(self, weights, device):
+        """Load the dict produced by ``synthetic.init_weights`` (TF HWIO kernels)."""
+        for i in range(self.model_settings["nbre_lvls"]):
+            self.encoder.conv_layers_s1[i].load_hwio(weights[f"enc.s1.{i}.kernel"], weights[f"enc.s1.{i}.bias"], device)
+            self.encoder.conv_layers_s2[i].load_hwio(weights[f"enc.s2.{i}.kernel"], weights[f"enc.s2.{i}.bias"], device)
+        dn = self.encoder.dn_layers[0]
+        dn.scale = torch.nn.Parameter(_to_device_f32(weights["enc.dn.0.scale"], device).reshape(1, 1, 1, -1), requires_grad=False)
+        dn.bias = torch.nn.Parameter(_to_device_f32(weights["enc.dn.0.bias"], device).reshape(1, 1, 1, -1), requires_grad=False)
+        for lvl in self.d_estimator.levels:
+            convs = list(lvl.disp_refiner.prep_conv_layers) + list(lvl.disp_refiner.est_d_conv_layers)
+            for i, conv in enumerate(convs):
+                conv.load_hwio(weights[f"lvl.{lvl.lvl_depth}.conv.{i}.kernel"], weights[f"lvl.{lvl.lvl_depth}.conv.{i}.bias"], device)
+        return self
+
+    def reset_state(self):
+        for lvl in self.d_estimator.levels:
+            lvl.reset_state()
+
+    # -- forward -------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, data, training=False):
+        traj_samples, camera = data[0], data[1]
+        self.step_counter += 1
+        f_maps_pyrs = [self.encoder(sample['RGB_im']) for sample in traj_samples]
+        d_maps_pyrs = self.d_estimator(f_maps_pyrs, traj_samples, camera, training)
+        self.last_estimates = d_maps_pyrs          # per step, per level {depth, parallax, other} (fine -> coarse)
+        if training:
+            return d_maps_pyrs
+        h, w = traj_samples[-1]['RGB_im'].shape[1:3]
+        return {"depth": nops.resize_nearest(d_maps_pyrs[-1][0]["depth"], h, w)}
+
+    # -- Keras-harness mirror (main.py:127-133) -------------------------------------------
+    def compile(self, metrics=None, **_unused):
+        self.compiled_metrics = list(metrics or [])
+
+    @torch.no_grad()
+    def test_step(self, data):
+        """m4depth_network.py:433-474."""
+        if data["depth"].dim() == 5:            # sequence input: metrics on the last frame only (:439-455)
+            seq_len = data["depth"].shape[1]
+            traj_samples = [{} for _ in range(seq_len)]
+            for key in ["depth", "RGB_im", "new_traj", "rot", "trans"]:
+                for i, item in enumerate(torch.unbind(data[key], dim=1)):
+                    traj_samples[i][key] = item
+            preds = self([traj_samples, data["camera"]], training=False)
+            gt = data["depth"][:, -1]
+            est = preds["depth"]
+            new_traj = False
+        else:                                   # one frame of a stream (:457-460)
+            preds = self([[data], data["camera"]], training=False)
+            gt = data["depth"]
+            est = preds["depth"]
+            nt = data["new_traj"]
+            new_traj = bool(nt.reshape(-1)[0].item()) if isinstance(nt, torch.Tensor) else bool(np.asarray(nt).reshape(-1)[0])
+        max_d = 80.
+        gt = torch.clamp(gt, 0.0, max_d)                                               # :465-467
+        est = torch.clamp(est, 0.001, max_d)
+        if not new_traj:                                                               # :469-470
+            for m in self.compiled_metrics:
+                m.update_state(gt, est)
+        return {m.name: m.result() for m in self.compiled_metrics}
+
+    @torch.no_grad()
+    def predict_step(self, data):
+        """m4depth_network.py:476-489."""
+        preds = self([[data], data["camera"]], training=False)
+        return {"image": data["RGB_im"], "depth": preds["depth"], "new_traj": data["new_traj"]}
+
+    def evaluate(self, dataset):
+        for m in self.compiled_metrics:
+            m.reset_state()
+        out = {}
+        for batch in dataset:
+            out = self.test_step(batch)
+        return [float(out[m.name]) for m in self.compiled_metrics]

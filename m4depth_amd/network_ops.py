@@ -1,0 +1,93 @@
+"""DepthEstimatorLevel glue kernels (m4depth_network.py:179-204, 218, 224-260)
+exposed as tensor functions.  All dispatch to libm4depth_hip.so.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import lib, dptr, stream_ptr, check, as_f32
+
+
+def normalize_cuts(x, nbre_cuts, out=None):
+    """Per-cut tf.linalg.normalize of m4depth_network.py:179-189 (no epsilon)."""
+    x = as_f32(x, "x")
+    b, h, w, C = x.shape
+    if C % nbre_cuts != 0:
+        raise ValueError(f"nbre_cuts={nbre_cuts} does not divide the {C} feature channels")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.m4d_normalize_cuts(dptr(x, "x"), b, h, w, C, int(nbre_cuts), dptr(out, "out"), stream_ptr()),
+          "m4d_normalize_cuts")
+    return out
+
+
+def resize_bilinear_v1(x, out_h, out_w, mul=1.0):
+    """tf.compat.v1.image.resize_bilinear with its defaults (legacy coordinates:
+    no half-pixel offset), m4depth_network.py:202-204."""
+    x = as_f32(x, "x")
+    b, ih, iw, c = x.shape
+    out = torch.empty((b, out_h, out_w, c), dtype=torch.float32, device=x.device)
+    check(lib.m4d_resize_bilinear_v1(dptr(x, "x"), b, ih, iw, c, int(out_h), int(out_w), float(mul), dptr(out),
+                                     stream_ptr()), "m4d_resize_bilinear_v1")
+    return out
+
+
+def resize_nearest(x, out_h, out_w):
+    """tf.image.resize(method=NEAREST_NEIGHBOR), m4depth_network.py:368."""
+    x = as_f32(x, "x")
+    b, ih, iw, c = x.shape
+    out = torch.empty((b, out_h, out_w, c), dtype=torch.float32, device=x.device)
+    check(lib.m4d_resize_nearest(dptr(x, "x"), b, ih, iw, c, int(out_h), int(out_w), dptr(out), stream_ptr()),
+          "m4d_resize_nearest")
+    return out
+
+
+def level_pre(prev_l_est, depth_prev_t, trans, camera, b, h, w, device, f_input=None, log_off=0,
+              other_off=-1, log_scale=1.0):
+    """Fused upsample of the coarser level's estimate (+ prev_d2para of the
+    temporal depth state, + the log-parallax / level-memory features written
+    straight into ``f_input``).  Returns (para_prev_l, depth_prev_l,
+    other_prev_l, para_prev_t or None)."""
+    para = torch.empty((b, h, w, 1), dtype=torch.float32, device=device)
+    depth = torch.empty_like(para)
+    other = torch.empty((b, h, w, 4), dtype=torch.float32, device=device)
+    para_t = torch.empty_like(para) if depth_prev_t is not None else None
+    if prev_l_est is not None:
+        pd = as_f32(prev_l_est["depth"], "prev_l_est['depth']")
+        pp = as_f32(prev_l_est["parallax"], "prev_l_est['parallax']")
+        po = as_f32(prev_l_est["other"], "prev_l_est['other']")
+        ph, pw = pd.shape[1:3]
+    else:
+        pd = pp = po = None
+        ph = pw = 0
+    tr = f = c = None
+    if depth_prev_t is not None:
+        tr = as_f32(trans, "trans").reshape(b, 3)
+        f = as_f32(camera["f"], "camera['f']").reshape(b, 2)
+        c = as_f32(camera["c"], "camera['c']").reshape(b, 2)
+    f_stride = f_input.shape[-1] if f_input is not None else 0
+    check(lib.m4d_level_pre(dptr(pd), dptr(pp), dptr(po), ph, pw, dptr(depth_prev_t, "depth_prev_t"), dptr(tr),
+                            dptr(f), dptr(c), b, h, w, dptr(para), dptr(depth), dptr(other), dptr(para_t),
+                            dptr(f_input, "f_input"), f_stride, int(log_off), int(other_off), float(log_scale),
+                            stream_ptr()), "m4d_level_pre")
+    return para, depth, other, para_t
+
+
+def level_post(refiner_out, rot, trans, camera, scale, depth_state=None):
+    """Fused tail of a level (m4depth_network.py:247-260): returns (parallax,
+    depth, other); ``depth_state`` (optional) receives the depth as well."""
+    ro = as_f32(refiner_out, "refiner_out")
+    b, h, w, five = ro.shape
+    if five != 5:
+        raise ValueError(f"refiner output must have 5 channels, got {five}")
+    rot = as_f32(rot, "rot")
+    tr = as_f32(trans, "trans").reshape(b, 3)
+    f = as_f32(camera["f"], "camera['f']").reshape(b, 2)
+    c = as_f32(camera["c"], "camera['c']").reshape(b, 2)
+    para = torch.empty((b, h, w, 1), dtype=torch.float32, device=ro.device)
+    depth = torch.empty_like(para)
+    other = torch.empty((b, h, w, 4), dtype=torch.float32, device=ro.device)
+    check(lib.m4d_level_post(dptr(ro), dptr(rot, "rot"), rot.shape[1], dptr(tr), dptr(f), dptr(c), b, h, w,
+                             float(scale), dptr(para), dptr(depth), dptr(other), dptr(depth_state, "depth_state"),
+                             stream_ptr()), "m4d_level_post")
+    return para, depth, other

@@ -1,0 +1,104 @@
+"""Seeded synthetic trajectories and random-init weights (host side, numpy).
+
+There is no dataset and no trained checkpoint in the build environment
+(reference ``data.zip`` / ``pretrained_weights.zip`` are absent), so both the
+parity tests and ``bench.py`` run on data of the reference's sample-dict shape
+(dataloaders/generic.py:23-34): ``RGB_im [b,H,W,3]``, ``depth [b,H,W,1]``,
+``rot [b,4]`` (quaternion w,x,y,z), ``trans [b,3]``, ``new_traj [b]`` and
+``camera {f [b,2], c [b,2]}`` with the Mid-Air intrinsics rule
+f = c = (0.5 W, 0.5 H) (dataloaders/midair.py:20-23).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+ENCODER_CHANNELS = [16, 32, 64, 96, 128, 192]          # m4depth_network.py:59
+REFINER_CHANNELS = [128, 128, 96, 64, 32, 16, 5]       # m4depth_network.py:103,109
+ABLATION_FIELDS = ('DINL', 'SNCV', 'time_recurr', 'normalize_features', 'subdivide_features', 'level_memory')
+
+
+def nbre_cuts_for(depth, subdivide_features=True):
+    """m4depth_network.py:173-176."""
+    return 2 ** (depth // 2) if subdivide_features else 1
+
+
+def f_input_channels(nbre_cuts, dscv_range=4, sncv_range=3, level_memory=True, SNCV=True, time_recurr=True):
+    """Width of the refiner input assembled at m4depth_network.py:224-242."""
+    n = (2 * dscv_range + 1) * nbre_cuts + 1
+    if level_memory:
+        n += 4
+    if SNCV:
+        n += (2 * sncv_range + 1) ** 2 * nbre_cuts
+    if time_recurr:
+        n += 1
+    return n
+
+
+def init_weights(nbre_levels=6, seed=42, dscv_range=4, sncv_range=3, ablation=None, bias_std=0.0):
+    """Random-init weights of the M4Depth architecture.
+
+    Conv kernels ~ N(0, 2/fan_in) in TF's HWIO layout [3,3,Cin,Cout] (Keras
+    HeNormal is the truncated variant; the trained weights are unavailable
+    anyway), biases ~ N(0, bias_std^2) (Keras default: zeros), DINL scale 1 /
+    bias 0 (m4depth_network.py:35-38).  Keys: ``enc.s1.<i>``, ``enc.s2.<i>``
+    (i = 0..L-1), ``enc.dn.0``, ``lvl.<depth>.conv.<0..6>`` (depth = 1..L)."""
+    rng = np.random.default_rng(seed)
+    ab = dict(zip(ABLATION_FIELDS, [True] * 6))
+    if ablation:
+        ab.update(ablation if isinstance(ablation, dict) else ablation._asdict())
+    W = {}
+
+    def conv(name, cin, cout):
+        W[name + ".kernel"] = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+        W[name + ".bias"] = (rng.standard_normal([cout]) * bias_std).astype(np.float32)
+
+    cin = 3
+    for i, co in enumerate(ENCODER_CHANNELS[:nbre_levels]):
+        conv(f"enc.s1.{i}", cin, co)
+        conv(f"enc.s2.{i}", co, co)
+        cin = co
+    W["enc.dn.0.scale"] = np.ones([ENCODER_CHANNELS[0]], np.float32)
+    W["enc.dn.0.bias"] = np.zeros([ENCODER_CHANNELS[0]], np.float32)
+    for d in range(1, nbre_levels + 1):
+        k = nbre_cuts_for(d, ab["subdivide_features"])
+        cin = f_input_channels(k, dscv_range, sncv_range, ab["level_memory"], ab["SNCV"], ab["time_recurr"])
+        for i, co in enumerate(REFINER_CHANNELS):
+            conv(f"lvl.{d}.conv.{i}", cin, co)
+            cin = co
+    return W
+
+
+def _box_blur5(x):
+    """5x5 box blur over H,W (edge-replicated) so that warps see smooth images."""
+    p = np.pad(x, [(0, 0), (2, 2), (2, 2), (0, 0)], mode="edge")
+    h, w = x.shape[1:3]
+    acc = np.zeros_like(x, dtype=np.float64)
+    for dy in range(5):
+        for dx in range(5):
+            acc += p[:, dy:dy + h, dx:dx + w]
+    return (acc / 25.0).astype(np.float32)
+
+
+def make_sequence(batch, seq_len, height, width, seed=1234):
+    """One batch of ``seq_len``-frame synthetic trajectories.
+
+    Returns (traj_samples, camera): a list of per-frame sample dicts and the
+    full-resolution intrinsics, exactly what ``M4Depth.call`` takes as
+    ``data = [traj_samples, camera]`` (m4depth_network.py:352-354)."""
+    rng = np.random.default_rng(seed)
+    cam = {"f": np.tile(np.array([[0.5 * width, 0.5 * height]], np.float32), [batch, 1]),
+           "c": np.tile(np.array([[0.5 * width, 0.5 * height]], np.float32), [batch, 1])}
+    samples = []
+    for t in range(seq_len):
+        rgb = _box_blur5(rng.random([batch, height, width, 3], dtype=np.float32))
+        depth = (1.0 + 79.0 * rng.random([batch, height, width, 1], dtype=np.float32)).astype(np.float32)
+        aa = rng.normal(0.0, 0.01, [batch, 3])
+        ang = np.linalg.norm(aa, axis=1, keepdims=True)
+        axis = aa / np.maximum(ang, 1e-12)
+        quat = np.concatenate([np.cos(ang / 2), axis * np.sin(ang / 2)], axis=1).astype(np.float32)
+        trans = rng.normal([0.0, 0.0, 0.3], 0.05, [batch, 3])
+        nrm = np.linalg.norm(trans, axis=1, keepdims=True)
+        trans = np.where(nrm > 1e-3, trans, np.array([[0.0, 0.0, 0.3]])).astype(np.float32)   # t = 0 is 0/0 in the reference
+        samples.append({"RGB_im": rgb, "depth": depth, "rot": quat, "trans": trans,
+                        "new_traj": np.full([batch], t == 0)})
+    return samples, cam

@@ -1,0 +1,256 @@
+"""HIP kernels (through the C ABI / the reference-named Python ops) vs the CPU
+oracle and the committed golden vectors.
+
+Tolerances (written here, as the contract demands):
+  * int32 bilinear index grids ........................ bit-exact
+  * warps, back_project, converters, DSCV cv, SNCV,
+    normalisation, resizes (+,-,*,/,sqrt only) ........ bit-exact (float32 bit pattern)
+  * anything through exp/log (libm differs) ........... 2e-6 relative
+  * back_project_grad scatter (atomic order) .......... 1e-5 absolute
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import m4depth_oracle as O
+from helpers import F, camera_np, motion_np, to_dev, npy, assert_bits_equal, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    import m4depth_amd
+    return m4depth_amd
+
+
+# ------------------------------------------------------------------------------- golden
+def test_golden_warp_and_backproject(M, dev, golden):
+    g = golden("ops")
+    out, idx = M.dense_image_warp(to_dev(g["warp_img"], dev), to_dev(g["warp_flow"], dev), return_index=True)
+    assert np.array_equal(npy(idx), g["warp_idx"])                    # bit-exact index grid
+    assert_bits_equal(npy(out), g["warp_out"], "dense_image_warp")
+    bp = M.back_project(to_dev(g["bp_in"], dev), to_dev(g["bp_coords"], dev))
+    assert_bits_equal(npy(bp), g["bp_out"], "back_project")
+    gi, gc = M.back_project_grad(to_dev(g["bp_in"], dev), to_dev(g["bp_coords"], dev), to_dev(g["bp_grad"], dev))
+    assert_bits_equal(npy(gc), g["bp_gco"], "back_project_grad coords")
+    assert np.max(np.abs(npy(gi) - g["bp_gin"])) < 1e-5
+
+
+def test_golden_converters_and_reproject(M, dev, golden):
+    g = golden("ops")
+    cam = to_dev(camera_np(2, 10, 14), dev)
+    for tag in ("q", "e"):
+        rot, trans, depth = [to_dev(g[f"cv_{tag}_{k}"], dev) for k in ("rot", "trans", "depth")]
+        para = M.depth2parallax(depth, rot, trans, cam)
+        assert_bits_equal(npy(para), g[f"cv_{tag}_d2p"], "depth2parallax")
+        assert_bits_equal(npy(M.parallax2depth(para, rot, trans, cam)), g[f"cv_{tag}_p2d"], "parallax2depth")
+        assert_bits_equal(npy(M.prev_d2para(depth, rot, trans, cam)), g[f"cv_{tag}_pd2p"], "prev_d2para")
+        assert_bits_equal(npy(M.recompute_depth(depth, rot, trans, cam)), g[f"cv_{tag}_recompute"], "recompute_depth")
+    out, (pmr, rotc) = M.reproject(to_dev(g["rp_map"], dev), to_dev(g["rp_depth"], dev), to_dev(g["rp_rot"], dev),
+                                   to_dev(g["rp_trans"], dev), cam)
+    assert_bits_equal(npy(out), g["rp_out"], "reproject")
+    assert_bits_equal(npy(pmr), g["rp_pmr"], "reproject aux 0")
+    assert_bits_equal(npy(rotc), g["rp_rotc"], "reproject aux 1")
+
+
+def test_golden_resize_normalize(M, dev, golden):
+    from m4depth_amd import network_ops as nops
+    g = golden("ops")
+    x = to_dev(g["rs_x"], dev)
+    assert_bits_equal(npy(nops.resize_bilinear_v1(x, 10, 14)), g["rs_bil_x2"], "resize x2")
+    assert_bits_equal(npy(nops.resize_bilinear_v1(x, 9, 13)), g["rs_bil_odd"], "resize odd")
+    assert_bits_equal(npy(nops.resize_nearest(x, 10, 14)), g["rs_near_x2"], "nearest x2")
+    assert_bits_equal(npy(nops.resize_nearest(x, 11, 15)), g["rs_near_odd"], "nearest odd")
+    nx = to_dev(g["nm_x"], dev)
+    for k in (1, 4, 3):
+        assert_bits_equal(npy(nops.normalize_cuts(nx, k)), g[f"nm_k{k}"], f"normalize k={k}")
+
+
+@pytest.mark.parametrize("tag", list("abcd"))
+def test_golden_cost_volumes(M, dev, golden, tag):
+    g = golden("cost_volumes")
+    b, h, w, C, k, rd, rs = [int(v) for v in g[f"{tag}_meta"]]
+    cam = to_dev(camera_np(b, h, w), dev)
+    c1, c2, dpt, disp, rot, trans = [to_dev(g[f"{tag}_{n}"], dev) for n in ("c1", "c2", "dpt", "disp", "rot", "trans")]
+    for acc in ("fp32_round", "fp16_seq"):
+        cv, pd, idx = M.get_parallax_sweeping_cv(c1, c2, dpt, disp, rot, trans, cam, rd, k, cv_accum=acc,
+                                                 return_index=True)
+        assert np.array_equal(npy(idx), g[f"{tag}_idx"]), "DSCV index grid must be bit-exact"
+        assert_bits_equal(npy(cv), g[f"{tag}_cv_{acc}"], f"dscv cv {acc}")
+        assert_bits_equal(npy(pd), g[f"{tag}_prev_disp"], "dscv prev_disp")
+    assert_bits_equal(npy(M.cost_volume(c1, c2, rs, nbre_cuts=k)), g[f"{tag}_sncv"], "sncv")
+    assert_bits_equal(npy(M.cost_volume(c1, c1, rs, nbre_cuts=k)), g[f"{tag}_sncv_auto"], "sncv auto")
+    if tag == "a":
+        assert_bits_equal(npy(M.cost_volume(c1, c2, 2, dilation_rate=2, nbre_cuts=k)), g["a_sncv_dil2"], "sncv dil 2")
+
+
+# ---------------------------------------------------------------- seeded, against the oracle
+LEVEL_GEOM = [(1, 48, 80, 16, 1), (2, 24, 40, 32, 2), (3, 24, 40, 64, 2), (4, 12, 20, 96, 4), (5, 12, 20, 128, 4),
+              (6, 6, 20, 192, 8)]
+
+
+@pytest.mark.parametrize("lvl,h,w,C,k", LEVEL_GEOM)
+def test_dscv_sncv_level_geometries(M, dev, lvl, h, w, C, k):
+    """Every (C, cuts) pair of the 6-level pyramid, batch 2, DSCV r=4 / SNCV r=3."""
+    rng = np.random.default_rng(100 + lvl)
+    b = 2
+    cam = camera_np(b, h, w)
+    rot, trans = motion_np(rng, b, t_scale=(3.0, 3.0, 1.0))
+    c1 = O.normalize_cuts(rng.standard_normal([b, h, w, C]).astype(F), k)
+    c2 = O.normalize_cuts(rng.standard_normal([b, h, w, C]).astype(F), k)
+    disp = (0.2 + 6.0 * rng.random([b, h, w, 1])).astype(F)
+    dpt = (0.2 + 6.0 * rng.random([b, h, w, 1])).astype(F)
+    ocv, opd, oy, ox = O.get_parallax_sweeping_cv(c1, c2, dpt, disp, rot, trans, cam, 4, k, return_index=True)
+    cv, pd, idx = M.get_parallax_sweeping_cv(*to_dev([c1, c2, dpt, disp, rot, trans], dev), to_dev(cam, dev), 4, k,
+                                             return_index=True)
+    assert np.array_equal(npy(idx), np.stack([oy, ox], -1))
+    assert_bits_equal(npy(cv), ocv, "dscv")
+    assert_bits_equal(npy(pd), opd, "prev_disp")
+    sn = M.cost_volume(to_dev(c1, dev), to_dev(c1, dev), 3, nbre_cuts=k)
+    assert_bits_equal(npy(sn), O.cost_volume(c1, c1, 3, nbre_cuts=k), "sncv")
+
+
+def test_warp_edge_cases(M, dev):
+    rng = np.random.default_rng(7)
+    img = rng.standard_normal([1, 2, 2, 1]).astype(F)                 # minimum legal size
+    fl = (rng.standard_normal([1, 2, 2, 2]) * 2).astype(F)
+    assert_bits_equal(npy(M.dense_image_warp(to_dev(img, dev), to_dev(fl, dev))), O.dense_image_warp(img, fl), "2x2")
+    img3 = rng.standard_normal([5, 6, 3]).astype(F)                   # rank-3 image (dense_image_warp.py:229-232)
+    fl3 = (rng.standard_normal([1, 5, 6, 2])).astype(F)
+    got = M.dense_image_warp(to_dev(img3, dev), to_dev(fl3, dev))
+    assert got.shape == (5, 6, 3)
+    assert_bits_equal(npy(got), O.dense_image_warp(img3[None], fl3)[0], "rank 3")
+    with pytest.raises(ValueError):
+        M.dense_image_warp(to_dev(np.zeros([1, 1, 4, 2], F), dev), to_dev(np.zeros([1, 1, 4, 2], F), dev))
+    # the BackProject route of dense_image_warp.py:246-253
+    import m4depth_amd.dense_image_warp  # noqa: F401
+    import sys
+    mod = sys.modules["m4depth_amd.dense_image_warp"]
+    img = rng.standard_normal([2, 7, 9, 4]).astype(F)
+    fl = (rng.standard_normal([2, 7, 9, 2]) * 4).astype(F)
+    mod.use_cuda_backproject = True
+    try:
+        got = mod.dense_image_warp(to_dev(img, dev), to_dev(fl, dev))
+    finally:
+        mod.use_cuda_backproject = False
+    assert_bits_equal(npy(got), O.dense_image_warp(img, fl, use_backproject=True), "op route")
+
+
+def test_interpolate_bilinear_free_points(M, dev):
+    rng = np.random.default_rng(8)
+    grid = rng.standard_normal([2, 6, 7, 3]).astype(F)
+    q = (rng.random([2, 11, 2]) * np.array([7.0, 8.0]) - 1.0).astype(F)
+    out, idx = M._interpolate_bilinear(to_dev(grid, dev), to_dev(q, dev), return_index=True)
+    o, y0, x0 = O.interpolate_bilinear(grid, q, return_index=True)
+    assert np.array_equal(npy(idx), np.stack([y0, x0], -1))
+    assert_bits_equal(npy(out), o, "interpolate_bilinear ij")
+    out_xy = M._interpolate_bilinear(to_dev(grid, dev), to_dev(q[..., ::-1].copy(), dev), indexing='xy')
+    assert_bits_equal(npy(out_xy), o, "interpolate_bilinear xy")
+    with pytest.raises(ValueError):
+        M._interpolate_bilinear(to_dev(grid, dev), to_dev(q, dev), indexing='zz')
+
+
+def test_backproject_autograd(M, dev):
+    rng = np.random.default_rng(9)
+    inp = torch.tensor(rng.standard_normal([1, 5, 6, 1, 3]).astype(F), device=dev, requires_grad=True)
+    co = torch.tensor((rng.random([1, 5, 6, 2, 1, 2]) * np.array([5.0, 4.0])).astype(F), device=dev, requires_grad=True)
+    out = M.back_project(inp, co)
+    g = torch.tensor(rng.standard_normal(list(out.shape)).astype(F), device=dev)
+    out.backward(g)
+    gi, gc = O.back_project_grad(npy(inp), npy(co), npy(g))
+    assert np.max(np.abs(npy(inp.grad) - gi)) < 1e-5
+    assert_bits_equal(npy(co.grad), gc, "coords grad")
+
+
+def test_error_behaviour(M, dev):
+    z = torch.zeros([1, 4, 4, 1], device=dev)
+    cam = to_dev(camera_np(1, 4, 4), dev)
+    with pytest.raises(ValueError):                                    # get_rot_mat, depth_operations.py:53
+        M.parallax2depth(z, torch.zeros([1, 5], device=dev), torch.zeros([1, 3], device=dev), cam)
+    with pytest.raises(ValueError):                                    # reproject, depth_operations.py:78-79
+        M.reproject(torch.zeros([1, 4, 4, 2], device=dev), torch.zeros([1, 3, 4, 1], device=dev),
+                    torch.zeros([1, 4], device=dev), torch.zeros([1, 3], device=dev), cam)
+    with pytest.raises(RuntimeError):                                  # no CPU fallback
+        M.cost_volume(torch.zeros([1, 4, 4, 4]), torch.zeros([1, 4, 4, 4]), 1)
+    with pytest.raises(ValueError):
+        M.cost_volume(torch.zeros([1, 4, 4, 6], device=dev), torch.zeros([1, 4, 4, 6], device=dev), 1, nbre_cuts=4)
+
+
+def test_level_pre_post_kernels(M, dev):
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(10)
+    b, h, w = 2, 12, 20
+    rot, trans = motion_np(rng, b)
+    cam = camera_np(b, h, w)
+    prev = {"depth": (1 + 50 * rng.random([b, 6, 10, 1])).astype(F),
+            "parallax": (0.1 + 3 * rng.random([b, 6, 10, 1])).astype(F),
+            "other": rng.standard_normal([b, 6, 10, 4]).astype(F)}
+    dprev = (1 + 50 * rng.random([b, h, w, 1])).astype(F)
+    f_in = torch.full((b, h, w, 12), -7.0, device=dev)
+    para, depth, other, para_t = nops.level_pre(to_dev(prev, dev), to_dev(dprev, dev), to_dev(trans, dev),
+                                                to_dev(cam, dev), b, h, w, dev, f_input=f_in, log_off=3,
+                                                other_off=4, log_scale=0.25)
+    op = O.resize_bilinear_v1(prev["parallax"], h, w) * F(2.)
+    assert_bits_equal(npy(para), op, "para_prev_l")
+    assert_bits_equal(npy(depth), O.resize_bilinear_v1(prev["depth"], h, w), "depth_prev_l")
+    assert_bits_equal(npy(other), O.resize_bilinear_v1(prev["other"], h, w), "other_prev_l")
+    assert_bits_equal(npy(para_t), O.prev_d2para(dprev, rot, trans, cam), "para_prev_t")
+    fi = npy(f_in)
+    assert np.max(rel_err(fi[..., 3], np.log(op[..., 0] * F(0.25)), 1e-3)) < 2e-6
+    assert_bits_equal(fi[..., 4:8], npy(other), "f_input other")
+    assert np.all(fi[..., :3] == -7.0) and np.all(fi[..., 8:] == -7.0)          # untouched channels
+    # coarsest level: constants (m4depth_network.py:198-200)
+    para, depth, other, _ = nops.level_pre(None, None, None, None, b, h, w, dev)
+    assert torch.all(para == 1) and torch.all(depth == 1000) and torch.all(other == 0)
+    # tail
+    ro = (rng.standard_normal([b, h, w, 5]) * 4).astype(F)
+    state = torch.empty((b, h, w, 1), device=dev)
+    p, d, o = nops.level_post(to_dev(ro, dev), to_dev(rot, dev), to_dev(trans, dev), to_dev(cam, dev), 4.0,
+                              depth_state=state)
+    ep = (np.exp(np.clip(ro[..., :1], F(-7), F(7))) / F(4.0)).astype(F)
+    assert np.max(rel_err(npy(p), ep)) < 2e-6
+    assert_bits_equal(npy(d), O.parallax2depth(npy(p), rot, trans, cam), "depth from the kernel's own parallax")
+    assert_bits_equal(npy(state), npy(d), "depth state")
+    assert_bits_equal(npy(o), ro[..., 1:], "other")
+
+
+# --------------------------------------- full-size properties (BASELINE sizes, no oracle run)
+def test_fullsize_properties(M, dev):
+    """384x1280-pyramid level-1 geometry (192x640, C=16), batch 4: size-independent
+    properties instead of an oracle run."""
+    torch.manual_seed(0)
+    b, h, w, C = 4, 192, 640, 16
+    rng = np.random.default_rng(11)
+    rot, trans = motion_np(rng, b)
+    cam = to_dev(camera_np(b, h, w), dev)
+    rot, trans = to_dev(rot, dev), to_dev(trans, dev)
+    from m4depth_amd import network_ops as nops
+    f = nops.normalize_cuts(torch.randn(b, h, w, C, device=dev), 1)
+    assert torch.allclose((f * f).sum(-1), torch.ones(b, h, w, device=dev), atol=1e-5)
+    # SNCV: centre displacement of a unit vector = 1/C; out-of-image displacements = 0
+    sn = M.cost_volume(f, f, 3, nbre_cuts=1)
+    assert torch.allclose(sn[..., 24], torch.full((b, h, w), 1.0 / C, device=dev), atol=1e-6)
+    assert torch.all(sn[:, 0, :, :21] == 0) and torch.all(sn[:, :, 0, 0::7] == 0)
+    # symmetry of the autocorrelation: cost(p, p+d) == cost(p+d, p) before the leaky relu sign is shared
+    assert torch.equal(sn[:, 5:-5, 5:-5, 24 + 1], sn[:, 5:-5, 6:-4, 24 - 1])
+    # identity warp / integer shift (bitwise, interior)
+    z = torch.zeros(b, h, w, 2, device=dev)
+    out, idx = M.dense_image_warp(f, z, return_index=True)
+    assert torch.equal(out[:, :-1, :-1], f[:, :-1, :-1])
+    jj, ii = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+    assert torch.equal(idx[0, :-1, :-1, 0], jj[:-1, :-1].int()) and torch.equal(idx[0, :-1, :-1, 1], ii[:-1, :-1].int())
+    # parallax <-> depth round trip
+    d = 1 + 79 * torch.rand(b, h, w, 1, device=dev)
+    back = M.parallax2depth(M.depth2parallax(d, rot, trans, cam), rot, trans, cam)
+    assert torch.max(torch.abs(back - d) / d) < 5e-5
+    # DSCV of spatially constant unit features = fp16(1/C) for every hypothesis
+    const = torch.full((b, h, w, C), 0.25, device=dev)
+    disp = 0.5 + 3 * torch.rand(b, h, w, 1, device=dev)
+    cv, pd = M.get_parallax_sweeping_cv(const, const, disp, disp, rot, trans, cam, 4, 1)
+    assert torch.all(cv == float(np.float16(1.0 / C)))
+    # hypotheses step by exactly one pixel along the epipolar line: the warped parallax map of a
+    # constant map is that constant
+    cst = torch.full((b, h, w, 1), 2.5, device=dev)
+    _, pd = M.get_parallax_sweeping_cv(f, f, cst, disp, rot, trans, cam, 4, 1)
+    assert torch.allclose(pd, torch.full_like(pd, 2.5), atol=1e-6)
