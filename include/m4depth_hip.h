@@ -160,6 +160,13 @@ int m4d_level_post(const float* refiner_out, const float* rot, int rot_c, const 
                    const float* cam_f, const float* cam_c, int b, int h, int w, float scale,
                    float* parallax, float* depth, float* other, float* depth_state, void* stream);
 
+/* Convolution epilogue on an NHWC activation [rows, C] (rows = b*h*w): out = leaky_relu(x +
+ * bias[c], slope) -- the bias add of Keras Conv2D and the tf.nn.leaky_relu(., 0.1) that
+ * follows it (m4depth_network.py:84,87,123,133); slope = 1 gives the bias add alone (last
+ * refiner convolution, :132).  In place when out == x. */
+int m4d_bias_act(const float* x, const float* bias, long long rows, int C, float slope,
+                 float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,13 +4,18 @@
 // The reference materialises (2r+1) tiled copies of c1, of concat[c2, disp_prev_t]
 // and of the flow field, warps them with 4 tf.gather passes and then multiplies /
 // reduces in float16: ~17x the algorithmic HBM traffic.  Here
-// one lane owns one (pixel, cut): it derives the 2r+1 query points in registers
-// from the per-sample motion, gathers the 4 corners of its cut's channel run
-// (NC contiguous floats, 16-byte loads) straight from the NHWC previous-frame
-// features, lerps in float32, forms the float16 products and reduces them
-// sequentially -- nothing but c1, c2, the two parallax maps and the outputs ever
-// touches HBM.  Lanes of one pixel are adjacent (cut-minor), so a wave reads
-// 64/k whole feature vectors per corner.
+// nothing but c1, c2, the two parallax maps and the outputs touches HBM.
+//
+// Wave layout (dscv_wave_kernel): the C channels of a pixel are spread over LP = C/4
+// adjacent lanes, 16 bytes each, so a wave covers 64/LP neighbouring pixels and every
+// corner fetch of a pixel is ONE contiguous 4*C-byte run (one or two cache lines)
+// instead of C/4 strided 16-byte pieces.  The 2r+1 query points of a pixel are
+// computed once, hypothesis t by lane t mod LP of the pixel, and broadcast with wave
+// shuffles; the per-cut float16 products are summed in channel order by a shuffle
+// chain over the G = LP/k lanes of the cut (same order as the sequential oracle, so
+// the result is bit-identical).  Workgroups are remapped so that each XCD sweeps a
+// contiguous band of the image: the gathers of neighbouring pixels then hit the
+// XCD's own 4 MiB L2.
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
 
@@ -24,11 +29,135 @@ struct DscvArgs {
   int32_t* index_out;
 };
 
-// NC > 0: channels per cut known at compile time (multiple of 4, float4 path).
-// NC == 0: runtime channel count, scalar loads (any C, any alignment).
-template <int NC>
+__device__ __forceinline__ void dscv_query(const M4dPixel& px, float start_x, float start_y, float disp,
+                                           int i, int j, int t, int r, float& qy, float& qx) {
+  const float n = (float)(t - r);
+  const float p = fminf(fmaxf(disp + n, 1e-6f), 1e6f);      // :235-236
+  const float divider = px.s / p;                           // :262
+  const float dxx = px.delta_x / divider;                   // :263
+  const float dyy = px.delta_y / divider;
+  const float flow_x = (px.proj_x + dxx) - start_x;         // :264
+  const float flow_y = (px.proj_y + dyy) - start_y;
+  qy = (float)j + flow_y;                                   // dense_image_warp.py:244
+  qx = (float)i + flow_x;
+}
+
+// LP lanes per pixel (C = 4*LP channels), G lanes per cut (nc = 4*G, k = LP/G cuts).
+template <int LP, int G>
 __global__ void __launch_bounds__(256)
-dscv_kernel(const DscvArgs a) {
+dscv_wave_kernel(const DscvArgs a) {
+  constexpr int PPW = 64 / LP;                 // pixels per wave
+  constexpr int J = (16 + LP - 1) / LP;        // owned hypotheses per lane (supports 2r+1 <= 16)
+  constexpr int NC = 4 * G;
+  const int bi = blockIdx.y;
+  const int hw = a.h * a.w;
+  const int C = 4 * LP;
+  const int ncp = 2 * a.r + 1;
+  // XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous band.
+  int blk = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) blk = (blk & 7) * (nb >> 3) + (blk >> 3);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int slot = lane / LP;                  // pixel slot in the wave
+  const int q = lane - slot * LP;              // float4 index inside the pixel's feature vector
+  const int g = q % G;                         // position inside the cut's lane group
+  const int kk = q / G;
+  const bool lane_on = slot < PPW;
+  int pix = (blk * 4 + wave) * PPW + slot;
+  const bool active = lane_on && pix < hw;
+  if (!active) pix = hw - 1;                   // keep addresses valid; results are discarded
+  const int i = pix % a.w, j = pix / a.w;
+  const long long gp = (long long)bi * hw + pix;
+  const int base_lane = slot * LP;
+
+  const M4dMotion m = m4d_load_motion(a.rot, a.rot_c, a.trans, a.cam_f, a.cam_c, bi);
+  const M4dPixel px = m4d_pixel_factors(m, i, j);
+  const float start_x = px.x * m.fx;           // :256
+  const float start_y = px.y * m.fy;
+  const float disp = a.disp[gp];
+
+  // hypotheses owned by this lane: t = jj*LP + q
+  float oqy[J], oqx[J];
+#pragma unroll
+  for (int jj = 0; jj < J; ++jj) {
+    const int t = jj * LP + q;
+    oqy[jj] = 0.f; oqx[jj] = 0.f;
+    if (jj * LP < ncp)                          // wave-uniform: skip rounds no hypothesis falls in
+      dscv_query(px, start_x, start_y, disp, i, j, t < ncp ? t : 0, a.r, oqy[jj], oqx[jj]);
+  }
+
+  // this lane's 4 channels of c1, pre-rounded to half (:276)
+  const float4 c1v = *reinterpret_cast<const float4*>(a.c1 + gp * C + 4 * q);
+  const float c1a = m4d_round_half(c1v.x), c1b = m4d_round_half(c1v.y);
+  const float c1c = m4d_round_half(c1v.z), c1d = m4d_round_half(c1v.w);
+  const float* c2b = a.c2 + (long long)bi * hw * C + 4 * q;
+  const float* dpt = a.disp_prev_t + (long long)bi * hw;
+  const long long rs = (long long)a.w * C;
+  const float n_c = (float)NC;
+  const bool seq16 = a.cv_accum != 0;
+
+#pragma unroll
+  for (int jj = 0; jj < J; ++jj) {
+#pragma unroll
+    for (int qo = 0; qo < LP; ++qo) {
+      const int t = jj * LP + qo;
+      if (t >= ncp) break;                      // wave-uniform
+      const float qy = __shfl(oqy[jj], base_lane + qo);
+      const float qx = __shfl(oqx[jj], base_lane + qo);
+      int y0, x0;
+      float ay, ax;
+      m4d_bilinear_axis(qy, a.h, y0, ay);
+      m4d_bilinear_axis(qx, a.w, x0, ax);
+      const float* tl = c2b + ((long long)y0 * a.w + x0) * C;
+      const float4 vtl = *reinterpret_cast<const float4*>(tl);
+      const float4 vtr = *reinterpret_cast<const float4*>(tl + C);
+      const float4 vbl = *reinterpret_cast<const float4*>(tl + rs);
+      const float4 vbr = *reinterpret_cast<const float4*>(tl + rs + C);
+      const float p0 = m4d_round_half(c1a * m4d_round_half(m4d_lerp2(vtl.x, vtr.x, vbl.x, vbr.x, ax, ay)));
+      const float p1 = m4d_round_half(c1b * m4d_round_half(m4d_lerp2(vtl.y, vtr.y, vbl.y, vbr.y, ax, ay)));
+      const float p2 = m4d_round_half(c1c * m4d_round_half(m4d_lerp2(vtl.z, vtr.z, vbl.z, vbr.z, ax, ay)));
+      const float p3 = m4d_round_half(c1d * m4d_round_half(m4d_lerp2(vtl.w, vtr.w, vbl.w, vbr.w, ax, ay)));
+      // sequential (channel-order) sum across the G lanes of the cut
+      float acc;
+      if (!seq16) {
+        acc = ((p0 + p1) + p2) + p3;
+#pragma unroll
+        for (int s = 1; s < G; ++s) {
+          const float prev = __shfl_up(acc, 1);
+          if (g == s) acc = (((prev + p0) + p1) + p2) + p3;
+        }
+      } else {
+        acc = m4d_round_half(m4d_round_half(m4d_round_half(p0 + p1) + p2) + p3);
+#pragma unroll
+        for (int s = 1; s < G; ++s) {
+          const float prev = __shfl_up(acc, 1);
+          if (g == s)
+            acc = m4d_round_half(m4d_round_half(m4d_round_half(m4d_round_half(prev + p0) + p1) + p2) + p3);
+        }
+      }
+      if (active && g == G - 1)
+        a.cv[gp * a.cv_stride + kk * ncp + t] = m4d_round_half(acc / n_c);      // :277-278
+      if (active && q == 0) {
+        if (a.index_out) {
+          a.index_out[(gp * ncp + t) * 2] = y0;
+          a.index_out[(gp * ncp + t) * 2 + 1] = x0;
+        }
+        const bool centre = (t == a.r) && a.log_center != nullptr;
+        if (a.prev_disp != nullptr || centre) {
+          const float* d0 = dpt + (long long)y0 * a.w + x0;                      // the extra channel of :268
+          const float wd = m4d_lerp2(d0[0], d0[1], d0[a.w], d0[a.w + 1], ax, ay);
+          if (a.prev_disp) a.prev_disp[gp * ncp + t] = wd;
+          if (centre) a.log_center[gp * a.log_stride] = logf(wd * a.log_scale);  // m4depth_network.py:238
+        }
+      }
+    }
+  }
+}
+
+// Any C / cuts / alignment / search range: one lane per (pixel, cut), scalar loads.
+__global__ void __launch_bounds__(256)
+dscv_generic_kernel(const DscvArgs a) {
   const int bi = blockIdx.y;
   const int hw = a.h * a.w;
   const int k = a.k;
@@ -37,80 +166,35 @@ dscv_kernel(const DscvArgs a) {
   const int kk = t_id % k;
   const int pix = t_id / k;
   const int i = pix % a.w, j = pix / a.w;
-  const long long gp = (long long)bi * hw + pix;            // global pixel index
-  const int nc = NC > 0 ? NC : a.nc;
+  const long long gp = (long long)bi * hw + pix;
+  const int nc = a.nc;
   const int C = a.C;
   const int ncp = 2 * a.r + 1;
-
   const M4dMotion m = m4d_load_motion(a.rot, a.rot_c, a.trans, a.cam_f, a.cam_c, bi);
   const M4dPixel px = m4d_pixel_factors(m, i, j);
-  const float start_x = px.x * m.fx;                          // :256
+  const float start_x = px.x * m.fx;
   const float start_y = px.y * m.fy;
   const float disp = a.disp[gp];
-
-  // c1 of this cut, pre-rounded to half (:276).
-  float c1h[NC > 0 ? NC : 1];
   const float* c1p = a.c1 + gp * C + kk * nc;
-  if (NC > 0) {
-#pragma unroll
-    for (int c = 0; c < NC; c += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(c1p + c);
-      c1h[c] = m4d_round_half(v.x); c1h[c + 1] = m4d_round_half(v.y);
-      c1h[c + 2] = m4d_round_half(v.z); c1h[c + 3] = m4d_round_half(v.w);
-    }
-  }
   const float* c2b = a.c2 + (long long)bi * hw * C + kk * nc;
   const float* dpt = a.disp_prev_t + (long long)bi * hw;
   const long long rs = (long long)a.w * C;
-  const float inv_n = (float)nc;
-
   for (int t = 0; t < ncp; ++t) {
-    const float n = (float)(t - a.r);
-    const float p = fminf(fmaxf(disp + n, 1e-6f), 1e6f);      // :235-236
-    const float divider = px.s / p;                           // :262
-    const float dxx = px.delta_x / divider;                   // :263
-    const float dyy = px.delta_y / divider;
-    const float flow_x = (px.proj_x + dxx) - start_x;         // :264
-    const float flow_y = (px.proj_y + dyy) - start_y;
-    const float qy = (float)j + flow_y;                       // dense_image_warp.py:244
-    const float qx = (float)i + flow_x;
+    float qy, qx;
+    dscv_query(px, start_x, start_y, disp, i, j, t, a.r, qy, qx);
     int y0, x0;
     float ay, ax;
     m4d_bilinear_axis(qy, a.h, y0, ay);
     m4d_bilinear_axis(qx, a.w, x0, ax);
     const float* tl = c2b + ((long long)y0 * a.w + x0) * C;
     float acc = 0.0f;
-    if (NC > 0) {
-#pragma unroll
-      for (int c = 0; c < NC; c += 4) {
-        const float4 vtl = *reinterpret_cast<const float4*>(tl + c);
-        const float4 vtr = *reinterpret_cast<const float4*>(tl + C + c);
-        const float4 vbl = *reinterpret_cast<const float4*>(tl + rs + c);
-        const float4 vbr = *reinterpret_cast<const float4*>(tl + rs + C + c);
-        const float w0 = m4d_round_half(m4d_lerp2(vtl.x, vtr.x, vbl.x, vbr.x, ax, ay));
-        const float w1 = m4d_round_half(m4d_lerp2(vtl.y, vtr.y, vbl.y, vbr.y, ax, ay));
-        const float w2 = m4d_round_half(m4d_lerp2(vtl.z, vtr.z, vbl.z, vbr.z, ax, ay));
-        const float w3 = m4d_round_half(m4d_lerp2(vtl.w, vtr.w, vbl.w, vbr.w, ax, ay));
-        const float p0 = m4d_round_half(c1h[c] * w0), p1 = m4d_round_half(c1h[c + 1] * w1);
-        const float p2 = m4d_round_half(c1h[c + 2] * w2), p3 = m4d_round_half(c1h[c + 3] * w3);
-        if (a.cv_accum == 0) {
-          if (c == 0) acc = p0; else acc = acc + p0;
-          acc = acc + p1; acc = acc + p2; acc = acc + p3;
-        } else {
-          if (c == 0) acc = p0; else acc = m4d_round_half(acc + p0);
-          acc = m4d_round_half(acc + p1); acc = m4d_round_half(acc + p2); acc = m4d_round_half(acc + p3);
-        }
-      }
-    } else {
-      for (int c = 0; c < nc; ++c) {
-        const float wv = m4d_round_half(m4d_lerp2(tl[c], tl[C + c], tl[rs + c], tl[rs + C + c], ax, ay));
-        const float pr = m4d_round_half(m4d_round_half(c1p[c]) * wv);
-        if (c == 0) acc = pr;
-        else acc = (a.cv_accum == 0) ? (acc + pr) : m4d_round_half(acc + pr);
-      }
+    for (int c = 0; c < nc; ++c) {
+      const float wv = m4d_round_half(m4d_lerp2(tl[c], tl[C + c], tl[rs + c], tl[rs + C + c], ax, ay));
+      const float pr = m4d_round_half(m4d_round_half(c1p[c]) * wv);
+      if (c == 0) acc = pr;
+      else acc = (a.cv_accum == 0) ? (acc + pr) : m4d_round_half(acc + pr);
     }
-    a.cv[gp * a.cv_stride + kk * ncp + t] = m4d_round_half(acc / inv_n);   // :277-278
-
+    a.cv[gp * a.cv_stride + kk * ncp + t] = m4d_round_half(acc / (float)nc);
     if (kk == 0) {
       if (a.index_out) {
         a.index_out[(gp * ncp + t) * 2] = y0;
@@ -118,13 +202,21 @@ dscv_kernel(const DscvArgs a) {
       }
       const bool centre = (t == a.r) && a.log_center != nullptr;
       if (a.prev_disp != nullptr || centre) {
-        const float* d0 = dpt + (long long)y0 * a.w + x0;     // the extra channel of :268
+        const float* d0 = dpt + (long long)y0 * a.w + x0;
         const float wd = m4d_lerp2(d0[0], d0[1], d0[a.w], d0[a.w + 1], ax, ay);
         if (a.prev_disp) a.prev_disp[gp * ncp + t] = wd;
-        if (centre) a.log_center[gp * a.log_stride] = logf(wd * a.log_scale);   // m4depth_network.py:238
+        if (centre) a.log_center[gp * a.log_stride] = logf(wd * a.log_scale);
       }
     }
   }
+}
+
+template <int LP, int G>
+void launch_wave(const DscvArgs& a, int b, hipStream_t s) {
+  constexpr int PPW = 64 / LP;
+  const int hw = a.h * a.w;
+  int nb = (hw + 4 * PPW - 1) / (4 * PPW);
+  hipLaunchKernelGGL((dscv_wave_kernel<LP, G>), dim3(nb, b), dim3(256), 0, s, a);
 }
 
 }  // namespace
@@ -148,15 +240,23 @@ extern "C" int m4d_dscv_fwd(const float* c1, const float* c2, const float* disp_
   a.h = h; a.w = w; a.C = C; a.r = search_range; a.k = nbre_cuts; a.nc = C / nbre_cuts; a.cv_accum = cv_accum;
   a.cv = cv; a.cv_stride = cv_stride; a.prev_disp = prev_disp; a.log_center = log_center;
   a.log_stride = log_stride; a.log_scale = log_scale; a.index_out = index_out;
-  const long long threads = (long long)h * w * nbre_cuts;
-  const dim3 grid(m4d_blocks(threads, 256), b), block(256);
-  const bool aligned = (((uintptr_t)c1 | (uintptr_t)c2) & 15u) == 0 && (a.nc % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
-  if (aligned && a.nc == 16) hipLaunchKernelGGL(dscv_kernel<16>, grid, block, 0, s, a);
-  else if (aligned && a.nc == 24) hipLaunchKernelGGL(dscv_kernel<24>, grid, block, 0, s, a);
-  else if (aligned && a.nc == 32) hipLaunchKernelGGL(dscv_kernel<32>, grid, block, 0, s, a);
-  else if (aligned && a.nc == 8) hipLaunchKernelGGL(dscv_kernel<8>, grid, block, 0, s, a);
-  else if (aligned && a.nc == 4) hipLaunchKernelGGL(dscv_kernel<4>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(dscv_kernel<0>, grid, block, 0, s, a);
+  const bool aligned = (((uintptr_t)c1 | (uintptr_t)c2) & 15u) == 0 && (a.nc % 4 == 0);
+  const int lp = C / 4, g = a.nc / 4;
+  const bool fits = aligned && (2 * search_range + 1) <= 16;
+  // (LP, G) pairs of the 6-level pyramid (C = 16..192, cuts 1,2,2,4,4,8) plus the small
+  // shapes the unit tests use; everything else takes the generic kernel.
+  if (fits && lp == 4 && g == 4) launch_wave<4, 4>(a, b, s);          // C=16  k=1
+  else if (fits && lp == 8 && g == 4) launch_wave<8, 4>(a, b, s);     // C=32  k=2
+  else if (fits && lp == 16 && g == 8) launch_wave<16, 8>(a, b, s);   // C=64  k=2
+  else if (fits && lp == 24 && g == 6) launch_wave<24, 6>(a, b, s);   // C=96  k=4
+  else if (fits && lp == 32 && g == 8) launch_wave<32, 8>(a, b, s);   // C=128 k=4
+  else if (fits && lp == 48 && g == 6) launch_wave<48, 6>(a, b, s);   // C=192 k=8
+  else if (fits && lp == 8 && g == 8) launch_wave<8, 8>(a, b, s);     // C=32  k=1
+  else if (fits && lp == 4 && g == 2) launch_wave<4, 2>(a, b, s);     // C=16  k=2
+  else {
+    const long long threads = (long long)h * w * nbre_cuts;
+    hipLaunchKernelGGL(dscv_generic_kernel, dim3(m4d_blocks(threads, 256), b), dim3(256), 0, s, a);
+  }
   return M4D_LAUNCH_RESULT();
 }

@@ -171,6 +171,34 @@ level_post_kernel(const float* __restrict__ ro, const float* __restrict__ rot, i
   }
 }
 
+// ---- convolution epilogue: + bias, leaky_relu (m4depth_network.py:84,87,123,133) -----
+// PyTorch-ROCm runs a MIOpen convolution, a broadcast bias add and the activation as three
+// kernels (three passes over the activation); this is one in-place pass.
+template <bool VEC4>
+__global__ void __launch_bounds__(256)
+bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias, long long total, int C,
+                float slope, float* __restrict__ out) {
+  if (VEC4) {
+    const int c4n = C >> 2;
+    for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < (total >> 2);
+         i4 += (long long)gridDim.x * blockDim.x) {
+      const int c = (int)(i4 % c4n) << 2;
+      float4 v = *reinterpret_cast<const float4*>(x + (i4 << 2));
+      const float4 b = *reinterpret_cast<const float4*>(bias + c);
+      v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w;
+      v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+      v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+      *reinterpret_cast<float4*>(out + (i4 << 2)) = v;
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+      float v = x[i] + bias[i % C];
+      out[i] = v > 0.f ? v : v * slope;
+    }
+  }
+}
+
 inline int grid1d(long long total) {
   long long g = (total + 255) / 256;
   if (g > 256 * 32) g = 256 * 32;
@@ -241,5 +269,15 @@ extern "C" int m4d_level_post(const float* refiner_out, const float* rot, int ro
   if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(level_post_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream,
                      refiner_out, rot, rot_c, trans, cam_f, cam_c, h, w, scale, parallax, depth, other, depth_state);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_bias_act(const float* x, const float* bias, long long rows, int C, float slope,
+                            float* out, void* stream) {
+  M4D_CHECK_ARG(x && bias && out && rows > 0 && C > 0);
+  const long long total = rows * C;
+  const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias) & 15u) == 0);
+  if (vec) hipLaunchKernelGGL(bias_act_kernel<true>, dim3(grid1d(total >> 2)), dim3(256), 0, (hipStream_t)stream, x, bias, total, C, slope, out);
+  else hipLaunchKernelGGL(bias_act_kernel<false>, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, x, bias, total, C, slope, out);
   return M4D_LAUNCH_RESULT();
 }

@@ -20,13 +20,23 @@ struct SncvArgs {
   float* out; int out_stride; int th, tw; int tiles_x;
 };
 
-template <int NC>
+// MO = 2r+1 known at compile time (MO > 0): the (2r+1)^2 results of a lane are kept in
+// registers, then -- after a barrier, once every lane has finished reading the halo tile --
+// written into the SAME LDS bytes as rows of (2r+1)^2*k floats per pixel and streamed out
+// by whole waves: each store instruction covers one pixel's contiguous channel run
+// (196*k bytes at r = 3) instead of 64 scattered 4-byte pieces, which is what bounded the
+// first version of this kernel (L2 request rate, not bytes).  MO == 0: runtime window,
+// direct per-lane stores (large windows whose results do not fit the register file).
+template <int NC, int MO>
 __global__ void __launch_bounds__(256)
 sncv_lds_kernel(const SncvArgs a) {
   extern __shared__ __align__(16) float tile[];
   const int bi = blockIdx.y;
-  const int tile_y = (blockIdx.x / a.tiles_x) * a.th;
-  const int tile_x = (blockIdx.x % a.tiles_x) * a.tw;
+  int blk = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) blk = (blk & 7) * (nb >> 3) + (blk >> 3);   // one contiguous band of tiles per XCD (halo reuse in its L2)
+  const int tile_y = (blk / a.tiles_x) * a.th;
+  const int tile_x = (blk % a.tiles_x) * a.tw;
   const int R = a.r * a.d;
   const int hw_t = a.tw + 2 * R;              // halo tile width (pixels)
   const int hh_t = a.th + 2 * R;
@@ -48,48 +58,73 @@ sncv_lds_kernel(const SncvArgs a) {
   __syncthreads();
 
   const int k = a.k;
-  const int mo = 2 * a.r + 1;
+  const int mo = MO > 0 ? MO : 2 * a.r + 1;
   const bool same = (a.c1 == a.c2);
   const float n_c = (float)NC;
-  for (int item = threadIdx.x; item < a.th * a.tw * k; item += blockDim.x) {
+  const int items = a.th * a.tw * k;           // <= 256 by construction when MO > 0
+  float res[MO > 0 ? MO * MO : 1];
+  for (int item = threadIdx.x; item < (MO > 0 ? 256 : items); item += blockDim.x) {
     const int kk = item % k;
     const int lp = item / k;
     const int ty = lp / a.tw, tx = lp % a.tw;
     const int gy = tile_y + ty, gx = tile_x + tx;
-    if (gy >= a.h || gx >= a.w) continue;
-    const long long gp = ((long long)bi * a.h + gy) * a.w + gx;
-    float c1r[NC];
-    if (same) {
-      const float* p = tile + ((ty + R) * hw_t + tx + R) * CP + kk * NC;
-#pragma unroll
-      for (int c = 0; c < NC; c += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(p + c);
-        c1r[c] = v.x; c1r[c + 1] = v.y; c1r[c + 2] = v.z; c1r[c + 3] = v.w;
-      }
-    } else {
-      const float* p = a.c1 + gp * C + kk * NC;
-#pragma unroll
-      for (int c = 0; c < NC; c += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(p + c);
-        c1r[c] = v.x; c1r[c + 1] = v.y; c1r[c + 2] = v.z; c1r[c + 3] = v.w;
-      }
-    }
-    float* o = a.out + gp * a.out_stride + kk;
-    for (int y = 0; y < mo; ++y) {
-      const float* row = tile + ((ty + y * a.d) * hw_t + tx) * CP + kk * NC;
-      for (int x = 0; x < mo; ++x) {
-        const float* p = row + x * a.d * CP;
-        float acc = 0.f;
+    const bool valid = item < items && gy < a.h && gx < a.w;
+    if (MO == 0 && !valid) continue;
+    if (valid) {
+      const long long gp = ((long long)bi * a.h + gy) * a.w + gx;
+      float c1r[NC];
+      if (same) {                               // c1 == c2: the pixel's own vector is already in LDS
+        const float* p1 = tile + ((ty + R) * hw_t + tx + R) * CP + kk * NC;
 #pragma unroll
         for (int c = 0; c < NC; c += 4) {
-          const float4 v = *reinterpret_cast<const float4*>(p + c);
-          if (c == 0) acc = c1r[0] * v.x; else acc = acc + c1r[c] * v.x;
-          acc = acc + c1r[c + 1] * v.y;
-          acc = acc + c1r[c + 2] * v.z;
-          acc = acc + c1r[c + 3] * v.w;
+          const float4 v = *reinterpret_cast<const float4*>(p1 + c);
+          c1r[c] = v.x; c1r[c + 1] = v.y; c1r[c + 2] = v.z; c1r[c + 3] = v.w;
         }
-        const float mean = acc / n_c;                                   // :308
-        o[(y * mo + x) * k] = mean > 0.f ? mean : mean * 0.1f;          // :311
+      } else {
+        const float* p1 = a.c1 + gp * C + kk * NC;
+#pragma unroll
+        for (int c = 0; c < NC; c += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(p1 + c);
+          c1r[c] = v.x; c1r[c + 1] = v.y; c1r[c + 2] = v.z; c1r[c + 3] = v.w;
+        }
+      }
+      float* o = a.out + gp * a.out_stride + kk;
+#pragma unroll
+      for (int y = 0; y < mo; ++y) {
+        const float* row = tile + ((ty + y * a.d) * hw_t + tx) * CP + kk * NC;
+#pragma unroll
+        for (int x = 0; x < mo; ++x) {
+          const float* p = row + x * a.d * CP;
+          float acc = 0.f;
+#pragma unroll
+          for (int c = 0; c < NC; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(p + c);
+            if (c == 0) acc = c1r[0] * v.x; else acc = acc + c1r[c] * v.x;
+            acc = acc + c1r[c + 1] * v.y;
+            acc = acc + c1r[c + 2] * v.z;
+            acc = acc + c1r[c + 3] * v.w;
+          }
+          const float mean = acc / n_c;                                   // :308
+          const float r = mean > 0.f ? mean : mean * 0.1f;                // :311
+          if (MO > 0) res[y * MO + x] = r; else o[(y * mo + x) * k] = r;
+        }
+      }
+    }
+    if (MO > 0) {
+      __syncthreads();                        // every lane is done with the halo tile
+      const int och = MO * MO * k;
+      if (valid) {
+#pragma unroll
+        for (int d = 0; d < MO * MO; ++d) tile[lp * och + d * k + kk] = res[d];
+      }
+      __syncthreads();
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      for (int p = wave; p < a.th * a.tw; p += 4) {
+        const int py = p / a.tw, pxx = p % a.tw;
+        const int oy = tile_y + py, ox = tile_x + pxx;
+        if (oy >= a.h || ox >= a.w) continue;                             // wave-uniform
+        float* o = a.out + (((long long)bi * a.h + oy) * a.w + ox) * a.out_stride;
+        for (int ch = lane; ch < och; ch += 64) o[ch] = tile[p * och + ch];
       }
     }
   }
@@ -124,16 +159,23 @@ sncv_generic_kernel(const SncvArgs a, long long total) {
   }
 }
 
-template <int NC>
-void launch_lds(const SncvArgs& a, int b, size_t lds, hipStream_t s) {
+template <int NC, int MO>
+void launch_lds_mo(const SncvArgs& a, int b, size_t lds, hipStream_t s) {
   const int tiles = a.tiles_x * ((a.h + a.th - 1) / a.th);
   static bool attr_set = false;     // raising the dynamic-LDS cap is idempotent; set once per instantiation
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sncv_lds_kernel<NC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sncv_lds_kernel<NC, MO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(sncv_lds_kernel<NC>, dim3(tiles, b), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((sncv_lds_kernel<NC, MO>), dim3(tiles, b), dim3(256), lds, s, a);
+}
+
+template <int NC>
+void launch_lds(const SncvArgs& a, int b, size_t lds, bool staged, hipStream_t s) {
+  if (staged && a.r == 3) launch_lds_mo<NC, 7>(a, b, lds, s);
+  else if (staged && a.r == 2) launch_lds_mo<NC, 5>(a, b, lds, s);
+  else launch_lds_mo<NC, 0>(a, b, lds, s);
 }
 
 }  // namespace
@@ -159,15 +201,20 @@ extern "C" int m4d_sncv_fwd(const float* c1, const float* c2, int b, int h, int 
   const size_t budget = 64 * 1024;           // two workgroups per CU
   auto lds_bytes = [&](int th_, int tw_) { return (size_t)(th_ + 2 * R) * (tw_ + 2 * R) * (C + 4) * sizeof(float); };
   while (lds_bytes(th, tw) > budget && (tw > 8 || th > 4)) { if (tw > th * 2 || th <= 4) tw >>= 1; else th >>= 1; }
-  const size_t lds = lds_bytes(th, tw);
+  size_t lds = lds_bytes(th, tw);
   if (aligned && nc_ok && lds <= 160 * 1024) {
     a.th = th; a.tw = tw; a.tiles_x = (w + tw - 1) / tw;
+    // register-staged, coalesced-store variant: needs one item per lane and the output rows of the
+    // tile to fit in LDS (they reuse the halo tile's bytes).
+    const size_t stage = (size_t)th * tw * mo * mo * nbre_cuts * sizeof(float);
+    const bool staged = (search_range == 2 || search_range == 3) && th * tw * nbre_cuts <= 256 && stage <= 160 * 1024;
+    if (staged && stage > lds) lds = stage;
     switch (a.nc) {
-      case 4: launch_lds<4>(a, b, lds, s); break;
-      case 8: launch_lds<8>(a, b, lds, s); break;
-      case 16: launch_lds<16>(a, b, lds, s); break;
-      case 24: launch_lds<24>(a, b, lds, s); break;
-      default: launch_lds<32>(a, b, lds, s); break;
+      case 4: launch_lds<4>(a, b, lds, staged, s); break;
+      case 8: launch_lds<8>(a, b, lds, staged, s); break;
+      case 16: launch_lds<16>(a, b, lds, staged, s); break;
+      case 24: launch_lds<24>(a, b, lds, staged, s); break;
+      default: launch_lds<32>(a, b, lds, staged, s); break;
     }
   } else {
     a.th = a.tw = a.tiles_x = 0;

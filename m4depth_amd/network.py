@@ -76,21 +76,30 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.bias = torch.nn.Parameter(_to_device_f32(bias, device).contiguous(), requires_grad=False)
 
-    def forward(self, x_nhwc):
+    def forward(self, x_nhwc, slope=None):
+        """Convolution + bias (+ leaky_relu(slope) when ``slope`` is given).  On the GPU the
+        bias add and the activation are one in-place HIP epilogue pass instead of two more
+        PyTorch kernels; on CPU tensors (host-logic tests) plain torch ops are used."""
         if self.weight is None:
             self._build(x_nhwc.shape[-1], x_nhwc.device)
         x = x_nhwc.permute(0, 3, 1, 2)                   # channels-last NCHW view, no copy
         h, w = x.shape[2:]
         s = self.stride
+        fused = x_nhwc.is_cuda
+        bias = None if fused else self.bias
         if s == 1:
-            y = F.conv2d(x, self.weight, self.bias, 1, 1)
+            y = F.conv2d(x, self.weight, bias, 1, 1)
         else:
             ph = max((-(-h // s) - 1) * s + 3 - h, 0)
             pw = max((-(-w // s) - 1) * s + 3 - w, 0)
             x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
-            y = F.conv2d(x, self.weight, self.bias, s, 0)
+            y = F.conv2d(x, self.weight, bias, s, 0)
         y = y.permute(0, 2, 3, 1)
-        return y if y.is_contiguous() else y.contiguous()
+        if not y.is_contiguous():
+            y = y.contiguous()
+        if fused:
+            return nops.bias_act_(y, self.bias, 1.0 if slope is None else slope)
+        return y if slope is None else F.leaky_relu(y, slope)
 
 
 class DomainNormalization(torch.nn.Module):
@@ -137,12 +146,11 @@ class FeaturePyramid(torch.nn.Module):
         feature_maps = as_f32(images, "images")
         outputs = []
         for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):
-            tmp = conv_s1(feature_maps)
             if self.use_dinl and i == 0:
-                tmp = dn_layer(tmp)
-            tmp = F.leaky_relu(tmp, 0.1)
-            tmp = conv_s2(tmp)
-            feature_maps = F.leaky_relu(tmp, 0.1)
+                tmp = F.leaky_relu(dn_layer(conv_s1(feature_maps)), 0.1)
+            else:
+                tmp = conv_s1(feature_maps, slope=0.1)
+            feature_maps = conv_s2(tmp, slope=0.1)
             outputs.append(feature_maps)
         return outputs
 
@@ -162,13 +170,11 @@ class DispRefiner(torch.nn.Module):
     def forward(self, feature_map):
         prev_out = feature_map
         for conv in self.prep_conv_layers:
-            prev_out = F.leaky_relu(conv(prev_out), 0.1)
+            prev_out = conv(prev_out, slope=0.1)
         prep = prev_out
         n = len(self.est_d_conv_layers)
         for i, conv in enumerate(self.est_d_conv_layers):
-            prev_out = conv(prev_out)
-            if i < n - 1:                                  # don't activate the last convolution output
-                prev_out = F.leaky_relu(prev_out, 0.1)
+            prev_out = conv(prev_out, slope=0.1 if i < n - 1 else None)   # last convolution: no activation
         return [prev_out, prep]
 
 
@@ -198,6 +204,7 @@ class DepthEstimatorLevel(torch.nn.Module):
         self.depth_prev_t = None
         self._spare_f = None
         self.last_f_input = None          # kept for inspection / parity tests
+        self.last_cv_inputs = None
 
     # -- temporal memory (build(), :153-165) ------------------------------------------
     def _ensure_state(self, shape, device):
@@ -282,6 +289,7 @@ class DepthEstimatorLevel(torch.nn.Module):
                 dptr(curr_f), dptr(curr_f), b, h, w, c, self.sncv_range, 1, k,
                 ctypes.c_void_p(fin_ptr + 4 * sncv_off), F_in, stream_ptr())), "m4d_sncv_fwd")
         self.last_f_input = f_input
+        self.last_cv_inputs = (curr_f, prev_f, para_prev_t, para_prev_l, rot_t, tr, cf, cc)   # for tools/bench_kernels.py
         # "depth_estimator" (:244-260)
         prev_out = self.disp_refiner(f_input)
         para_curr_l, depth, other = nops.level_post(prev_out[0], rot_t, tr, {"f": cf, "c": cc}, scale,
@@ -424,6 +432,16 @@ class M4Depth(torch.nn.Module):
         preds = self([[data], data["camera"]], training=False)
         return {"image": data["RGB_im"], "depth": preds["depth"], "new_traj": data["new_traj"]}
 
+    def graphed_test_step(self, data, runner):
+        """``test_step`` for a 5-D sequence batch with the forward replayed from a
+        ``GraphedSequence`` (metrics stay eager: Keras ``Mean`` keeps host-side counts)."""
+        est = runner(data)
+        gt = torch.clamp(data["depth"][:, -1], 0.0, 80.)
+        est = torch.clamp(est, 0.001, 80.)
+        for m in self.compiled_metrics:
+            m.update_state(gt, est)
+        return {m.name: m.result() for m in self.compiled_metrics}
+
     def evaluate(self, dataset):
         for m in self.compiled_metrics:
             m.reset_state()
@@ -431,3 +449,55 @@ class M4Depth(torch.nn.Module):
         for batch in dataset:
             out = self.test_step(batch)
         return [float(out[m.name]) for m in self.compiled_metrics]
+
+
+class GraphedSequence:
+    """One ``M4Depth`` sequence forward captured in a hipGraph.
+
+    A 384x1280 / 6-level frame is ~110 kernel launches (12 encoder + 42 refiner
+    convolutions with their epilogues, 6 x 5 hand-written level kernels); at batch 1
+    the eager loop is host-launch bound (GPU ~50 % idle, profiles/).  Capturing the
+    whole sequence once and replaying it removes the host from the loop.  The capture
+    is valid because the step has no host synchronisation: ``new_traj`` lives on the
+    host and is baked in as the control flow of the captured sequence, every kernel of
+    libm4depth_hip.so is enqueued on the capturing stream, and the level state buffers
+    are persistent allocations made before the capture.
+
+    ``runner(data)`` copies a new batch into the static input buffers (device-side
+    copies), replays, and returns the static ``depth`` output tensor."""
+
+    def __init__(self, model, example, warmup=2):
+        self.model = model
+        self.new_traj = example["new_traj"].clone() if isinstance(example["new_traj"], torch.Tensor) else example["new_traj"]
+        self.static = {k: example[k].clone() for k in ("RGB_im", "rot", "trans")}
+        self.camera = {k: v.clone() for k, v in example["camera"].items()}
+        self.seq_len = self.static["RGB_im"].shape[1]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.depth = self._run()
+
+    def _samples(self):
+        nt = torch.unbind(self.new_traj, dim=1)
+        return [{"RGB_im": self.static["RGB_im"][:, t], "rot": self.static["rot"][:, t],
+                 "trans": self.static["trans"][:, t], "new_traj": nt[t]} for t in range(self.seq_len)]
+
+    def _run(self):
+        return self.model([self._samples(), self.camera])["depth"]
+
+    def __call__(self, data=None):
+        if data is not None:
+            for k in self.static:
+                if data[k].data_ptr() != self.static[k].data_ptr():
+                    self.static[k].copy_(data[k], non_blocking=True)
+            for k in self.camera:
+                if data["camera"][k].data_ptr() != self.camera[k].data_ptr():
+                    self.camera[k].copy_(data["camera"][k], non_blocking=True)
+        self.graph.replay()
+        return self.depth

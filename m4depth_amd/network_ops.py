@@ -91,3 +91,13 @@ def level_post(refiner_out, rot, trans, camera, scale, depth_state=None):
                              float(scale), dptr(para), dptr(depth), dptr(other), dptr(depth_state, "depth_state"),
                              stream_ptr()), "m4d_level_post")
     return para, depth, other
+
+
+def bias_act_(x, bias, slope=0.1):
+    """In-place convolution epilogue on an NHWC tensor: x = leaky_relu(x + bias, slope)
+    (slope = 1.0: bias add only)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    check(lib.m4d_bias_act(dptr(x, "x"), dptr(bias, "bias"), rows, C, float(slope), dptr(x, "x"), stream_ptr()),
+          "m4d_bias_act")
+    return x

@@ -183,3 +183,37 @@ def test_test_step_semantics(dev):
         model.test_step(d)
         assert model.compiled_metrics[0].count == t
     assert np.isfinite(ref) and ref > 0
+
+
+def test_graphed_sequence_matches_eager(dev):
+    """hipGraph replay of the sequence forward (the bench's launch path) against the
+    eager forward of the same batch (not bitwise: MIOpen nondeterminism, see above), and
+    replay on a second batch copied into the static buffers."""
+    import m4depth_amd as M
+    from m4depth_amd import network as net
+    L, H, Wd, T, b = 3, 64, 96, 2, 2
+    W = S.init_weights(L, seed=8)
+    model = _build(dev, L, 4, 3, W)
+    model.compile(metrics=M.default_metrics())
+
+    def batch(seed):
+        samples, cam = S.make_sequence(b, T, H, Wd, seed=seed)
+        d = {k: torch.stack([to_dev(s[k], dev) for s in samples], dim=1) for k in ("depth", "RGB_im", "rot", "trans")}
+        d["new_traj"] = torch.stack([torch.from_numpy(s["new_traj"]) for s in samples], dim=1)
+        d["camera"] = to_dev(cam, dev)
+        return d
+
+    d1, d2 = batch(31), batch(32)
+    model.test_step(d1)
+    eager1 = npy(model.last_estimates[-1][0]["parallax"])
+    model.test_step(d2)
+    eager2 = npy(model.last_estimates[-1][0]["parallax"])
+    runner = net.GraphedSequence(model, d1)
+    for m in model.compiled_metrics:
+        m.reset_state()
+    for d, ref in ((d1, eager1), (d2, eager2), (d1, eager1)):
+        res = model.graphed_test_step(d, runner)
+        torch.cuda.synchronize()
+        rp = rel_err(npy(model.last_estimates[-1][0]["parallax"]), ref, 1e-12)
+        assert rp.max() < 1e-4 and np.median(rp) < 1e-6, (rp.max(), np.median(rp))
+    assert model.compiled_metrics[0].count == 3 and np.isfinite(float(res["AbsRel"]))

@@ -254,3 +254,16 @@ def test_fullsize_properties(M, dev):
     cst = torch.full((b, h, w, 1), 2.5, device=dev)
     _, pd = M.get_parallax_sweeping_cv(f, f, cst, disp, rot, trans, cam, 4, 1)
     assert torch.allclose(pd, torch.full_like(pd, 2.5), atol=1e-6)
+
+
+def test_bias_act_epilogue(M, dev):
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(12)
+    for C in (16, 5, 128):
+        x = rng.standard_normal([2, 7, 9, C]).astype(F)
+        b = rng.standard_normal([C]).astype(F)
+        for slope in (0.1, 1.0):
+            got = nops.bias_act_(to_dev(x.copy(), dev), to_dev(b, dev), slope)
+            y = x + b
+            ref = np.where(y > 0, y, y * F(slope)).astype(F)
+            assert_bits_equal(npy(got), ref, f"bias_act C={C} slope={slope}")

@@ -1,0 +1,58 @@
+"""The C-ABI shared library loads on a GPU-less host and exports every symbol that
+include/m4depth_hip.h declares; argument validation returns hipErrorInvalidValue
+without touching a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "m4depth_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(m4d_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported():
+    from m4depth_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 19
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/m4depth_hip.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == syms, "ctypes binding and header disagree"
+    assert _lib.lib.m4d_abi_version() == 1
+    assert "gfx950" in _lib.build_info()
+
+
+def test_argument_validation_without_gpu():
+    from m4depth_amd._lib import lib
+    dims = (ctypes.c_int * 6)(1, 4, 4, 1, 1, 3)
+    assert lib.m4d_backproject_fwd(None, None, dims, None, None) == 1
+    assert lib.m4d_dense_image_warp(None, None, 1, 4, 4, 1, None, None, None) == 1
+    assert lib.m4d_sncv_fwd(None, None, 1, 4, 4, 4, 1, 1, 1, None, 9, None) == 1
+    assert lib.m4d_normalize_cuts(None, 1, 4, 4, 4, 1, None, None) == 1
+    assert lib.m4d_bias_act(None, None, 4, 4, 0.1, None, None) == 1
+    fake = ctypes.c_void_p(4096)           # never dereferenced: validation fails first
+    assert lib.m4d_dense_image_warp(fake, fake, 1, 1, 4, 1, fake, None, None) == 1          # H < 2
+    assert lib.m4d_sncv_fwd(fake, fake, 1, 4, 4, 6, 1, 1, 4, fake, 36, None) == 1            # cuts do not divide C
+    assert lib.m4d_dscv_fwd(fake, fake, fake, fake, fake, 5, fake, fake, fake, 1, 4, 4, 4, 1, 1, 0,
+                            fake, 3, None, None, 0, 1.0, None, None) == 1                    # rot_c not in {3,4}
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    import importlib
+    from m4depth_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU / PyTorch fallback"):
+        _lib._load()
+
+
+def test_cpu_tensor_is_rejected():
+    import torch
+    import m4depth_amd as M
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        M.dense_image_warp(torch.zeros(1, 4, 4, 1), torch.zeros(1, 4, 4, 2))
