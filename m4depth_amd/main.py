@@ -1,0 +1,105 @@
+"""Eval / predict driver -- the counterpart of the reference ``main.py --mode=eval``
+(main.py:111-148) and ``--mode=predict`` (:150-172) over a seeded synthetic dataset
+(no dataset or checkpoint exists in the build environment).
+
+    python -m m4depth_amd.main --mode=eval --arch_depth=6 --seq_len=4 --batch_size=2 \\
+           --n_batches=4 --ckpt_dir=/tmp/m4d
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+           -m m4depth_amd.main --mode=eval --batch_size=256        # global batch, sharded
+
+Flag names follow ``m4depth_options.py`` where the flag exists there.  Like the
+reference it writes the 7 metrics with ``%.18e`` (one per line, as np.savetxt does for the 1-D list) to
+``<ckpt_dir>/perfs-<dataset>.txt`` (main.py:144-148).  With several ranks the batch
+is sharded (m4depth_amd.dist) and the metric accumulators are all-gathered over RCCL.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import dist as D
+from . import synthetic as S
+from .metrics import default_metrics
+from .network import M4Depth, M4depthAblationParameters, GraphedSequence
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="M4Depth (MI355X native) eval driver")
+    p.add_argument("--mode", default="eval", choices=["eval", "predict"])
+    p.add_argument("--dataset", default="synthetic")
+    p.add_argument("--arch_depth", type=int, default=6, help="number of pyramid levels (m4depth_options.py:64)")
+    p.add_argument("--seq_len", type=int, default=4)
+    p.add_argument("--db_seq_len", type=int, default=None)
+    p.add_argument("--batch_size", type=int, default=1, help="GLOBAL batch (sharded over ranks)")
+    p.add_argument("--n_batches", type=int, default=2)
+    p.add_argument("--height", type=int, default=384)
+    p.add_argument("--width", type=int, default=1280)
+    p.add_argument("--ckpt_dir", default="ckpt")
+    p.add_argument("--seed", type=int, default=1234)
+    p.add_argument("--graph", action="store_true", help="replay the sequence forward from a hipGraph")
+    for flag in ("DINL", "SNCV", "time_recurr", "normalize_features", "subdivide_features", "level_memory"):
+        p.add_argument(f"--no_{flag}", action="store_true")
+    return p
+
+
+def synthetic_batches(args, rank, world, dev):
+    lo, hi = D.shard_range(args.batch_size, rank, world)
+    for i in range(args.n_batches):
+        samples, cam = S.make_sequence(args.batch_size, args.seq_len, args.height, args.width, seed=args.seed + i)
+        data = {k: torch.from_numpy(np.stack([s[k][lo:hi] for s in samples], axis=1)).to(dev)
+                for k in ("depth", "RGB_im", "rot", "trans")}
+        data["new_traj"] = torch.from_numpy(np.stack([s["new_traj"][lo:hi] for s in samples], axis=1))
+        data["camera"] = {k: torch.from_numpy(v[lo:hi]).to(dev) for k, v in cam.items()}
+        yield data
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    rank, world, _, dev = D.init_from_env()
+    if dev.type != "cuda":
+        raise SystemExit("m4depth_amd.main needs a GPU: the hot path has no CPU fallback")
+    ablation = M4depthAblationParameters(**{f: not getattr(args, f"no_{f}") for f in M4depthAblationParameters._fields})
+    model = M4Depth(nbre_levels=args.arch_depth, ablation_settings=ablation)
+    model.load_numpy_weights(S.init_weights(args.arch_depth, seed=42, ablation=ablation), dev)
+    model.compile(metrics=default_metrics())
+    runner = None
+    preds = []
+    for data in synthetic_batches(args, rank, world, dev):
+        if args.mode == "predict":
+            for t in range(args.seq_len):
+                frame = {k: data[k][:, t] for k in ("depth", "RGB_im", "rot", "trans", "new_traj")}
+                frame["camera"] = data["camera"]
+                preds.append(model.predict_step(frame)["depth"].cpu().numpy())
+            continue
+        if args.graph:
+            if runner is None:
+                model.test_step(data)              # eager warm-up (MIOpen solver search, state allocation)
+                for m in model.compiled_metrics:
+                    m.reset_state()
+                runner = GraphedSequence(model, data)
+            model.graphed_test_step(data, runner)
+        else:
+            model.test_step(data)
+    if args.mode == "predict":
+        if rank == 0:
+            os.makedirs(args.ckpt_dir, exist_ok=True)
+            np.save(os.path.join(args.ckpt_dir, "predictions.npy"), np.concatenate(preds, axis=0))
+        return 0
+    gathered = D.all_gather_metric_states(model.compiled_metrics, dev)
+    metrics = D.reduce_metric_states(gathered).cpu().numpy()
+    if rank == 0:
+        os.makedirs(args.ckpt_dir, exist_ok=True)
+        path = os.path.join(args.ckpt_dir, "perfs-" + args.dataset + ".txt")
+        np.savetxt(path, metrics, fmt='%.18e', delimiter='\t', newline='\n')      # main.py:147 (1-D: one metric per line)
+        for m, v in zip(model.compiled_metrics, metrics):
+            print(f"{m.name}: {v:.6f}")
+        print("wrote", path)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
