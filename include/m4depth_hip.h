@@ -119,6 +119,19 @@ int m4d_dscv_fwd(const float* c1, const float* c2, const float* disp_prev_t, con
                  float* log_center, int log_stride, float log_scale,
                  int32_t* index_out, void* stream);
 
+/* Tuning / debugging hooks of the DSCV (process-wide, not part of the reference surface):
+ * variant 0 = generic kernel, 1 = wave kernel with global gathers (default: fastest measured),
+ * 2 = LDS search-window kernel, 3 / 4 = LDS window with 3 / all hypotheses per lane.  The fallback counter (device uint32, may be NULL) is incremented by
+ * every workgroup of the window kernel whose footprint box did not fit the LDS window. */
+void m4d_dscv_set_variant(int variant);
+void m4d_dscv_set_fallback_counter(unsigned int* device_counter);
+/* Profiling only: ablation mask for the hypothesis-per-lane kernel (1 = skip cv stores, 2 = skip
+ * corner loads, 4 = skip the centre / warped-parallax outputs).  Results are then meaningless. */
+void m4d_dscv_set_ablation(int mask);
+/* Profiling only: 6 uint64 per workgroup of the hypothesis-per-lane kernel = cycle counter at
+ * entry / after the box reduction / after window staging / at exit, window pixels, window width. */
+void m4d_dscv_set_stamps(unsigned long long* device_buffer);
+
 /* cost_volume, the SNCV (:284-313): out channel ((y*(2r+1)+x)*k + kk) =
  * leaky_relu(mean_c c1[j,i,c] * c2pad[j+y*d, i+x*d, c], 0.1), written at
  * out[p*out_stride + channel]. */

@@ -43,7 +43,10 @@ _SIGNATURES = {
                        _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
 }
 
-EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES)
+_VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
+                    "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp]}
+
+EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES) + list(_VOID_SIGNATURES)
 
 
 def _load():
@@ -60,6 +63,10 @@ def _load():
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale: loud by design
         fn.restype = _c_int
+        fn.argtypes = args
+    for name, args in _VOID_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = None
         fn.argtypes = args
     if lib.m4d_abi_version() != 1:
         raise ImportError(f"m4depth_amd: ABI mismatch, library reports {lib.m4d_abi_version()}, binding expects 1")

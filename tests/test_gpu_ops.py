@@ -267,3 +267,29 @@ def test_bias_act_epilogue(M, dev):
             y = x + b
             ref = np.where(y > 0, y, y * F(slope)).astype(F)
             assert_bits_equal(npy(got), ref, f"bias_act C={C} slope={slope}")
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_dscv_kernel_variants_bit_identical(M, dev, variant):
+    """generic / wave / LDS-window / hypothesis-per-lane DSCV kernels: same bits, incl. at a
+    size whose tiles straddle the image border and with large flows (window fallback)."""
+    from m4depth_amd._lib import lib
+    rng = np.random.default_rng(300)
+    try:
+        lib.m4d_dscv_set_variant(variant)
+        for (b, h, w, C, k, tscale) in [(2, 40, 72, 16, 1, 3.0), (1, 24, 40, 32, 2, 3.0), (1, 16, 24, 64, 2, 3.0),
+                                        (1, 20, 44, 16, 1, 40.0)]:
+            cam = camera_np(b, h, w)
+            rot, trans = motion_np(rng, b, t_scale=(tscale, tscale, 1.0))
+            c1 = O.normalize_cuts(rng.standard_normal([b, h, w, C]).astype(F), k)
+            c2 = O.normalize_cuts(rng.standard_normal([b, h, w, C]).astype(F), k)
+            disp = (0.2 + 6.0 * rng.random([b, h, w, 1])).astype(F)
+            dpt = (0.2 + 6.0 * rng.random([b, h, w, 1])).astype(F)
+            ocv, opd, oy, ox = O.get_parallax_sweeping_cv(c1, c2, dpt, disp, rot, trans, cam, 4, k, return_index=True)
+            cv, pd, idx = M.get_parallax_sweeping_cv(*to_dev([c1, c2, dpt, disp, rot, trans], dev), to_dev(cam, dev), 4, k,
+                                                     return_index=True)
+            assert np.array_equal(npy(idx), np.stack([oy, ox], -1))
+            assert_bits_equal(npy(cv), ocv, f"dscv variant {variant} C={C}")
+            assert_bits_equal(npy(pd), opd, f"prev_disp variant {variant}")
+    finally:
+        lib.m4d_dscv_set_variant(1)

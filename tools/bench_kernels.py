@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--which", default="dscv,sncv")
+    ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--smooth", action="store_true", help="replace the parallax maps by smooth fields (coherent gathers)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -64,9 +65,35 @@ def main():
         return lib.m4d_sncv_fwd(dptr(c1), dptr(c1), b, h, w, C, 3, 1, k, ctypes.c_void_p(fin + 4 * (9 * k + 5)), F_in,
                                 stream_ptr())
 
-    for name, fn in (("dscv", run_dscv), ("sncv", run_sncv)):
-        if name not in args.which.split(","):
+    lib.m4d_dscv_set_ablation(args.ablate)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    variants = [("dscv[wave]", run_dscv, 1), ("dscv[lds-window]", run_dscv, 2), ("dscv[lds-hyp]", run_dscv, 3), ("dscv[lds-hyp9]", run_dscv, 4),
+                ("sncv", run_sncv, None)]
+    bytes_["dscv[wave]"] = bytes_["dscv[lds-window]"] = bytes_["dscv[lds-hyp]"] = bytes_["dscv[lds-hyp9]"] = bytes_["dscv"]
+    for name, fn, variant in variants:
+        if name.split("[")[0] not in args.which.split(","):
             continue
+        if variant is not None:
+            lib.m4d_dscv_set_variant(variant)
+            lib.m4d_dscv_set_fallback_counter(ctypes.c_void_p(counter.data_ptr()))
+            counter.zero_()
+            fn()
+            torch.cuda.synchronize()
+            tiles = -(-w // 32) * -(-h // 8) * b
+            print(f"  {name}: fallback workgroups {int(counter.item())} of ~{tiles}", flush=True)
+            lib.m4d_dscv_set_fallback_counter(None)
+            if variant in (3, 4):
+                stamps = torch.zeros((tiles * 4, 6), dtype=torch.int64, device=dev)
+                lib.m4d_dscv_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+                fn()
+                torch.cuda.synchronize()
+                lib.m4d_dscv_set_stamps(None)
+                st = stamps[stamps[:, 0] != 0].double()
+                if len(st):
+                    d = [float((st[:, i + 1] - st[:, i]).mean()) for i in range(3)]
+                    print(f"  {name}: cycles/workgroup box {d[0]:.0f}  stage {d[1]:.0f}  gather+compute {d[2]:.0f}  | window px mean "
+                          f"{float(st[:, 4].mean()):.0f} max {float(st[:, 4].max()):.0f}, width mean {float(st[:, 5].mean()):.1f}; "
+                          f"kernel span {(float(st[:, 3].max()) - float(st[:, 0].min())) / 1e3:.0f} kcycles over {len(st)} workgroups", flush=True)
         for _ in range(3):
             assert fn() == 0
         torch.cuda.synchronize()
