@@ -10,6 +10,7 @@
 // window out of LDS with ds_read_b128.  HBM traffic is the algorithmic minimum
 // plus the halo: read C floats (x halo factor) and write (2r+1)^2 * k floats per
 // pixel.
+#include <cstdlib>
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
 
@@ -130,6 +131,156 @@ sncv_lds_kernel(const SncvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// r = 3, dilation 1, c1 == c2 specialisation with everything known at compile time
+// (channels per cut NC, cuts K, tile TW x TH with TW*TH*K = 256 lanes): every LDS access
+// is ds_read/write with an immediate offset, there is no index arithmetic on runtime tile
+// geometry, the products are formed on register pairs (v_pk_mul_f32), and the workgroup is
+// PERSISTENT: it walks a band of tiles and prefetches the next tile's halo into registers
+// while the current one is being correlated and written out, so the global-load latency
+// (which bounded the one-tile-per-workgroup version at three workgroups per CU) is hidden.
+// Arithmetic: products rounded individually, summed in channel order, / NC, leaky_relu --
+// identical to the oracle, bit for bit.
+typedef float sncv_f2 __attribute__((ext_vector_type(2)));
+
+template <int NC, int K, int TW, int TH>
+__global__ void __launch_bounds__(256)
+sncv7_kernel(const float* __restrict__ c, int b, int h, int w, float* __restrict__ out, int out_stride,
+             int tiles_x, int tiles_y, int tiles_per_wg_band) {
+  constexpr int R = 3, MO = 7;
+  constexpr int C = NC * K, CP = C + 4, C4 = C / 4;
+  constexpr int HWT = TW + 2 * R, HHT = TH + 2 * R;
+  constexpr int P = TW * TH;
+  constexpr int HALO_F4 = HHT * HWT * C4;
+  constexpr int U = (HALO_F4 + 255) / 256;           // float4 loads per lane to stage one halo
+  constexpr int OCH = MO * MO * K;
+  static_assert(P * K == 256, "one (pixel, cut) item per lane");
+  extern __shared__ __align__(16) float tile[];       // halo tile, later re-used as the output stage
+  const int t = threadIdx.x;
+  const int tiles_img = tiles_x * tiles_y;
+  const long long total_tiles = (long long)tiles_img * b;
+  // XCD banding: workgroup g runs on XCD g % 8 and owns every (gridDim/8)-th tile of band g % 8
+  const int nwg = gridDim.x;
+  const int band = blockIdx.x & 7, lane_in_band = blockIdx.x >> 3, wg_per_band = nwg >> 3;
+  const long long band_len = (total_tiles + 7) / 8;
+  const long long band_lo = band * band_len;
+  const long long band_hi = band_lo + band_len < total_tiles ? band_lo + band_len : total_tiles;
+
+  const int kk = t % K, lp = t / K;
+  const int ty = lp / TW, tx = lp % TW;
+
+  float4 pre[U];
+  auto issue_loads = [&](long long tile_id) {
+    const int bi = (int)(tile_id / tiles_img);
+    const int tl = (int)(tile_id - (long long)bi * tiles_img);
+    const int y0 = (tl / tiles_x) * TH - R, x0 = (tl % tiles_x) * TW - R;
+    const float* img = c + (long long)bi * h * w * C;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = u * 256 + t;
+      const int hp = idx / C4, c4 = idx % C4;
+      const int py = hp / HWT, pxx = hp % HWT;
+      const int gy = y0 + py, gx = x0 + pxx;
+      pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);                                   // zero padding (:293)
+      if (idx < HALO_F4 && gy >= 0 && gy < h && gx >= 0 && gx < w)
+        pre[u] = *reinterpret_cast<const float4*>(img + ((long long)gy * w + gx) * C + c4 * 4);
+    }
+  };
+  auto commit_loads = [&]() {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = u * 256 + t;
+      const int hp = idx / C4, c4 = idx % C4;
+      if (idx < HALO_F4) *reinterpret_cast<float4*>(tile + hp * CP + c4 * 4) = pre[u];
+    }
+  };
+
+  long long cur = band_lo + lane_in_band;
+  if (cur >= band_hi) return;
+  issue_loads(cur);
+  commit_loads();
+  __syncthreads();
+  while (true) {
+    const long long nxt = cur + wg_per_band;
+    const bool has_next = nxt < band_hi;
+    if (has_next) issue_loads(nxt);                    // in flight during the whole body below
+
+    const int bi = (int)(cur / tiles_img);
+    const int tl = (int)(cur - (long long)bi * tiles_img);
+    const int tile_y = (tl / tiles_x) * TH, tile_x = (tl % tiles_x) * TW;
+
+    // ---- correlate: lane = (pixel, cut); c1 = the pixel's own vector (tile centre)
+    const float* base = tile + (ty * HWT + tx) * CP + kk * NC;
+    sncv_f2 c1p[NC / 2];
+#pragma unroll
+    for (int cc = 0; cc < NC; cc += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (R * HWT + R) * CP + cc);
+      c1p[cc / 2] = sncv_f2{v.x, v.y};
+      c1p[cc / 2 + 1] = sncv_f2{v.z, v.w};
+    }
+    float res[MO * MO];
+#pragma unroll
+    for (int y = 0; y < MO; ++y) {
+#pragma unroll
+      for (int x = 0; x < MO; ++x) {
+        float acc = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < NC; cc += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(base + (y * HWT + x) * CP + cc);
+          const sncv_f2 pa = c1p[cc / 2] * sncv_f2{v.x, v.y};
+          const sncv_f2 pb = c1p[cc / 2 + 1] * sncv_f2{v.z, v.w};
+          if (cc == 0) acc = pa.x; else acc = acc + pa.x;
+          acc = acc + pa.y; acc = acc + pb.x; acc = acc + pb.y;
+        }
+        const float mean = acc / (float)NC;                             // :308
+        res[y * MO + x] = fmaxf(mean, mean * 0.1f);                     // leaky_relu(0.1) == max(x, 0.1 x) (:311)
+      }
+    }
+    __syncthreads();                                   // every lane is done reading the halo
+    // ---- output rows of the tile, [pixel][(y*7+x)*K + kk], in the same LDS bytes
+#pragma unroll
+    for (int d = 0; d < MO * MO; ++d) tile[lp * OCH + d * K + kk] = res[d];
+    __syncthreads();
+#pragma unroll 7
+    for (int it = 0; it < MO * MO; ++it) {             // P*OCH floats = (P*K/256) * 49 = 49 rounds of 256 lanes
+      const int e = it * 256 + t;
+      const int pxl = e / OCH, ch = e % OCH;
+      const int oy = tile_y + pxl / TW, ox = tile_x + pxl % TW;
+      if (oy < h && ox < w)
+        out[(((long long)bi * h + oy) * w + ox) * out_stride + ch] = tile[e];
+    }
+    if (!has_next) break;
+    __syncthreads();                                   // stage fully read before the halo overwrites it
+    commit_loads();
+    __syncthreads();
+    cur = nxt;
+  }
+}
+
+template <int NC, int K, int TW, int TH>
+bool launch_sncv7(const float* c, int b, int h, int w, float* out, int out_stride, hipStream_t s) {
+  constexpr int C = NC * K, CP = C + 4, HWT = TW + 6, HHT = TH + 6, OCH = 49 * K;
+  constexpr size_t halo = (size_t)HHT * HWT * CP * sizeof(float);
+  constexpr size_t stage = (size_t)TW * TH * OCH * sizeof(float);
+  constexpr size_t lds = halo > stage ? halo : stage;
+  static_assert(lds <= 160 * 1024, "tile does not fit LDS");
+  const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+  const long long total = (long long)tiles_x * tiles_y * b;
+  const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
+  long long nwg = 256LL * (per_cu > 0 ? per_cu : 1);            // persistent: one resident wave of workgroups
+  if (nwg > total) nwg = (total + 7) / 8 * 8;
+  if (nwg < 8) nwg = 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sncv7_kernel<NC, K, TW, TH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((sncv7_kernel<NC, K, TW, TH>), dim3((int)nwg), dim3(256), lds, s, c, b, h, w, out, out_stride,
+                     tiles_x, tiles_y, 0);
+  return true;
+}
+
 // Any C / k / alignment / window: one lane per output element, global reads.
 __global__ void __launch_bounds__(256)
 sncv_generic_kernel(const SncvArgs a, long long total) {
@@ -194,6 +345,17 @@ extern "C" int m4d_sncv_fwd(const float* c1, const float* c2, int b, int h, int 
   const int R = search_range * dilation_rate;
   const bool aligned = (((uintptr_t)c1 | (uintptr_t)c2) & 15u) == 0;
   const bool nc_ok = a.nc == 4 || a.nc == 8 || a.nc == 16 || a.nc == 24 || a.nc == 32;
+  static int variant = -1;                  // M4D_SNCV_VARIANT=0 disables the specialised kernels (debugging)
+  if (variant < 0) { const char* e = getenv("M4D_SNCV_VARIANT"); variant = e ? atoi(e) : 1; }
+  if (variant == 1 && aligned && c1 == c2 && search_range == 3 && dilation_rate == 1) {
+    bool done = false;
+    if (a.nc == 16 && nbre_cuts == 1) done = launch_sncv7<16, 1, 32, 8>(c1, b, h, w, out, out_stride, s);
+    else if (a.nc == 16 && nbre_cuts == 2) done = launch_sncv7<16, 2, 16, 8>(c1, b, h, w, out, out_stride, s);
+    else if (a.nc == 32 && nbre_cuts == 2) done = launch_sncv7<32, 2, 16, 8>(c1, b, h, w, out, out_stride, s);
+    // coarser levels (C >= 96: a few hundred pixels per image) stay on the generic LDS kernel below:
+    // the persistent kernel's 250+ VGPRs buy nothing there (measured slower).
+    if (done) return M4D_LAUNCH_RESULT();
+  }
   // Tile choice: 256 lanes = TH*TW*k items when possible, shrink until the halo fits in LDS.
   int tw = 32, th = 8;
   while (tw * th * nbre_cuts > 256 && tw > 4) tw >>= 1;
