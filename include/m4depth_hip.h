@@ -180,6 +180,22 @@ int m4d_level_post(const float* refiner_out, const float* rot, int rot_c, const 
 int m4d_bias_act(const float* x, const float* bias, long long rows, int C, float slope,
                  float* out, void* stream);
 
+/* DomainNormalization (m4depth_network.py:44-48) fused with the leaky_relu(slope) that follows it
+ * at encoder level 0 (:82-84; slope = 1 for the normalisation alone).  x, out [b,h,w,C] (C = 16 or
+ * 32); mean and the two-pass variance over (h,w) per (b,c); (x-mean)/(var+1e-12); l2-normalise
+ * over channels; scale*n + bias.  workspace: m4d_dinl_workspace_floats(b, C) floats. */
+long long m4d_dinl_workspace_floats(int b, int C);
+int m4d_dinl_fwd(const float* x, const float* scale, const float* bias, int b, int h, int w, int C,
+                 float slope, float* workspace, float* out, void* stream);
+
+/* The 7 metrics of metrics.py (AbsRel, SqRel, RMSE, RMSE_log, Delta1..3) of one batch in one
+ * pass, including test_step's clipping gt in [0,max_d], est in [0.001,max_d]
+ * (m4depth_network.py:465-467).  gt, est: n floats; out7: 7 floats (main.py:127-130 order);
+ * workspace: m4d_metrics_workspace_bytes() bytes. */
+long long m4d_metrics_workspace_bytes(void);
+int m4d_depth_metrics(const float* gt, const float* est, long long n, float max_d, void* workspace,
+                      float* out7, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

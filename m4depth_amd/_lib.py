@@ -37,16 +37,19 @@ _SIGNATURES = {
     "m4d_resize_bilinear_v1": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_resize_nearest": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_bias_act": [_c_fp, _c_fp, ctypes.c_longlong, _c_int, _c_f, _c_fp, _c_fp],
+    "m4d_dinl_fwd": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp, _c_fp],
+    "m4d_depth_metrics": [_c_fp, _c_fp, ctypes.c_longlong, _c_f, _c_fp, _c_fp, _c_fp],
     "m4d_level_pre": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int,
                       _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp],
     "m4d_level_post": [_c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
                        _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
 }
 
+_LL_SIGNATURES = {"m4d_dinl_workspace_floats": [_c_int, _c_int], "m4d_metrics_workspace_bytes": []}
 _VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
                     "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp]}
 
-EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES) + list(_VOID_SIGNATURES)
+EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES) + list(_VOID_SIGNATURES) + list(_LL_SIGNATURES)
 
 
 def _load():
@@ -63,6 +66,10 @@ def _load():
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale: loud by design
         fn.restype = _c_int
+        fn.argtypes = args
+    for name, args in _LL_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_longlong
         fn.argtypes = args
     for name, args in _VOID_SIGNATURES.items():
         fn = getattr(lib, name)

@@ -1,0 +1,201 @@
+// Two small fused reductions that the reference runs as a dozen (DINL) / ~50 (metrics)
+// separate TF ops, and that PyTorch would run as as many tiny kernels:
+//   * DomainNormalization (m4depth_network.py:44-48) fused with the leaky_relu that follows it
+//     at encoder level 0 (:82-84): two deterministic two-stage reductions (mean, then the
+//     two-pass variance TF computes) and ONE apply pass, instead of ~12 passes over the
+//     largest activation of the network ([b,H,W,16]);
+//   * the 7 depth metrics of metrics.py in one pass over (gt, est).
+// Partial sums are combined in a fixed order (no atomics): results are run-to-run identical.
+#include "m4d_common.h"
+#include "../../include/m4depth_hip.h"
+
+namespace {
+
+constexpr int kDinlMaxBlocks = 256;
+
+// pass 0: sum x ; pass 1: sum (x - mean)^2, per (batch, channel); C % 4 == 0, C/4 divides 256
+__global__ void __launch_bounds__(256)
+dinl_partial_kernel(const float* __restrict__ x, const float* __restrict__ mean, int hw, int C, int pass,
+                    float* __restrict__ partial) {
+  __shared__ float4 sh[256];
+  const int bi = blockIdx.y;
+  const int c4n = C >> 2;
+  const int ppi = 256 / c4n;                       // pixels per block iteration
+  const int c4 = threadIdx.x % c4n, po = threadIdx.x / c4n;
+  const float* xb = x + (long long)bi * hw * C;
+  float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pass == 1) m = *reinterpret_cast<const float4*>(mean + bi * C + c4 * 4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p = blockIdx.x * ppi + po; p < hw; p += gridDim.x * ppi) {
+    float4 v = *reinterpret_cast<const float4*>(xb + (long long)p * C + c4 * 4);
+    if (pass == 1) {
+      v.x = v.x - m.x; v.y = v.y - m.y; v.z = v.z - m.z; v.w = v.w - m.w;
+      v.x = v.x * v.x; v.y = v.y * v.y; v.z = v.z * v.z; v.w = v.w * v.w;
+    }
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (po == 0) {                                   // fixed-order combine of the ppi partials of this channel group
+    float4 s = sh[c4];
+    for (int r = 1; r < ppi; ++r) {
+      const float4 v = sh[r * c4n + c4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(partial + ((long long)bi * gridDim.x + blockIdx.x) * C + c4 * 4) = s;
+  }
+}
+
+__global__ void dinl_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int hw, float* __restrict__ out) {
+  const int bi = blockIdx.x, c = threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < nblk; ++k) s += (double)partial[((long long)bi * nblk + k) * C + c];
+  out[bi * C + c] = (float)(s / (double)hw);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+dinl_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
+                  const float* __restrict__ scale, const float* __restrict__ bias, int hw, float slope,
+                  float* __restrict__ out) {
+  const int bi = blockIdx.y;
+  float mu[C], dv[C], sc[C], bs[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    mu[c] = mean[bi * C + c];
+    dv[c] = var[bi * C + c] + 1e-12f;              // (x - mean) / (var + 1e-12): variance, not std (:47)
+    sc[c] = scale[c];
+    bs[c] = bias[c];
+  }
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
+    const float* px = x + ((long long)bi * hw + p) * C;
+    float n[C];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; c += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(px + c);
+      n[c] = (v.x - mu[c]) / dv[c]; n[c + 1] = (v.y - mu[c + 1]) / dv[c + 1];
+      n[c + 2] = (v.z - mu[c + 2]) / dv[c + 2]; n[c + 3] = (v.w - mu[c + 3]) / dv[c + 3];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) ss = ss + n[c] * n[c];
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));                    // tf.math.l2_normalize
+    float* po = out + ((long long)bi * hw + p) * C;
+#pragma unroll
+    for (int c = 0; c < C; c += 4) {
+      float4 o;
+      o.x = sc[c] * (n[c] * inv) + bs[c]; o.y = sc[c + 1] * (n[c + 1] * inv) + bs[c + 1];
+      o.z = sc[c + 2] * (n[c + 2] * inv) + bs[c + 2]; o.w = sc[c + 3] * (n[c + 3] * inv) + bs[c + 3];
+      o.x = o.x > 0.f ? o.x : o.x * slope; o.y = o.y > 0.f ? o.y : o.y * slope;
+      o.z = o.z > 0.f ? o.z : o.z * slope; o.w = o.w > 0.f ? o.w : o.w * slope;
+      *reinterpret_cast<float4*>(po + c) = o;
+    }
+  }
+}
+
+// ---- metrics.py in one pass ---------------------------------------------------------
+constexpr int kMetricSums = 9;
+constexpr int kMetricBlocks = 512;
+
+__global__ void __launch_bounds__(256)
+metrics_partial_kernel(const float* __restrict__ gt_raw, const float* __restrict__ est_raw, long long n, float max_d,
+                       double* __restrict__ partial) {
+  float s[kMetricSums];
+#pragma unroll
+  for (int k = 0; k < kMetricSums; ++k) s[k] = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gt = fminf(fmaxf(gt_raw[i], 0.0f), max_d);               // m4depth_network.py:465-467
+    const float est = fminf(fmaxf(est_raw[i], 0.001f), max_d);
+    const bool m = gt > 1e-6f;                                            // metrics.py:3-5
+    const float diff = gt - est;
+    const float lg = logf(gt + 1e-6f), le = logf(est + 1e-6f);
+    const bool m2 = lg > 1e-6f;                                           // RMSE_log masks on the LOG (metrics.py:24-28)
+    const float th = fmaxf(gt / est, est / gt);
+    if (m) {
+      s[0] += 1.0f;
+      s[1] += fabsf(diff) / (gt + 1e-6f);
+      s[2] += diff * diff / (gt + 1e-6f);
+      s[3] += diff * diff;
+      s[6] += th < 1.25f ? 1.0f : 0.0f;
+      s[7] += th < 1.5625f ? 1.0f : 0.0f;
+      s[8] += th < 1.953125f ? 1.0f : 0.0f;
+    }
+    if (m2) { s[4] += 1.0f; s[5] += (lg - le) * (lg - le); }
+  }
+  __shared__ double sh[4][kMetricSums];
+#pragma unroll
+  for (int k = 0; k < kMetricSums; ++k) {
+    double v = (double)s[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);             // fixed tree: deterministic
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kMetricSums)
+    partial[(long long)blockIdx.x * kMetricSums + threadIdx.x] =
+        ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
+__global__ void metrics_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out7) {
+  __shared__ double tot[kMetricSums];
+  if (threadIdx.x < kMetricSums) {
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += partial[(long long)k * kMetricSums + threadIdx.x];
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double cnt = tot[0] > 1.0 ? tot[0] : 1.0, cnt2 = tot[4] > 1.0 ? tot[4] : 1.0;
+    out7[0] = (float)(tot[1] / cnt);                 // AbsRel
+    out7[1] = (float)(tot[2] / cnt);                 // SqRel
+    out7[2] = sqrtf((float)(tot[3] / cnt));          // RMSE
+    out7[3] = sqrtf((float)(tot[5] / cnt2));         // RMSE_log
+    out7[4] = (float)(tot[6] / cnt);                 // Delta1..3
+    out7[5] = (float)(tot[7] / cnt);
+    out7[6] = (float)(tot[8] / cnt);
+  }
+}
+
+}  // namespace
+
+extern "C" long long m4d_dinl_workspace_floats(int b, int C) {
+  return (long long)b * (kDinlMaxBlocks + 2) * C;
+}
+
+extern "C" int m4d_dinl_fwd(const float* x, const float* scale, const float* bias, int b, int h, int w, int C,
+                            float slope, float* workspace, float* out, void* stream) {
+  M4D_CHECK_ARG(x && scale && bias && workspace && out && b > 0 && h > 0 && w > 0);
+  M4D_CHECK_ARG(C == 16 || C == 32);               // the reference applies DINL to encoder level 0 only (16 channels)
+  M4D_CHECK_ARG(((((uintptr_t)x | (uintptr_t)out | (uintptr_t)workspace)) & 15u) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int hw = h * w;
+  const int ppi = 256 / (C / 4);
+  int nblk = (hw + ppi * 8 - 1) / (ppi * 8);
+  if (nblk > kDinlMaxBlocks) nblk = kDinlMaxBlocks;
+  float* partial = workspace;
+  float* mean = workspace + (long long)b * kDinlMaxBlocks * C;
+  float* var = mean + (long long)b * C;
+  hipLaunchKernelGGL(dinl_partial_kernel, dim3(nblk, b), dim3(256), 0, s, x, (const float*)nullptr, hw, C, 0, partial);
+  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(64), 0, s, partial, nblk, C, hw, mean);
+  hipLaunchKernelGGL(dinl_partial_kernel, dim3(nblk, b), dim3(256), 0, s, x, (const float*)mean, hw, C, 1, partial);
+  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(64), 0, s, partial, nblk, C, hw, var);
+  int gx = m4d_blocks(hw, 256);
+  if (gx > 2048) gx = 2048;
+  if (C == 16) hipLaunchKernelGGL(dinl_apply_kernel<16>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, slope, out);
+  else hipLaunchKernelGGL(dinl_apply_kernel<32>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, slope, out);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" long long m4d_metrics_workspace_bytes(void) { return (long long)kMetricBlocks * kMetricSums * sizeof(double); }
+
+extern "C" int m4d_depth_metrics(const float* gt, const float* est, long long n, float max_d, void* workspace,
+                                 float* out7, void* stream) {
+  M4D_CHECK_ARG(gt && est && workspace && out7 && n > 0);
+  hipStream_t s = (hipStream_t)stream;
+  long long g = (n + 255) / 256;
+  const int nblk = (int)(g < kMetricBlocks ? g : kMetricBlocks);
+  hipLaunchKernelGGL(metrics_partial_kernel, dim3(nblk), dim3(256), 0, s, gt, est, n, max_d, (double*)workspace);
+  hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nblk, out7);
+  return M4D_LAUNCH_RESULT();
+}

@@ -117,9 +117,17 @@ class DomainNormalization(torch.nn.Module):
         self.scale = torch.nn.Parameter(torch.ones(1, 1, 1, channels, device=device), requires_grad=False)
         self.bias = torch.nn.Parameter(torch.zeros(1, 1, 1, channels, device=device), requires_grad=False)
 
-    def forward(self, f_map):
+    def forward(self, f_map, slope=1.0):
+        """``slope`` != 1 additionally applies the leaky_relu that follows the layer in the
+        encoder (fused into the same HIP pass on the GPU)."""
         if self.scale is None:
             self._build(f_map.shape[-1], f_map.device)
+        if f_map.is_cuda and f_map.shape[-1] in (16, 32):
+            return nops.dinl_act(f_map, self.scale, self.bias, slope)
+        out = self._forward_torch(f_map)
+        return out if slope == 1.0 else F.leaky_relu(out, slope)
+
+    def _forward_torch(self, f_map):
         mean = f_map.mean(dim=(1, 2), keepdim=True)
         centred = f_map - mean
         var = (centred * centred).mean(dim=(1, 2), keepdim=True)
@@ -147,7 +155,7 @@ class FeaturePyramid(torch.nn.Module):
         outputs = []
         for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):
             if self.use_dinl and i == 0:
-                tmp = F.leaky_relu(dn_layer(conv_s1(feature_maps)), 0.1)
+                tmp = dn_layer(conv_s1(feature_maps), slope=0.1)
             else:
                 tmp = conv_s1(feature_maps, slope=0.1)
             feature_maps = conv_s2(tmp, slope=0.1)
@@ -314,6 +322,9 @@ class DepthEstimatorPyramid(torch.nn.Module):
     def forward(self, f_maps_pyrs, traj_samples, camera, training=False):
         d_est_seq = []
         n_lvls = len(self.levels)
+        # level-local intrinsics camera / 2**depth (:300-302): the same for every sequence step
+        local_cameras = [{"f": camera["f"] / 2. ** (lvl + 1), "c": camera["c"] / 2. ** (lvl + 1)}
+                         for lvl in range(n_lvls)]
         for seq_i, (f_pyr_curr, sample) in enumerate(zip(f_maps_pyrs, traj_samples)):
             rot = sample['rot']
             trans = sample['trans']
@@ -327,7 +338,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
                 if self.is_training and seq_i != 0:
                     f_maps_prev = f_maps_pyrs[seq_i - 1][-l - 1]
                     d_est_prev = d_est_seq[-1][-l - 1]["depth"]
-                local_camera = {"f": camera["f"] / 2. ** cnter, "c": camera["c"] / 2. ** cnter}
+                local_camera = local_cameras[lvl]
                 d_est = None if d_est_curr is None else dict(d_est_curr[-1])
                 est = level(f_maps_curr, d_est, rot, trans, local_camera, sample["new_traj"],
                             prev_f_maps=f_maps_prev, prev_t_depth=d_est_prev)
@@ -399,6 +410,24 @@ class M4Depth(torch.nn.Module):
     def compile(self, metrics=None, **_unused):
         self.compiled_metrics = list(metrics or [])
 
+    def _update_metrics(self, gt_raw, est_raw, max_d=80.):
+        """compiled_metrics.update_state on the clipped maps (:465-470).  With the default
+        metric list on the GPU all 7 values come from ONE fused HIP pass."""
+        from . import metrics as MT
+        ms = self.compiled_metrics
+        default = (len(ms) == 7 and gt_raw.is_cuda and isinstance(ms[0], MT.AbsRelError) and isinstance(ms[1], MT.SqRelError)
+                   and isinstance(ms[2], MT.RootMeanSquaredError) and isinstance(ms[3], MT.RootMeanSquaredLogError)
+                   and all(isinstance(ms[4 + i], MT.ThresholdRelError) and ms[4 + i].threshold == i + 1 for i in range(3)))
+        if default:
+            vals = nops.depth_metrics(gt_raw, est_raw, max_d)
+            for i, m in enumerate(ms):
+                m._update(vals[i])
+            return
+        gt = torch.clamp(gt_raw, 0.0, max_d)
+        est = torch.clamp(est_raw, 0.001, max_d)
+        for m in ms:
+            m.update_state(gt, est)
+
     @torch.no_grad()
     def test_step(self, data):
         """m4depth_network.py:433-474."""
@@ -418,12 +447,8 @@ class M4Depth(torch.nn.Module):
             est = preds["depth"]
             nt = data["new_traj"]
             new_traj = bool(nt.reshape(-1)[0].item()) if isinstance(nt, torch.Tensor) else bool(np.asarray(nt).reshape(-1)[0])
-        max_d = 80.
-        gt = torch.clamp(gt, 0.0, max_d)                                               # :465-467
-        est = torch.clamp(est, 0.001, max_d)
-        if not new_traj:                                                               # :469-470
-            for m in self.compiled_metrics:
-                m.update_state(gt, est)
+        if not new_traj:                                                               # :465-470
+            self._update_metrics(gt, est, 80.)
         return {m.name: m.result() for m in self.compiled_metrics}
 
     @torch.no_grad()
@@ -436,10 +461,7 @@ class M4Depth(torch.nn.Module):
         """``test_step`` for a 5-D sequence batch with the forward replayed from a
         ``GraphedSequence`` (metrics stay eager: Keras ``Mean`` keeps host-side counts)."""
         est = runner(data)
-        gt = torch.clamp(data["depth"][:, -1], 0.0, 80.)
-        est = torch.clamp(est, 0.001, 80.)
-        for m in self.compiled_metrics:
-            m.update_state(gt, est)
+        self._update_metrics(data["depth"][:, -1], est, 80.)
         return {m.name: m.result() for m in self.compiled_metrics}
 
     def evaluate(self, dataset):

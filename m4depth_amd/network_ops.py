@@ -101,3 +101,40 @@ def bias_act_(x, bias, slope=0.1):
     check(lib.m4d_bias_act(dptr(x, "x"), dptr(bias, "bias"), rows, C, float(slope), dptr(x, "x"), stream_ptr()),
           "m4d_bias_act")
     return x
+
+
+_ws_cache = {}
+
+
+def _workspace(key, nbytes, device):
+    ws = _ws_cache.get((key, device))
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _ws_cache[(key, device)] = ws
+    return ws
+
+
+def dinl_act(x, scale, bias, slope=1.0):
+    """DomainNormalization (m4depth_network.py:44-48) fused with leaky_relu(slope)
+    (slope = 1.0: normalisation alone).  x [b,h,w,C], C in (16, 32)."""
+    x = as_f32(x, "x")
+    b, h, w, C = x.shape
+    ws = _workspace("dinl", 4 * int(lib.m4d_dinl_workspace_floats(b, C)), x.device)
+    out = torch.empty_like(x)
+    check(lib.m4d_dinl_fwd(dptr(x, "x"), dptr(scale.reshape(-1), "scale"), dptr(bias.reshape(-1), "bias"), b, h, w, C,
+                           float(slope), dptr(ws), dptr(out), stream_ptr()), "m4d_dinl_fwd")
+    return out
+
+
+def depth_metrics(gt, est, max_d=80.0):
+    """The 7 metrics of metrics.py for one batch, one pass: returns a [7] device tensor
+    (AbsRel, SqRel, RMSE, RMSE_log, Delta1, Delta2, Delta3); clipping as in test_step."""
+    gt = as_f32(gt, "gt")
+    est = as_f32(est, "est")
+    if gt.numel() != est.numel():
+        raise ValueError(f"gt {tuple(gt.shape)} and est {tuple(est.shape)} differ in size")
+    ws = _workspace("metrics", int(lib.m4d_metrics_workspace_bytes()), gt.device)
+    out = torch.empty(7, dtype=torch.float32, device=gt.device)
+    check(lib.m4d_depth_metrics(dptr(gt, "gt"), dptr(est, "est"), gt.numel(), float(max_d), dptr(ws), dptr(out),
+                                stream_ptr()), "m4d_depth_metrics")
+    return out

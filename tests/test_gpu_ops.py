@@ -293,3 +293,34 @@ def test_dscv_kernel_variants_bit_identical(M, dev, variant):
             assert_bits_equal(npy(pd), opd, f"prev_disp variant {variant}")
     finally:
         lib.m4d_dscv_set_variant(1)
+
+
+def test_fused_dinl_and_metrics(M, dev):
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(13)
+    x = (rng.standard_normal([2, 40, 56, 16]) * 2 + 0.5).astype(F)
+    scale = (1 + 0.1 * rng.standard_normal(16)).astype(F)
+    bias = (0.1 * rng.standard_normal(16)).astype(F)
+    ref = O.domain_normalization(x, scale, bias)
+    got = nops.dinl_act(to_dev(x, dev), to_dev(scale, dev), to_dev(bias, dev), 1.0)
+    assert np.max(np.abs(npy(got) - ref)) < 2e-6                       # reductions in a different (fixed) order
+    got = nops.dinl_act(to_dev(x, dev), to_dev(scale, dev), to_dev(bias, dev), 0.1)
+    assert np.max(np.abs(npy(got) - O.leaky_relu(ref, 0.1))) < 2e-6
+    a = nops.dinl_act(to_dev(x, dev), to_dev(scale, dev), to_dev(bias, dev), 0.1)
+    assert torch.equal(a, got)                                          # deterministic
+    gt = (80 * rng.random([2, 64, 96, 1])).astype(F)
+    gt[0, :7] = 0.0
+    gt[1, 5, :9] = 200.0                                                # above the 80 m clip
+    est = (gt * (1 + 0.2 * rng.standard_normal(gt.shape)) + 0.01).astype(F)
+    est[0, 20, :5] = -3.0                                               # below the 0.001 clip
+    vals = npy(nops.depth_metrics(to_dev(gt, dev), to_dev(est, dev), 80.0))
+    ref = O.metrics_batch(gt, est)
+    assert np.max(rel_err(vals, ref, 1e-6)) < 2e-5, (vals, ref)
+    # the class-based path of the product gives the same numbers
+    mets = M.default_metrics()
+    g = torch.clamp(to_dev(gt, dev), 0.0, 80.0)
+    e = torch.clamp(to_dev(est, dev), 0.001, 80.0)
+    for m in mets:
+        m.update_state(g, e)
+    cls = np.array([float(m.result()) for m in mets])
+    assert np.max(rel_err(vals, cls, 1e-6)) < 2e-5
