@@ -180,11 +180,22 @@ int m4d_level_post(const float* refiner_out, const float* rot, int rot_c, const 
 int m4d_bias_act(const float* x, const float* bias, long long rows, int C, float slope,
                  float* out, void* stream);
 
+/* m4d_bias_act whose result lands inside a larger, zero-bordered [b,out_h,out_w,C] buffer at
+ * (off_y,off_x): the TF 'SAME' padding of the stride-2 encoder convolution that consumes it
+ * (m4depth_network.py:68-72; bottom/right only for even sizes) without a separate pad pass.
+ * The caller keeps the border zero (the kernel never writes it).  C % 4 == 0. */
+int m4d_bias_act_padded(const float* x, const float* bias, int b, int h, int w, int C, float slope,
+                        float* out, int out_h, int out_w, int off_y, int off_x, void* stream);
+
 /* DomainNormalization (m4depth_network.py:44-48) fused with the leaky_relu(slope) that follows it
  * at encoder level 0 (:82-84; slope = 1 for the normalisation alone).  x, out [b,h,w,C] (C = 16 or
  * 32); mean and the two-pass variance over (h,w) per (b,c); (x-mean)/(var+1e-12); l2-normalise
  * over channels; scale*n + bias.  workspace: m4d_dinl_workspace_floats(b, C) floats. */
 long long m4d_dinl_workspace_floats(int b, int C);
+/* ... written into a [b,out_h,out_w,C] buffer at (off_y,off_x) (see m4d_bias_act_padded). */
+int m4d_dinl_fwd_padded(const float* x, const float* scale, const float* bias, int b, int h, int w, int C,
+                        float slope, float* workspace, float* out, int out_h, int out_w, int off_y,
+                        int off_x, void* stream);
 int m4d_dinl_fwd(const float* x, const float* scale, const float* bias, int b, int h, int w, int C,
                  float slope, float* workspace, float* out, void* stream);
 

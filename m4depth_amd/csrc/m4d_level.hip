@@ -199,6 +199,29 @@ bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias, lon
   }
 }
 
+// Same epilogue, written into a zero-bordered [b,out_h,out_w,C] buffer at (off_y, off_x): the
+// TF 'SAME' padding of the stride-2 convolution that follows (bottom/right only for even sizes)
+// then costs nothing -- no separate pad/copy pass over the activation.
+__global__ void __launch_bounds__(256)
+bias_act_padded_kernel(const float* __restrict__ x, const float* __restrict__ bias, int h, int w, int C, float slope,
+                       float* __restrict__ out, int out_h, int out_w, int off_y, int off_x, long long total4) {
+  const int c4n = C >> 2;
+  for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4;
+       i4 += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i4 % c4n) << 2;
+    long long p = i4 / c4n;
+    const int i = (int)(p % w); p /= w;
+    const int j = (int)(p % h);
+    const long long bi = p / h;
+    float4 v = *reinterpret_cast<const float4*>(x + (i4 << 2));
+    const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+    v.x = v.x + bb.x; v.y = v.y + bb.y; v.z = v.z + bb.z; v.w = v.w + bb.w;
+    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+    v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+    *reinterpret_cast<float4*>(out + ((bi * out_h + j + off_y) * out_w + i + off_x) * C + c) = v;
+  }
+}
+
 inline int grid1d(long long total) {
   long long g = (total + 255) / 256;
   if (g > 256 * 32) g = 256 * 32;
@@ -279,5 +302,16 @@ extern "C" int m4d_bias_act(const float* x, const float* bias, long long rows, i
   const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias) & 15u) == 0);
   if (vec) hipLaunchKernelGGL(bias_act_kernel<true>, dim3(grid1d(total >> 2)), dim3(256), 0, (hipStream_t)stream, x, bias, total, C, slope, out);
   else hipLaunchKernelGGL(bias_act_kernel<false>, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, x, bias, total, C, slope, out);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_bias_act_padded(const float* x, const float* bias, int b, int h, int w, int C, float slope,
+                                   float* out, int out_h, int out_w, int off_y, int off_x, void* stream) {
+  M4D_CHECK_ARG(x && bias && out && b > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0);
+  M4D_CHECK_ARG(off_y >= 0 && off_x >= 0 && off_y + h <= out_h && off_x + w <= out_w);
+  M4D_CHECK_ARG(((((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias)) & 15u) == 0);
+  const long long total4 = (long long)b * h * w * (C / 4);
+  hipLaunchKernelGGL(bias_act_padded_kernel, dim3(grid1d(total4)), dim3(256), 0, (hipStream_t)stream,
+                     x, bias, h, w, C, slope, out, out_h, out_w, off_y, off_x, total4);
   return M4D_LAUNCH_RESULT();
 }

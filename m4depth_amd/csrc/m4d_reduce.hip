@@ -46,19 +46,28 @@ dinl_partial_kernel(const float* __restrict__ x, const float* __restrict__ mean,
   }
 }
 
-__global__ void dinl_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int hw, float* __restrict__ out) {
-  const int bi = blockIdx.x, c = threadIdx.x;
-  if (c >= C) return;
+// 256 lanes: lane (j, c) sums every (256/C)-th partial of channel c, then the 256/C sub-sums are
+// combined in index order -- a fixed summation tree, so the result is run-to-run identical.
+__global__ void __launch_bounds__(256)
+dinl_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int hw, float* __restrict__ out) {
+  __shared__ double sh[256];
+  const int bi = blockIdx.x;
+  const int c = threadIdx.x % C, j = threadIdx.x / C, nj = 256 / C;
   double s = 0.0;
-  for (int k = 0; k < nblk; ++k) s += (double)partial[((long long)bi * nblk + k) * C + c];
-  out[bi * C + c] = (float)(s / (double)hw);
+  for (int k = j; k < nblk; k += nj) s += (double)partial[((long long)bi * nblk + k) * C + c];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (j == 0) {
+    for (int r = 1; r < nj; ++r) s += sh[r * C + c];
+    out[bi * C + c] = (float)(s / (double)hw);
+  }
 }
 
 template <int C>
 __global__ void __launch_bounds__(256)
 dinl_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
-                  const float* __restrict__ scale, const float* __restrict__ bias, int hw, float slope,
-                  float* __restrict__ out) {
+                  const float* __restrict__ scale, const float* __restrict__ bias, int hw, int w, float slope,
+                  float* __restrict__ out, int out_h, int out_w, int off_y, int off_x) {
   const int bi = blockIdx.y;
   float mu[C], dv[C], sc[C], bs[C];
 #pragma unroll
@@ -81,7 +90,7 @@ dinl_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, c
 #pragma unroll
     for (int c = 0; c < C; ++c) ss = ss + n[c] * n[c];
     const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));                    // tf.math.l2_normalize
-    float* po = out + ((long long)bi * hw + p) * C;
+    float* po = out + (((long long)bi * out_h + (p / w + off_y)) * out_w + (p % w + off_x)) * C;   // dense or padded target
 #pragma unroll
     for (int c = 0; c < C; c += 4) {
       float4 o;
@@ -137,12 +146,18 @@ metrics_partial_kernel(const float* __restrict__ gt_raw, const float* __restrict
         ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
 }
 
-__global__ void metrics_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out7) {
+__global__ void __launch_bounds__(kMetricSums * 32)
+metrics_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out7) {
+  __shared__ double sub[kMetricSums * 32];
   __shared__ double tot[kMetricSums];
-  if (threadIdx.x < kMetricSums) {
-    double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += partial[(long long)k * kMetricSums + threadIdx.x];
-    tot[threadIdx.x] = s;
+  const int q = threadIdx.x % kMetricSums, j = threadIdx.x / kMetricSums;    // 32 sub-sums per quantity
+  double s = 0.0;
+  for (int k = j; k < nblk; k += 32) s += partial[(long long)k * kMetricSums + q];
+  sub[threadIdx.x] = s;
+  __syncthreads();
+  if (j == 0) {
+    for (int r = 1; r < 32; ++r) s += sub[r * kMetricSums + q];               // fixed order
+    tot[q] = s;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -165,7 +180,14 @@ extern "C" long long m4d_dinl_workspace_floats(int b, int C) {
 
 extern "C" int m4d_dinl_fwd(const float* x, const float* scale, const float* bias, int b, int h, int w, int C,
                             float slope, float* workspace, float* out, void* stream) {
+  return m4d_dinl_fwd_padded(x, scale, bias, b, h, w, C, slope, workspace, out, h, w, 0, 0, stream);
+}
+
+extern "C" int m4d_dinl_fwd_padded(const float* x, const float* scale, const float* bias, int b, int h, int w, int C,
+                                   float slope, float* workspace, float* out, int out_h, int out_w, int off_y,
+                                   int off_x, void* stream) {
   M4D_CHECK_ARG(x && scale && bias && workspace && out && b > 0 && h > 0 && w > 0);
+  M4D_CHECK_ARG(off_y >= 0 && off_x >= 0 && off_y + h <= out_h && off_x + w <= out_w);
   M4D_CHECK_ARG(C == 16 || C == 32);               // the reference applies DINL to encoder level 0 only (16 channels)
   M4D_CHECK_ARG(((((uintptr_t)x | (uintptr_t)out | (uintptr_t)workspace)) & 15u) == 0);
   hipStream_t s = (hipStream_t)stream;
@@ -177,13 +199,13 @@ extern "C" int m4d_dinl_fwd(const float* x, const float* scale, const float* bia
   float* mean = workspace + (long long)b * kDinlMaxBlocks * C;
   float* var = mean + (long long)b * C;
   hipLaunchKernelGGL(dinl_partial_kernel, dim3(nblk, b), dim3(256), 0, s, x, (const float*)nullptr, hw, C, 0, partial);
-  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(64), 0, s, partial, nblk, C, hw, mean);
+  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
   hipLaunchKernelGGL(dinl_partial_kernel, dim3(nblk, b), dim3(256), 0, s, x, (const float*)mean, hw, C, 1, partial);
-  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(64), 0, s, partial, nblk, C, hw, var);
+  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, var);
   int gx = m4d_blocks(hw, 256);
   if (gx > 2048) gx = 2048;
-  if (C == 16) hipLaunchKernelGGL(dinl_apply_kernel<16>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, slope, out);
-  else hipLaunchKernelGGL(dinl_apply_kernel<32>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, slope, out);
+  if (C == 16) hipLaunchKernelGGL(dinl_apply_kernel<16>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, w, slope, out, out_h, out_w, off_y, off_x);
+  else hipLaunchKernelGGL(dinl_apply_kernel<32>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, w, slope, out, out_h, out_w, off_y, off_x);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -196,6 +218,6 @@ extern "C" int m4d_depth_metrics(const float* gt, const float* est, long long n,
   long long g = (n + 255) / 256;
   const int nblk = (int)(g < kMetricBlocks ? g : kMetricBlocks);
   hipLaunchKernelGGL(metrics_partial_kernel, dim3(nblk), dim3(256), 0, s, gt, est, n, max_d, (double*)workspace);
-  hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nblk, out7);
+  hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(kMetricSums * 32), 0, s, (const double*)workspace, nblk, out7);
   return M4D_LAUNCH_RESULT();
 }

@@ -76,6 +76,20 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.bias = torch.nn.Parameter(_to_device_f32(bias, device).contiguous(), requires_grad=False)
 
+    def same_pads(self, h, w):
+        """TF 'SAME' (before, after) pads for rows and columns at this stride."""
+        s = self.stride
+        ph = max((-(-h // s) - 1) * s + 3 - h, 0)
+        pw = max((-(-w // s) - 1) * s + 3 - w, 0)
+        return (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)
+
+    def conv_raw(self, x_nhwc, padding):
+        """The bare MIOpen convolution (no bias) of an NHWC tensor; NHWC result."""
+        if self.weight is None:
+            self._build(x_nhwc.shape[-1], x_nhwc.device)
+        y = F.conv2d(x_nhwc.permute(0, 3, 1, 2), self.weight, None, self.stride, padding).permute(0, 2, 3, 1)
+        return y if y.is_contiguous() else y.contiguous()
+
     def forward(self, x_nhwc, slope=None):
         """Convolution + bias (+ leaky_relu(slope) when ``slope`` is given).  On the GPU the
         bias add and the activation are one in-place HIP epilogue pass instead of two more
@@ -149,8 +163,42 @@ class FeaturePyramid(torch.nn.Module):
         self.conv_layers_s1 = torch.nn.ModuleList([_Conv3x3SameTF(n, 1, ci) for n, ci in zip(self.out_sizes, cin)])
         self.conv_layers_s2 = torch.nn.ModuleList([_Conv3x3SameTF(n, 2, n) for n in self.out_sizes])
         self.dn_layers = torch.nn.ModuleList([DomainNormalization(regularizer_weight) for _ in self.out_sizes])
+        self._padded = {}
+
+    def _padded_buffer(self, shape, device):
+        """Persistent zero-bordered buffers: the stride-1 epilogue writes the interior, the
+        border stays zero, and the stride-2 convolution reads it with padding 0."""
+        key = (tuple(shape), device)
+        buf = self._padded.get(key)
+        if buf is None:
+            buf = torch.zeros(shape, dtype=torch.float32, device=device)
+            self._padded[key] = buf
+        return buf
+
+    def _forward_gpu(self, images):
+        """Same arithmetic as ``forward``'s generic path; the bias / DINL / leaky_relu epilogue of
+        the stride-1 convolution writes straight into the padded input of the stride-2 one."""
+        feature_maps = as_f32(images, "images")
+        outputs = []
+        for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):
+            y = conv_s1.conv_raw(feature_maps, 1)
+            b, h, w, c = y.shape
+            (pt, pb), (pl, pr) = conv_s2.same_pads(h, w)
+            padded = self._padded_buffer((b, h + pt + pb, w + pl + pr, c), y.device)
+            if self.use_dinl and i == 0:
+                nops.bias_act_(y, conv_s1.bias, 1.0)
+                if dn_layer.scale is None:
+                    dn_layer._build(c, y.device)
+                nops.dinl_act(y, dn_layer.scale, dn_layer.bias, 0.1, out=padded, offset=(pt, pl))
+            else:
+                nops.bias_act_padded(y, conv_s1.bias, 0.1, padded, (pt, pl))
+            feature_maps = nops.bias_act_(conv_s2.conv_raw(padded, 0), conv_s2.bias, 0.1)
+            outputs.append(feature_maps)
+        return outputs
 
     def forward(self, images):
+        if isinstance(images, torch.Tensor) and images.is_cuda:
+            return self._forward_gpu(images)
         feature_maps = as_f32(images, "images")
         outputs = []
         for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):

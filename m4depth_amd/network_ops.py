@@ -114,15 +114,28 @@ def _workspace(key, nbytes, device):
     return ws
 
 
-def dinl_act(x, scale, bias, slope=1.0):
+def dinl_act(x, scale, bias, slope=1.0, out=None, offset=(0, 0)):
     """DomainNormalization (m4depth_network.py:44-48) fused with leaky_relu(slope)
-    (slope = 1.0: normalisation alone).  x [b,h,w,C], C in (16, 32)."""
+    (slope = 1.0: normalisation alone).  x [b,h,w,C], C in (16, 32).  ``out`` may be a larger
+    zero-bordered [b,H',W',C] buffer; the result is then written at ``offset`` (row, col)."""
     x = as_f32(x, "x")
     b, h, w, C = x.shape
     ws = _workspace("dinl", 4 * int(lib.m4d_dinl_workspace_floats(b, C)), x.device)
-    out = torch.empty_like(x)
-    check(lib.m4d_dinl_fwd(dptr(x, "x"), dptr(scale.reshape(-1), "scale"), dptr(bias.reshape(-1), "bias"), b, h, w, C,
-                           float(slope), dptr(ws), dptr(out), stream_ptr()), "m4d_dinl_fwd")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.m4d_dinl_fwd_padded(dptr(x, "x"), dptr(scale.reshape(-1), "scale"), dptr(bias.reshape(-1), "bias"),
+                                  b, h, w, C, float(slope), dptr(ws), dptr(out, "out"), out.shape[1], out.shape[2],
+                                  int(offset[0]), int(offset[1]), stream_ptr()), "m4d_dinl_fwd_padded")
+    return out
+
+
+def bias_act_padded(x, bias, slope, out, offset=(0, 0)):
+    """leaky_relu(x + bias, slope) written into the zero-bordered buffer ``out`` [b,H',W',C] at
+    ``offset``: the activation arrives already TF-'SAME'-padded for the stride-2 convolution."""
+    b, h, w, C = x.shape
+    check(lib.m4d_bias_act_padded(dptr(x, "x"), dptr(bias, "bias"), b, h, w, C, float(slope), dptr(out, "out"),
+                                  out.shape[1], out.shape[2], int(offset[0]), int(offset[1]), stream_ptr()),
+          "m4d_bias_act_padded")
     return out
 
 
