@@ -446,7 +446,16 @@ class M4Depth(torch.nn.Module):
     def forward(self, data, training=False):
         traj_samples, camera = data[0], data[1]
         self.step_counter += 1
-        f_maps_pyrs = [self.encoder(sample['RGB_im']) for sample in traj_samples]
+        # The encoder is independent per frame (:358-360): run it ONCE on the frames stacked along
+        # the batch axis (same per-sample arithmetic incl. the per-sample DINL statistics, a
+        # quarter of the launches, larger MIOpen problems), then hand each frame its slice.
+        n_fr = len(traj_samples)
+        if n_fr > 1 and all(s['RGB_im'].shape == traj_samples[0]['RGB_im'].shape for s in traj_samples):
+            bsz = traj_samples[0]['RGB_im'].shape[0]
+            stacked = self.encoder(torch.cat([s['RGB_im'] for s in traj_samples], dim=0))
+            f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in stacked] for t in range(n_fr)]
+        else:
+            f_maps_pyrs = [self.encoder(sample['RGB_im']) for sample in traj_samples]
         d_maps_pyrs = self.d_estimator(f_maps_pyrs, traj_samples, camera, training)
         self.last_estimates = d_maps_pyrs          # per step, per level {depth, parallax, other} (fine -> coarse)
         if training:
