@@ -212,11 +212,20 @@ def main():
     if timer.events:
         summ = timer.summary()
         bytes_l1 = level_bytes(args, args.batch, 1)
+        # HBM traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
+        # WRITE_SIZE, KiB; profiles/r01_pmc_traffic.json), measured on the same kernels at the same
+        # geometry; null when no measurement exists for this batch size.
+        traffic = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = tj.get(f"batch{args.batch}", {})
+        except Exception:
+            pass
         dom = max(summ, key=lambda k: summ[k][1])
         for name, (n, sec) in summ.items():
             gbs = bytes_l1[name] / sec / 1e9
             rec = {"kernel": f"{name}_level1", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
                    "algorithmic_bytes_per_launch": bytes_l1[name], "avg_launch_us": round(sec * 1e6, 2), "launches": n}
             out["roofline" if name == dom else f"roofline_{name}"] = rec
     if not args.no_cpu_baseline and world == 1:

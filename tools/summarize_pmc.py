@@ -9,7 +9,7 @@ for r in rows:
     name = r.get("Kernel_Name", "")
     if "anonymous namespace" not in name:
         continue
-    short = name.split("::")[-1].split("(")[0]
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     for c, v in d.items():
