@@ -187,6 +187,16 @@ int m4d_bias_act(const float* x, const float* bias, long long rows, int C, float
 int m4d_bias_act_padded(const float* x, const float* bias, int b, int h, int w, int C, float slope,
                         float* out, int out_h, int out_w, int off_y, int off_x, void* stream);
 
+/* Keras Conv2D(Cout, 3, strides 1, padding 'same') + bias + leaky_relu(slope) (slope = 1: no
+ * activation) in one launch on the f32-input matrix cores (m4depth_network.py:104-135, :63-67).
+ * x [b,h,w,Cin] NHWC (Cin even), out [b,h,w,Cout].  wp: the HWIO kernel re-packed by the host as
+ * [ceil(Cin/16)][9 taps (ky*3+kx)][CoutPad][16] with CoutPad = Cout rounded up to 32, input
+ * channels of a chunk stored even-first (0,2,..,14,1,3,..,15), zero padded
+ * (m4depth_amd.network_ops.pack_conv_weights).  Deterministic; float32 exact (fmaf chain over
+ * chunk, ky, kx, channel). */
+int m4d_conv3x3_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                         int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
+
 /* DomainNormalization (m4depth_network.py:44-48) fused with the leaky_relu(slope) that follows it
  * at encoder level 0 (:82-84; slope = 1 for the normalisation alone).  x, out [b,h,w,C] (C = 16 or
  * 32); mean and the two-pass variance over (h,w) per (b,c); (x-mean)/(var+1e-12); l2-normalise

@@ -1,0 +1,204 @@
+// 3x3 / stride 1 / 'SAME' convolution on NHWC float32 with the Keras bias add and the
+// leaky_relu that follows it fused into the epilogue (m4depth_network.py:104-135: the seven
+// DispRefiner convolutions; :63-67: the stride-1 encoder convolutions) -- the "next" row f-2 of
+// 70 of the 73.6 GMAC of a frame.
+//
+// Implicit GEMM on the f32-input matrix cores: v_mfma_f32_32x32x2_f32 is exact float32 (bitwise
+// an fmaf chain in k order: one rounding per product-accumulate, no wider accumulator), runs at
+// the fp32 vector peak (157 TFLOP/s) and is DETERMINISTIC -- unlike several of the MIOpen
+// solvers this replaces (atomic split-K; tools/debug_determinism3.py).
+//
+//   M = pixels, N = output channels, K = 9 taps x Cin.
+//   workgroup = 4 waves = one 16x8 pixel tile x BN = 32*NT output channels; wave w owns tile
+//   rows 2w, 2w+1 (32 pixels = one MFMA M-tile) and NT accumulators (32 x 32 each).
+//   K is walked in chunks of 16 input channels; per chunk the (16+2)x(8+2) halo of the input is
+//   staged once in LDS and used by all 9 taps (the 3x3 window is an LDS address offset), the
+//   weights of 3 taps at a time.  Channels are stored even-first/odd-last inside a chunk so
+//   that the two k-lanes of the MFMA (lane>>5) read the 8 k-steps of a chunk as two
+//   ds_read_b128; rows are padded to 20 floats (conflict-free 16-byte reads).
+//   The global loads of the NEXT stage are issued into registers before the MFMAs of the
+//   current one (software pipeline), so one workgroup per SIMD already hides memory latency.
+#include "m4d_common.h"
+#include "../../include/m4depth_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* x; const float* wp; const float* bias; float* out;
+  int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
+  float slope;
+};
+
+constexpr int kTW = 16, kTH = 8, kHWT = kTW + 2, kHHT = kTH + 2, kHP = kHWT * kHHT;   // 180 halo pixels
+constexpr int kKC = 16, kRS = 20;                                                   // chunk size, LDS row stride (floats)
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+conv3x3_mfma_kernel(const ConvArgs a) {
+  constexpr int BN = 32 * NT;
+  constexpr int A_F2 = kHP * (kKC / 2);               // float2 loads to stage one halo chunk (1440)
+  constexpr int A_PER = (A_F2 + 255) / 256;           // 6
+  constexpr int B_F4 = 3 * BN * (kKC / 4);            // float4 loads to stage 3 taps of weights
+  constexpr int B_PER = (B_F4 + 255) / 256;           // 6 at NT = 4
+  __shared__ __align__(16) float lds_a[kHP * kRS];
+  __shared__ __align__(16) float lds_b[3 * BN * kRS];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int tile = blockIdx.x;
+  const int tile_y = (tile / a.tiles_x) * kTH, tile_x = (tile % a.tiles_x) * kTW;
+  const int n0 = blockIdx.y * BN;
+  const int bi = blockIdx.z;
+  const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
+
+  float2 ra[A_PER];
+  float4 rb[B_PER];
+
+  // ---- stage loaders (global -> registers) and committers (registers -> LDS)
+  auto load_a = [&](int chunk) {
+    const int c0 = chunk * kKC;
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const int idx = u * 256 + t;
+      const int hp = idx >> 3, k2 = (idx & 7) * 2;     // halo pixel, channel pair inside the chunk
+      const int gy = tile_y - 1 + hp / kHWT, gx = tile_x - 1 + hp % kHWT;
+      ra[u] = make_float2(0.f, 0.f);
+      if (idx < A_F2 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && c0 + k2 < a.Cin)
+        ra[u] = *reinterpret_cast<const float2*>(ximg + ((long long)gy * a.w + gx) * a.Cin + c0 + k2);
+    }
+  };
+  auto commit_a = [&]() {
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const int idx = u * 256 + t;
+      const int hp = idx >> 3, kp = idx & 7;
+      if (idx < A_F2) {                                // even channel -> slot kp, odd channel -> slot 8 + kp
+        lds_a[hp * kRS + kp] = ra[u].x;
+        lds_a[hp * kRS + 8 + kp] = ra[u].y;
+      }
+    }
+  };
+  auto load_b = [&](int chunk, int s) {
+    // wp layout: [chunk][tap][CoutPad][16 (even-first)] -> rows n0..n0+BN of taps 3s..3s+2
+#pragma unroll
+    for (int u = 0; u < B_PER; ++u) {
+      const int idx = u * 256 + t;
+      const int row = idx >> 2, c4 = idx & 3;          // row = tap_local * BN + n
+      const int tl = row / BN, n = row % BN;
+      rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < B_F4)
+        rb[u] = *reinterpret_cast<const float4*>(
+            a.wp + ((((long long)chunk * 9 + 3 * s + tl) * a.CoutPad + n0 + n) * kKC + c4 * 4));
+    }
+  };
+  auto commit_b = [&]() {
+#pragma unroll
+    for (int u = 0; u < B_PER; ++u) {
+      const int idx = u * 256 + t;
+      const int row = idx >> 2, c4 = idx & 3;
+      if (idx < B_F4) *reinterpret_cast<float4*>(lds_b + row * kRS + c4 * 4) = rb[u];
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+  const int m = lane & 31, kh = lane >> 5;
+  const int prow = 2 * wave + (m >> 4), pcol = m & 15;        // pixel of this lane inside the tile
+  const float* a_lane = lds_a + (prow * kHWT + pcol) * kRS + kh * 8;
+  const float* b_lane = lds_b + m * kRS + kh * 8;
+
+  load_a(0);
+  load_b(0, 0);
+  commit_a();
+  commit_b();
+  __syncthreads();
+  const int n_stages = a.n_chunks * 3;
+  for (int st = 0; st < n_stages; ++st) {
+    const int chunk = st / 3, s = st - chunk * 3;
+    const bool has_next = st + 1 < n_stages;
+    const int nchunk = (st + 1) / 3, ns = (st + 1) - nchunk * 3;
+    if (has_next) {
+      load_b(nchunk, ns);
+      if (ns == 0) load_a(nchunk);
+    }
+    // ---- 3 taps (ky = s, kx = 0..2) x 8 k-steps x NT tiles
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float* ap = a_lane + (s * kHWT + kx) * kRS;
+      const float4 a0 = *reinterpret_cast<const float4*>(ap);
+      const float4 a1 = *reinterpret_cast<const float4*>(ap + 4);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      float bv[NT][8];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float* bp = b_lane + (kx * BN + nt * 32) * kRS;
+        const float4 b0 = *reinterpret_cast<const float4*>(bp);
+        const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
+        bv[nt][0] = b0.x; bv[nt][1] = b0.y; bv[nt][2] = b0.z; bv[nt][3] = b0.w;
+        bv[nt][4] = b1.x; bv[nt][5] = b1.y; bv[nt][6] = b1.z; bv[nt][7] = b1.w;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[nt][ks], acc[nt], 0, 0, 0);
+    }
+    __syncthreads();                                   // all waves done with lds_b (and lds_a when ns == 0)
+    if (has_next) {
+      commit_b();
+      if (ns == 0) commit_a();
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: + bias, leaky_relu, NHWC store.  C/D map of the 32x32 MFMA:
+  //      col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = n0 + nt * 32 + m;
+    const float bias = co < a.Cout ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;  // pixel index inside the wave's 32
+      const int oy = tile_y + 2 * wave + (mr >> 4), ox = tile_x + (mr & 15);
+      if (co < a.Cout && oy < a.h && ox < a.w) {
+        float v = acc[nt][r] + bias;
+        v = v > 0.f ? v : v * a.slope;
+        oimg[((long long)oy * a.w + ox) * a.Cout + co] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int m4d_conv3x3_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                                    int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  M4D_CHECK_ARG(x && wp && bias && out && b > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0);
+  M4D_CHECK_ARG(Cin % 2 == 0 && CoutPad % 32 == 0 && CoutPad >= Cout);
+  M4D_CHECK_ARG(((((uintptr_t)x) & 7u) == 0) && ((((uintptr_t)wp) & 15u) == 0));
+  ConvArgs a;
+  a.x = x; a.wp = wp; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
+  a.CoutPad = CoutPad; a.n_chunks = (Cin + kKC - 1) / kKC;
+  a.tiles_x = (w + kTW - 1) / kTW; a.tiles_y = (h + kTH - 1) / kTH; a.slope = slope;
+  const long long tiles = (long long)a.tiles_x * a.tiles_y;
+  const int n32 = CoutPad / 32;
+  // N-tiles per workgroup: as wide as possible (A reuse) while the launch still fills the chip
+  int nt = n32 >= 4 && n32 % 4 == 0 ? 4 : (n32 % 3 == 0 ? 3 : (n32 % 2 == 0 ? 2 : 1));
+  while (nt > 1 && tiles * b * (n32 / nt) < 512) nt = (nt == 4 || nt == 2) ? nt / 2 : 1;
+  const dim3 grid((unsigned)tiles, (unsigned)(n32 / nt), (unsigned)b), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (nt) {
+    case 4: hipLaunchKernelGGL(conv3x3_mfma_kernel<4>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(conv3x3_mfma_kernel<3>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(conv3x3_mfma_kernel<2>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, grid, block, 0, s, a); break;
+  }
+  return M4D_LAUNCH_RESULT();
+}

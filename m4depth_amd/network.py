@@ -32,6 +32,11 @@ M4depthAblationParameters = namedtuple('M4depthAblationParameters',
 
 _CV_ACCUM = {"fp32_round": 0, "fp16_seq": 1}
 
+# Stride-1 3x3 convolutions with at least this many output pixels (b*h*w) run on the hand-written
+# fp32-MFMA kernel with fused bias/leaky-relu epilogue (csrc/m4d_conv.hip); smaller ones (the
+# coarsest pyramid levels: one or two workgroups of work, long K) stay on MIOpen.  0 disables.
+mfma_conv_min_pixels = 4096
+
 # bench.py installs an object with ``run(name, level, thunk)`` here to bracket the
 # hand-written kernels with HIP events on the launch stream; None = no overhead.
 kernel_timer = None
@@ -61,6 +66,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.stride = stride
         self.weight = None
         self.bias = None
+        self._packed = None
         if in_channels is not None:
             self._build(in_channels, None)
 
@@ -69,12 +75,22 @@ class _Conv3x3SameTF(torch.nn.Module):
         torch.nn.init.kaiming_normal_(w, nonlinearity='relu')       # ks.initializers.HeNormal (:61,:100)
         self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.bias = torch.nn.Parameter(torch.zeros(self.out_channels, device=device), requires_grad=False)
+        self._packed = None
 
     def load_hwio(self, kernel, bias, device):
         """Load a TF-layout [3,3,Cin,Cout] kernel."""
         w = _to_device_f32(kernel, device).permute(3, 2, 0, 1)
         self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.bias = torch.nn.Parameter(_to_device_f32(bias, device).contiguous(), requires_grad=False)
+        self._packed = None
+
+    def _packed_weights(self):
+        """(wp, CoutPad) for m4d_conv3x3_bias_act, packed once from the OIHW parameter."""
+        if self._packed is None or self._packed[0].device != self.weight.device:
+            hwio = self.weight.detach().permute(2, 3, 1, 0).cpu().numpy()
+            wp, cpad = nops.pack_conv_weights(hwio)
+            self._packed = (torch.from_numpy(wp).to(self.weight.device), cpad)
+        return self._packed
 
     def same_pads(self, h, w):
         """TF 'SAME' (before, after) pads for rows and columns at this stride."""
@@ -96,6 +112,11 @@ class _Conv3x3SameTF(torch.nn.Module):
         PyTorch kernels; on CPU tensors (host-logic tests) plain torch ops are used."""
         if self.weight is None:
             self._build(x_nhwc.shape[-1], x_nhwc.device)
+        if (x_nhwc.is_cuda and self.stride == 1 and mfma_conv_min_pixels > 0 and x_nhwc.shape[-1] % 2 == 0
+                and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= mfma_conv_min_pixels):
+            wp, cpad = self._packed_weights()
+            return nops.conv3x3_bias_act(x_nhwc, wp, self.bias, self.out_channels, cpad,
+                                         1.0 if slope is None else slope)
         x = x_nhwc.permute(0, 3, 1, 2)                   # channels-last NCHW view, no copy
         h, w = x.shape[2:]
         s = self.stride

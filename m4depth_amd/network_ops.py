@@ -151,3 +151,30 @@ def depth_metrics(gt, est, max_d=80.0):
     check(lib.m4d_depth_metrics(dptr(gt, "gt"), dptr(est, "est"), gt.numel(), float(max_d), dptr(ws), dptr(out),
                                 stream_ptr()), "m4d_depth_metrics")
     return out
+
+
+def pack_conv_weights(kernel_hwio):
+    """Re-pack a TF HWIO [3,3,Cin,Cout] kernel for m4d_conv3x3_bias_act:
+    [ceil(Cin/16)][9][CoutPad][16], CoutPad = Cout rounded up to 32, the 16 input channels of a
+    chunk stored even-first, zero padded.  numpy in, numpy out (host side, once per model)."""
+    import numpy as np
+    k = np.asarray(kernel_hwio, dtype=np.float32)
+    assert k.shape[:2] == (3, 3)
+    cin, cout = k.shape[2], k.shape[3]
+    nch = -(-cin // 16)
+    cpad = -(-cout // 32) * 32
+    full = np.zeros((3, 3, nch * 16, cpad), np.float32)
+    full[:, :, :cin, :cout] = k
+    perm = np.array([0, 2, 4, 6, 8, 10, 12, 14, 1, 3, 5, 7, 9, 11, 13, 15])
+    w = full.reshape(9, nch, 16, cpad)[:, :, perm, :]            # [tap][chunk][16p][n]
+    return np.ascontiguousarray(w.transpose(1, 0, 3, 2)), cpad    # [chunk][tap][n][16p]
+
+
+def conv3x3_bias_act(x, wp, bias, cout, cout_pad, slope=0.1):
+    """3x3 stride-1 'SAME' convolution + bias + leaky_relu(slope) on the matrix cores."""
+    x = as_f32(x, "x")
+    b, h, w, cin = x.shape
+    out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    check(lib.m4d_conv3x3_bias_act(dptr(x, "x"), dptr(wp, "wp"), dptr(bias, "bias"), b, h, w, cin, int(cout),
+                                   int(cout_pad), float(slope), dptr(out), stream_ptr()), "m4d_conv3x3_bias_act")
+    return out
