@@ -196,6 +196,13 @@ int m4d_bias_act_padded(const float* x, const float* bias, int b, int h, int w, 
  * chunk, ky, kx, channel). */
 int m4d_conv3x3_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
                          int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
+/* Same, with a caller-owned workspace (m4d_conv3x3_workspace_floats floats) that lets small
+ * problems (coarse pyramid levels: a handful of pixel tiles, K up to 9*470) split K over
+ * workgroups; partial sums are reduced in split order by a second kernel (still deterministic). */
+long long m4d_conv3x3_workspace_floats(int b, int h, int w, int CoutPad);
+int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                            int Cin, int Cout, int CoutPad, float slope, float* out, float* workspace,
+                            long long workspace_floats, void* stream);
 
 /* DomainNormalization (m4depth_network.py:44-48) fused with the leaky_relu(slope) that follows it
  * at encoder level 0 (:82-84; slope = 1 for the normalisation alone).  x, out [b,h,w,C] (C = 16 or

@@ -42,6 +42,8 @@ _SIGNATURES = {
                             _c_int, _c_int, _c_int, _c_int, _c_fp],
     "m4d_bias_act_padded": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_fp],
     "m4d_conv3x3_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
+    "m4d_conv3x3_bias_act_ws": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp,
+                                _c_fp, ctypes.c_longlong, _c_fp],
     "m4d_depth_metrics": [_c_fp, _c_fp, ctypes.c_longlong, _c_f, _c_fp, _c_fp, _c_fp],
     "m4d_level_pre": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int,
                       _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp],
@@ -49,7 +51,8 @@ _SIGNATURES = {
                        _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
 }
 
-_LL_SIGNATURES = {"m4d_dinl_workspace_floats": [_c_int, _c_int], "m4d_metrics_workspace_bytes": []}
+_LL_SIGNATURES = {"m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
+                  "m4d_dinl_workspace_floats": [_c_int, _c_int], "m4d_metrics_workspace_bytes": []}
 _VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
                     "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp]}
 

@@ -29,6 +29,8 @@ struct ConvArgs {
   const float* x; const float* wp; const float* bias; float* out;
   int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
   float slope;
+  int ksplit, chunks_per_split;       // split-K (coarse pyramid levels): partial sums -> ws, reduced in order
+  float* ws;
 };
 
 constexpr int kTW = 16, kTH = 8, kHWT = kTW + 2, kHHT = kTH + 2, kHP = kHWT * kHHT;   // 180 halo pixels
@@ -49,7 +51,9 @@ conv3x3_mfma_kernel(const ConvArgs a) {
   const int tile = blockIdx.x;
   const int tile_y = (tile / a.tiles_x) * kTH, tile_x = (tile % a.tiles_x) * kTW;
   const int n0 = blockIdx.y * BN;
-  const int bi = blockIdx.z;
+  const int bi = blockIdx.z / a.ksplit, ks = blockIdx.z - bi * a.ksplit;
+  const int chunk_lo = ks * a.chunks_per_split;
+  const int chunk_hi = min(chunk_lo + a.chunks_per_split, a.n_chunks);
   const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
 
   float2 ra[A_PER];
@@ -112,16 +116,16 @@ conv3x3_mfma_kernel(const ConvArgs a) {
   const float* a_lane = lds_a + (prow * kHWT + pcol) * kRS + kh * 8;
   const float* b_lane = lds_b + m * kRS + kh * 8;
 
-  load_a(0);
-  load_b(0, 0);
+  load_a(chunk_lo);
+  load_b(chunk_lo, 0);
   commit_a();
   commit_b();
   __syncthreads();
-  const int n_stages = a.n_chunks * 3;
+  const int n_stages = (chunk_hi - chunk_lo) * 3;
   for (int st = 0; st < n_stages; ++st) {
-    const int chunk = st / 3, s = st - chunk * 3;
+    const int s = st % 3;
     const bool has_next = st + 1 < n_stages;
-    const int nchunk = (st + 1) / 3, ns = (st + 1) - nchunk * 3;
+    const int nchunk = chunk_lo + (st + 1) / 3, ns = (st + 1) % 3;
     if (has_next) {
       load_b(nchunk, ns);
       if (ns == 0) load_a(nchunk);
@@ -158,6 +162,20 @@ conv3x3_mfma_kernel(const ConvArgs a) {
 
   // ---- epilogue: + bias, leaky_relu, NHWC store.  C/D map of the 32x32 MFMA:
   //      col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  if (a.ksplit > 1) {                                  // raw partial sums; conv_splitk_reduce_kernel finishes
+    float* wimg = a.ws + ((long long)ks * a.b + bi) * a.h * a.w * a.CoutPad;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = n0 + nt * 32 + m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int oy = tile_y + 2 * wave + (mr >> 4), ox = tile_x + (mr & 15);
+        if (oy < a.h && ox < a.w) wimg[((long long)oy * a.w + ox) * a.CoutPad + co] = acc[nt][r];
+      }
+    }
+    return;
+  }
   float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -176,10 +194,35 @@ conv3x3_mfma_kernel(const ConvArgs a) {
   }
 }
 
+// out = leaky_relu(bias + sum_ks ws[ks]) with the partial sums added in split order (deterministic)
+__global__ void __launch_bounds__(256)
+conv_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias, long long pixels, int Cout,
+                          int CoutPad, int ksplit, float slope, float* __restrict__ out) {
+  const long long total = pixels * Cout;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / Cout;
+    const int co = (int)(i - p * Cout);
+    float v = ws[p * CoutPad + co];
+    for (int k = 1; k < ksplit; ++k) v = v + ws[((long long)k * pixels + p) * CoutPad + co];
+    v = v + bias[co];
+    out[i] = v > 0.f ? v : v * slope;
+  }
+}
+
 }  // namespace
 
 extern "C" int m4d_conv3x3_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
                                     int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  return m4d_conv3x3_bias_act_ws(x, wp, bias, b, h, w, Cin, Cout, CoutPad, slope, out, nullptr, 0, stream);
+}
+
+extern "C" long long m4d_conv3x3_workspace_floats(int b, int h, int w, int CoutPad) {
+  return 16LL * b * h * w * CoutPad;                   // up to 16 K-splits
+}
+
+extern "C" int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                                    int Cin, int Cout, int CoutPad, float slope, float* out, float* workspace,
+                                       long long workspace_floats, void* stream) {
   M4D_CHECK_ARG(x && wp && bias && out && b > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0);
   M4D_CHECK_ARG(Cin % 2 == 0 && CoutPad % 32 == 0 && CoutPad >= Cout);
   M4D_CHECK_ARG(((((uintptr_t)x) & 7u) == 0) && ((((uintptr_t)wp) & 15u) == 0));
@@ -192,13 +235,33 @@ extern "C" int m4d_conv3x3_bias_act(const float* x, const float* wp, const float
   // N-tiles per workgroup: as wide as possible (A reuse) while the launch still fills the chip
   int nt = n32 >= 4 && n32 % 4 == 0 ? 4 : (n32 % 3 == 0 ? 3 : (n32 % 2 == 0 ? 2 : 1));
   while (nt > 1 && tiles * b * (n32 / nt) < 512) nt = (nt == 4 || nt == 2) ? nt / 2 : 1;
-  const dim3 grid((unsigned)tiles, (unsigned)(n32 / nt), (unsigned)b), block(256);
+  // split-K when even the narrowest N split leaves most of the chip idle (coarse pyramid levels):
+  // every split keeps >= 2 chunks, partial sums go through the caller's workspace
+  const long long blocks = tiles * b * (n32 / nt);
+  int ksplit = 1;
+  if (workspace != nullptr && blocks < 128 && a.n_chunks >= 4) {
+    ksplit = (int)((256 + blocks - 1) / blocks);
+    if (ksplit > a.n_chunks / 2) ksplit = a.n_chunks / 2;
+    if (ksplit > 16) ksplit = 16;
+    while (ksplit > 1 && (long long)ksplit * b * h * w * CoutPad > workspace_floats) --ksplit;
+  }
+  a.chunks_per_split = (a.n_chunks + ksplit - 1) / ksplit;
+  ksplit = (a.n_chunks + a.chunks_per_split - 1) / a.chunks_per_split;     // no empty split
+  a.ksplit = ksplit; a.ws = workspace;
+  const dim3 grid((unsigned)tiles, (unsigned)(n32 / nt), (unsigned)(b * ksplit)), block(256);
   hipStream_t s = (hipStream_t)stream;
   switch (nt) {
     case 4: hipLaunchKernelGGL(conv3x3_mfma_kernel<4>, grid, block, 0, s, a); break;
     case 3: hipLaunchKernelGGL(conv3x3_mfma_kernel<3>, grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL(conv3x3_mfma_kernel<2>, grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, grid, block, 0, s, a); break;
+  }
+  if (ksplit > 1) {
+    const long long pixels = (long long)b * h * w;
+    long long g = (pixels * Cout + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, workspace, bias, pixels, Cout,
+                       CoutPad, ksplit, slope, out);
   }
   return M4D_LAUNCH_RESULT();
 }

@@ -33,9 +33,10 @@ M4depthAblationParameters = namedtuple('M4depthAblationParameters',
 _CV_ACCUM = {"fp32_round": 0, "fp16_seq": 1}
 
 # Stride-1 3x3 convolutions with at least this many output pixels (b*h*w) run on the hand-written
-# fp32-MFMA kernel with fused bias/leaky-relu epilogue (csrc/m4d_conv.hip); smaller ones (the
-# coarsest pyramid levels: one or two workgroups of work, long K) stay on MIOpen.  0 disables.
-mfma_conv_min_pixels = 4096
+# fp32-MFMA kernel with fused bias/leaky-relu epilogue (csrc/m4d_conv.hip), which beats MIOpen +
+# epilogue on every layer of every level (tools/bench_conv.py); 0 disables it (MIOpen everywhere).
+import os as _os
+mfma_conv_min_pixels = int(_os.environ.get("M4D_MFMA_CONV_MIN_PIXELS", "1"))
 
 # bench.py installs an object with ``run(name, level, thunk)`` here to bracket the
 # hand-written kernels with HIP events on the launch stream; None = no overhead.

@@ -175,6 +175,12 @@ def conv3x3_bias_act(x, wp, bias, cout, cout_pad, slope=0.1):
     x = as_f32(x, "x")
     b, h, w, cin = x.shape
     out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
-    check(lib.m4d_conv3x3_bias_act(dptr(x, "x"), dptr(wp, "wp"), dptr(bias, "bias"), b, h, w, cin, int(cout),
-                                   int(cout_pad), float(slope), dptr(out), stream_ptr()), "m4d_conv3x3_bias_act")
+    ws = None
+    ws_floats = 0
+    if b * h * w <= 16384:                               # coarse levels: allow split-K through a workspace
+        ws_floats = int(lib.m4d_conv3x3_workspace_floats(b, h, w, int(cout_pad)))
+        ws = _workspace("conv_splitk", 4 * ws_floats, x.device)
+    check(lib.m4d_conv3x3_bias_act_ws(dptr(x, "x"), dptr(wp, "wp"), dptr(bias, "bias"), b, h, w, cin, int(cout),
+                                      int(cout_pad), float(slope), dptr(out), dptr(ws), ws_floats, stream_ptr()),
+          "m4d_conv3x3_bias_act_ws")
     return out
