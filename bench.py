@@ -206,7 +206,9 @@ def main():
                                "(BASELINE.json configs[1] when batch=1, configs[2] when batch=32)",
                    "global_batch": world * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",
-                   "conv_backend": "MIOpen fp32 (PyTorch-ROCm)", "hot_path": "libm4depth_hip.so (HIP, gfx950)"},
+                   "conv_backend": "stride-1 3x3 convs: hand-written fp32-MFMA implicit GEMM with fused bias+leaky-relu "
+                                   "(libm4depth_hip.so); stride-2 / 3-channel encoder convs: MIOpen fp32",
+                   "hot_path": "libm4depth_hip.so (HIP, gfx950)"},
         "AbsRel": round(metrics[0], 6), "launch": "eager" if args.eager else "hipGraph replay of the sequence forward",
     }
     if timer.events:

@@ -36,16 +36,20 @@ struct ConvArgs {
 constexpr int kTW = 16, kTH = 8, kHWT = kTW + 2, kHHT = kTH + 2, kHP = kHWT * kHHT;   // 180 halo pixels
 constexpr int kKC = 16, kRS = 20;                                                   // chunk size, LDS row stride (floats)
 
-template <int NT>
+// TS = taps staged per pipeline stage (3 or 9).  Narrow workgroups (NT <= 2: small layers, coarse
+// levels, K-splits) do little MFMA work per stage, so they stage all 9 taps of a chunk at once:
+// a third of the barriers and global round trips on what is a latency-bound launch.
+template <int NT, int TS>
 __global__ void __launch_bounds__(256)
 conv3x3_mfma_kernel(const ConvArgs a) {
   constexpr int BN = 32 * NT;
+  constexpr int SPC = 9 / TS;                         // stages per chunk
   constexpr int A_F2 = kHP * (kKC / 2);               // float2 loads to stage one halo chunk (1440)
   constexpr int A_PER = (A_F2 + 255) / 256;           // 6
-  constexpr int B_F4 = 3 * BN * (kKC / 4);            // float4 loads to stage 3 taps of weights
-  constexpr int B_PER = (B_F4 + 255) / 256;           // 6 at NT = 4
+  constexpr int B_F4 = TS * BN * (kKC / 4);           // float4 loads to stage TS taps of weights
+  constexpr int B_PER = (B_F4 + 255) / 256;           // 6 at NT = 4, TS = 3
   __shared__ __align__(16) float lds_a[kHP * kRS];
-  __shared__ __align__(16) float lds_b[3 * BN * kRS];
+  __shared__ __align__(16) float lds_b[TS * BN * kRS];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int tile = blockIdx.x;
@@ -84,7 +88,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     }
   };
   auto load_b = [&](int chunk, int s) {
-    // wp layout: [chunk][tap][CoutPad][16 (even-first)] -> rows n0..n0+BN of taps 3s..3s+2
+    // wp layout: [chunk][tap][CoutPad][16 (even-first)] -> rows n0..n0+BN of taps TS*s..TS*s+TS-1
 #pragma unroll
     for (int u = 0; u < B_PER; ++u) {
       const int idx = u * 256 + t;
@@ -93,7 +97,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
       rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < B_F4)
         rb[u] = *reinterpret_cast<const float4*>(
-            a.wp + ((((long long)chunk * 9 + 3 * s + tl) * a.CoutPad + n0 + n) * kKC + c4 * 4));
+            a.wp + ((((long long)chunk * 9 + TS * s + tl) * a.CoutPad + n0 + n) * kKC + c4 * 4));
     }
   };
   auto commit_b = [&]() {
@@ -121,26 +125,27 @@ conv3x3_mfma_kernel(const ConvArgs a) {
   commit_a();
   commit_b();
   __syncthreads();
-  const int n_stages = (chunk_hi - chunk_lo) * 3;
+  const int n_stages = (chunk_hi - chunk_lo) * SPC;
   for (int st = 0; st < n_stages; ++st) {
-    const int s = st % 3;
+    const int s = st % SPC;
     const bool has_next = st + 1 < n_stages;
-    const int nchunk = chunk_lo + (st + 1) / 3, ns = (st + 1) % 3;
+    const int nchunk = chunk_lo + (st + 1) / SPC, ns = (st + 1) % SPC;
     if (has_next) {
       load_b(nchunk, ns);
       if (ns == 0) load_a(nchunk);
     }
-    // ---- 3 taps (ky = s, kx = 0..2) x 8 k-steps x NT tiles
+    // ---- TS taps x 8 k-steps x NT tiles
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const float* ap = a_lane + (s * kHWT + kx) * kRS;
+    for (int tl = 0; tl < TS; ++tl) {
+      const int ky = TS == 9 ? tl / 3 : s, kx = TS == 9 ? tl % 3 : tl;
+      const float* ap = a_lane + (ky * kHWT + kx) * kRS;
       const float4 a0 = *reinterpret_cast<const float4*>(ap);
       const float4 a1 = *reinterpret_cast<const float4*>(ap + 4);
       const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
       float bv[NT][8];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const float* bp = b_lane + (kx * BN + nt * 32) * kRS;
+        const float* bp = b_lane + (tl * BN + nt * 32) * kRS;
         const float4 b0 = *reinterpret_cast<const float4*>(bp);
         const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
         bv[nt][0] = b0.x; bv[nt][1] = b0.y; bv[nt][2] = b0.z; bv[nt][3] = b0.w;
@@ -251,10 +256,10 @@ extern "C" int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const fl
   const dim3 grid((unsigned)tiles, (unsigned)(n32 / nt), (unsigned)(b * ksplit)), block(256);
   hipStream_t s = (hipStream_t)stream;
   switch (nt) {
-    case 4: hipLaunchKernelGGL(conv3x3_mfma_kernel<4>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(conv3x3_mfma_kernel<3>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(conv3x3_mfma_kernel<2>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(conv3x3_mfma_kernel<1>, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((conv3x3_mfma_kernel<4, 3>), grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((conv3x3_mfma_kernel<3, 3>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((conv3x3_mfma_kernel<2, 9>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((conv3x3_mfma_kernel<1, 9>), grid, block, 0, s, a); break;
   }
   if (ksplit > 1) {
     const long long pixels = (long long)b * h * w;
