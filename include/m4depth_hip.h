@@ -200,6 +200,12 @@ int m4d_conv3x3_bias_act(const float* x, const float* wp, const float* bias, int
  * problems (coarse pyramid levels: a handful of pixel tiles, K up to 9*470) split K over
  * workgroups; partial sums are reduced in split order by a second kernel (still deterministic). */
 long long m4d_conv3x3_workspace_floats(int b, int h, int w, int CoutPad);
+/* General form: stride 1 or 2 with TensorFlow 'SAME' padding computed inside (stride 2 on an even
+ * size pads bottom/right only -- no padded copy of the input is needed); out is
+ * [b, ceil(h/stride), ceil(w/stride), Cout].  Cin may be odd (the 3-channel input image). */
+int m4d_conv3x3s_bias_act_ws(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                             int Cin, int Cout, int CoutPad, int stride, float slope, float* out,
+                             float* workspace, long long workspace_floats, void* stream);
 int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const float* bias, int b, int h, int w,
                             int Cin, int Cout, int CoutPad, float slope, float* out, float* workspace,
                             long long workspace_floats, void* stream);

@@ -1,7 +1,7 @@
-// 3x3 / stride 1 / 'SAME' convolution on NHWC float32 with the Keras bias add and the
-// leaky_relu that follows it fused into the epilogue (m4depth_network.py:104-135: the seven
-// DispRefiner convolutions; :63-67: the stride-1 encoder convolutions) -- the "next" row f-2 of
-// 70 of the 73.6 GMAC of a frame.
+// 3x3 'SAME' convolution (stride 1 or 2, TensorFlow padding rule) on NHWC float32 with the Keras
+// bias add and the leaky_relu that follows it fused into the epilogue (m4depth_network.py:104-135:
+// the seven DispRefiner convolutions; :63-72: the stride-1 and stride-2 encoder convolutions) --
+// the "next" row f-2 of SURVEY section 8: all 73.6 GMAC of a frame.
 //
 // Implicit GEMM on the f32-input matrix cores: v_mfma_f32_32x32x2_f32 is exact float32 (bitwise
 // an fmaf chain in k order: one rounding per product-accumulate, no wider accumulator), runs at
@@ -28,28 +28,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct ConvArgs {
   const float* x; const float* wp; const float* bias; float* out;
   int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
+  int oh, ow, pad_y, pad_x;           // output size and TF 'SAME' pad before (1 at stride 1; 0 or 1 at stride 2)
   float slope;
   int ksplit, chunks_per_split;       // split-K (coarse pyramid levels): partial sums -> ws, reduced in order
   float* ws;
 };
 
-constexpr int kTW = 16, kTH = 8, kHWT = kTW + 2, kHHT = kTH + 2, kHP = kHWT * kHHT;   // 180 halo pixels
-constexpr int kKC = 16, kRS = 20;                                                   // chunk size, LDS row stride (floats)
+constexpr int kTW = 16, kTH = 8;                    // output tile
+constexpr int kKC = 16, kRS = 20;                   // chunk size, LDS row stride (floats)
 
 // TS = taps staged per pipeline stage (3 or 9).  Narrow workgroups (NT <= 2: small layers, coarse
 // levels, K-splits) do little MFMA work per stage, so they stage all 9 taps of a chunk at once:
 // a third of the barriers and global round trips on what is a latency-bound launch.
-template <int NT, int TS>
+template <int NT, int TS, int STRIDE>
 __global__ void __launch_bounds__(256)
 conv3x3_mfma_kernel(const ConvArgs a) {
+  constexpr int kHWT = (kTW - 1) * STRIDE + 3, kHHT = (kTH - 1) * STRIDE + 3, kHP = kHWT * kHHT;   // input halo: 18x10 / 33x17
   constexpr int BN = 32 * NT;
   constexpr int SPC = 9 / TS;                         // stages per chunk
   constexpr int A_F2 = kHP * (kKC / 2);               // float2 loads to stage one halo chunk (1440)
   constexpr int A_PER = (A_F2 + 255) / 256;           // 6
   constexpr int B_F4 = TS * BN * (kKC / 4);           // float4 loads to stage TS taps of weights
   constexpr int B_PER = (B_F4 + 255) / 256;           // 6 at NT = 4, TS = 3
-  __shared__ __align__(16) float lds_a[kHP * kRS];
-  __shared__ __align__(16) float lds_b[TS * BN * kRS];
+  extern __shared__ __align__(16) float lds_dyn[];
+  float* lds_a = lds_dyn;                             // [kHP][kRS]
+  float* lds_b = lds_dyn + kHP * kRS;                 // [TS * BN][kRS]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int tile = blockIdx.x;
@@ -70,10 +73,13 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     for (int u = 0; u < A_PER; ++u) {
       const int idx = u * 256 + t;
       const int hp = idx >> 3, k2 = (idx & 7) * 2;     // halo pixel, channel pair inside the chunk
-      const int gy = tile_y - 1 + hp / kHWT, gx = tile_x - 1 + hp % kHWT;
+      const int gy = tile_y * STRIDE - a.pad_y + hp / kHWT, gx = tile_x * STRIDE - a.pad_x + hp % kHWT;
       ra[u] = make_float2(0.f, 0.f);
-      if (idx < A_F2 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && c0 + k2 < a.Cin)
-        ra[u] = *reinterpret_cast<const float2*>(ximg + ((long long)gy * a.w + gx) * a.Cin + c0 + k2);
+      if (idx < A_F2 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && c0 + k2 < a.Cin) {
+        const float* px = ximg + ((long long)gy * a.w + gx) * a.Cin + c0 + k2;
+        if (a.Cin & 1) { ra[u].x = px[0]; if (c0 + k2 + 1 < a.Cin) ra[u].y = px[1]; }     // 3-channel input image
+        else ra[u] = *reinterpret_cast<const float2*>(px);
+      }
     }
   };
   auto commit_a = [&]() {
@@ -117,7 +123,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
 
   const int m = lane & 31, kh = lane >> 5;
   const int prow = 2 * wave + (m >> 4), pcol = m & 15;        // pixel of this lane inside the tile
-  const float* a_lane = lds_a + (prow * kHWT + pcol) * kRS + kh * 8;
+  const float* a_lane = lds_a + (prow * STRIDE * kHWT + pcol * STRIDE) * kRS + kh * 8;
   const float* b_lane = lds_b + m * kRS + kh * 8;
 
   load_a(chunk_lo);
@@ -168,7 +174,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
   // ---- epilogue: + bias, leaky_relu, NHWC store.  C/D map of the 32x32 MFMA:
   //      col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   if (a.ksplit > 1) {                                  // raw partial sums; conv_splitk_reduce_kernel finishes
-    float* wimg = a.ws + ((long long)ks * a.b + bi) * a.h * a.w * a.CoutPad;
+    float* wimg = a.ws + ((long long)ks * a.b + bi) * a.oh * a.ow * a.CoutPad;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int co = n0 + nt * 32 + m;
@@ -176,12 +182,12 @@ conv3x3_mfma_kernel(const ConvArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;
         const int oy = tile_y + 2 * wave + (mr >> 4), ox = tile_x + (mr & 15);
-        if (oy < a.h && ox < a.w) wimg[((long long)oy * a.w + ox) * a.CoutPad + co] = acc[nt][r];
+        if (oy < a.oh && ox < a.ow) wimg[((long long)oy * a.ow + ox) * a.CoutPad + co] = acc[nt][r];
       }
     }
     return;
   }
-  float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+  float* oimg = a.out + (long long)bi * a.oh * a.ow * a.Cout;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int co = n0 + nt * 32 + m;
@@ -190,10 +196,10 @@ conv3x3_mfma_kernel(const ConvArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;  // pixel index inside the wave's 32
       const int oy = tile_y + 2 * wave + (mr >> 4), ox = tile_x + (mr & 15);
-      if (co < a.Cout && oy < a.h && ox < a.w) {
+      if (co < a.Cout && oy < a.oh && ox < a.ow) {
         float v = acc[nt][r] + bias;
         v = v > 0.f ? v : v * a.slope;
-        oimg[((long long)oy * a.w + ox) * a.Cout + co] = v;
+        oimg[((long long)oy * a.ow + ox) * a.Cout + co] = v;
       }
     }
   }
@@ -214,11 +220,35 @@ conv_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict_
   }
 }
 
+template <int NT, int TS, int STRIDE>
+void launch_conv(const ConvArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int HP = ((kTW - 1) * STRIDE + 3) * ((kTH - 1) * STRIDE + 3);
+  constexpr size_t lds = (size_t)(HP * kRS + TS * 32 * NT * kRS) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<NT, TS, STRIDE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<NT, TS, STRIDE>), grid, dim3(256), lds, s, a);
+}
+
+template <int STRIDE>
+void dispatch_conv(const ConvArgs& a, int nt, dim3 grid, hipStream_t s) {
+  switch (nt) {
+    case 4: launch_conv<4, 3, STRIDE>(a, grid, s); break;
+    case 3: launch_conv<3, 3, STRIDE>(a, grid, s); break;
+    case 2: launch_conv<2, STRIDE == 1 ? 9 : 3, STRIDE>(a, grid, s); break;
+    default: launch_conv<1, 9, STRIDE>(a, grid, s); break;
+  }
+}
+
 }  // namespace
 
 extern "C" int m4d_conv3x3_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
                                     int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
-  return m4d_conv3x3_bias_act_ws(x, wp, bias, b, h, w, Cin, Cout, CoutPad, slope, out, nullptr, 0, stream);
+  return m4d_conv3x3s_bias_act_ws(x, wp, bias, b, h, w, Cin, Cout, CoutPad, 1, slope, out, nullptr, 0, stream);
 }
 
 extern "C" long long m4d_conv3x3_workspace_floats(int b, int h, int w, int CoutPad) {
@@ -226,15 +256,26 @@ extern "C" long long m4d_conv3x3_workspace_floats(int b, int h, int w, int CoutP
 }
 
 extern "C" int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const float* bias, int b, int h, int w,
-                                    int Cin, int Cout, int CoutPad, float slope, float* out, float* workspace,
+                                       int Cin, int Cout, int CoutPad, float slope, float* out, float* workspace,
                                        long long workspace_floats, void* stream) {
+  return m4d_conv3x3s_bias_act_ws(x, wp, bias, b, h, w, Cin, Cout, CoutPad, 1, slope, out, workspace,
+                                  workspace_floats, stream);
+}
+
+extern "C" int m4d_conv3x3s_bias_act_ws(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                                        int Cin, int Cout, int CoutPad, int stride, float slope, float* out,
+                                        float* workspace, long long workspace_floats, void* stream) {
   M4D_CHECK_ARG(x && wp && bias && out && b > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0);
-  M4D_CHECK_ARG(Cin % 2 == 0 && CoutPad % 32 == 0 && CoutPad >= Cout);
-  M4D_CHECK_ARG(((((uintptr_t)x) & 7u) == 0) && ((((uintptr_t)wp) & 15u) == 0));
+  M4D_CHECK_ARG((stride == 1 || stride == 2) && CoutPad % 32 == 0 && CoutPad >= Cout);
+  M4D_CHECK_ARG(((((uintptr_t)x) & (Cin % 2 == 0 ? 7u : 3u)) == 0) && ((((uintptr_t)wp) & 15u) == 0));
   ConvArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
   a.CoutPad = CoutPad; a.n_chunks = (Cin + kKC - 1) / kKC;
-  a.tiles_x = (w + kTW - 1) / kTW; a.tiles_y = (h + kTH - 1) / kTH; a.slope = slope;
+  // TensorFlow 'SAME': out = ceil(in / stride), total pad = max((out-1)*stride + 3 - in, 0), before = total / 2
+  a.oh = (h + stride - 1) / stride; a.ow = (w + stride - 1) / stride;
+  const int tph = (a.oh - 1) * stride + 3 - h, tpw = (a.ow - 1) * stride + 3 - w;
+  a.pad_y = (tph > 0 ? tph : 0) / 2; a.pad_x = (tpw > 0 ? tpw : 0) / 2;
+  a.tiles_x = (a.ow + kTW - 1) / kTW; a.tiles_y = (a.oh + kTH - 1) / kTH; a.slope = slope;
   const long long tiles = (long long)a.tiles_x * a.tiles_y;
   const int n32 = CoutPad / 32;
   // N-tiles per workgroup: as wide as possible (A reuse) while the launch still fills the chip
@@ -248,21 +289,17 @@ extern "C" int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const fl
     ksplit = (int)((256 + blocks - 1) / blocks);
     if (ksplit > a.n_chunks / 2) ksplit = a.n_chunks / 2;
     if (ksplit > 16) ksplit = 16;
-    while (ksplit > 1 && (long long)ksplit * b * h * w * CoutPad > workspace_floats) --ksplit;
+    while (ksplit > 1 && (long long)ksplit * b * a.oh * a.ow * CoutPad > workspace_floats) --ksplit;
   }
   a.chunks_per_split = (a.n_chunks + ksplit - 1) / ksplit;
   ksplit = (a.n_chunks + a.chunks_per_split - 1) / a.chunks_per_split;     // no empty split
   a.ksplit = ksplit; a.ws = workspace;
-  const dim3 grid((unsigned)tiles, (unsigned)(n32 / nt), (unsigned)(b * ksplit)), block(256);
+  const dim3 grid((unsigned)tiles, (unsigned)(n32 / nt), (unsigned)(b * ksplit));
   hipStream_t s = (hipStream_t)stream;
-  switch (nt) {
-    case 4: hipLaunchKernelGGL((conv3x3_mfma_kernel<4, 3>), grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((conv3x3_mfma_kernel<3, 3>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((conv3x3_mfma_kernel<2, 9>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((conv3x3_mfma_kernel<1, 9>), grid, block, 0, s, a); break;
-  }
+  if (stride == 1) dispatch_conv<1>(a, nt, grid, s);
+  else dispatch_conv<2>(a, nt, grid, s);
   if (ksplit > 1) {
-    const long long pixels = (long long)b * h * w;
+    const long long pixels = (long long)b * a.oh * a.ow;
     long long g = (pixels * Cout + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, workspace, bias, pixels, Cout,

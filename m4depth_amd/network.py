@@ -32,11 +32,24 @@ M4depthAblationParameters = namedtuple('M4depthAblationParameters',
 
 _CV_ACCUM = {"fp32_round": 0, "fp16_seq": 1}
 
-# Stride-1 3x3 convolutions with at least this many output pixels (b*h*w) run on the hand-written
-# fp32-MFMA kernel with fused bias/leaky-relu epilogue (csrc/m4d_conv.hip), which beats MIOpen +
-# epilogue on every layer of every level (tools/bench_conv.py); 0 disables it (MIOpen everywhere).
+# 3x3 convolutions with at least this many input pixels (b*h*w) run on the hand-written
+# fp32-MFMA kernel with fused bias/leaky-relu epilogue (csrc/m4d_conv.hip; stride 1 and 2, TF
+# 'SAME' padding inside), which beats MIOpen + epilogue on every layer of every level
+# (tools/bench_conv.py) and is deterministic; 0 disables it (MIOpen everywhere).
 import os as _os
 mfma_conv_min_pixels = int(_os.environ.get("M4D_MFMA_CONV_MIN_PIXELS", "1"))
+
+# The 3-channel image convolution (K = 27 padded to 144, N = 16 padded to 32) wastes 10x the MFMA
+# work and is faster on MIOpen (tools/bench_conv_enc.py): only layers with at least this many
+# input channels take the hand-written kernel.
+mfma_conv_min_cin = int(_os.environ.get("M4D_MFMA_CONV_MIN_CIN", "8"))
+
+# Encoder on the hand-written kernel too (stride 1 and 2)?  A/B on one MI355X, whole bench at batch 1:
+# 7.11 ms / step with it, 7.13 ms with MIOpen + padded-buffer epilogues -- equal, so the default is the
+# hand-written kernel (deterministic, no padded buffers).  With mfma_conv_min_cin = 1 on top (+0.1 ms:
+# the 3-channel layer) no MIOpen kernel is left in the model and two runs are bit-identical
+# (tests/test_gpu_model.py::test_fully_deterministic_mode_is_bitwise).
+mfma_conv_encoder = _os.environ.get("M4D_MFMA_CONV_ENCODER", "1") == "1"
 
 # bench.py installs an object with ``run(name, level, thunk)`` here to bracket the
 # hand-written kernels with HIP events on the launch stream; None = no overhead.
@@ -113,11 +126,11 @@ class _Conv3x3SameTF(torch.nn.Module):
         PyTorch kernels; on CPU tensors (host-logic tests) plain torch ops are used."""
         if self.weight is None:
             self._build(x_nhwc.shape[-1], x_nhwc.device)
-        if (x_nhwc.is_cuda and self.stride == 1 and mfma_conv_min_pixels > 0 and x_nhwc.shape[-1] % 2 == 0
+        if (x_nhwc.is_cuda and self.stride in (1, 2) and mfma_conv_min_pixels > 0 and x_nhwc.shape[-1] >= mfma_conv_min_cin
                 and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= mfma_conv_min_pixels):
             wp, cpad = self._packed_weights()
             return nops.conv3x3_bias_act(x_nhwc, wp, self.bias, self.out_channels, cpad,
-                                         1.0 if slope is None else slope)
+                                         1.0 if slope is None else slope, stride=self.stride)
         x = x_nhwc.permute(0, 3, 1, 2)                   # channels-last NCHW view, no copy
         h, w = x.shape[2:]
         s = self.stride
@@ -198,8 +211,9 @@ class FeaturePyramid(torch.nn.Module):
         return buf
 
     def _forward_gpu(self, images):
-        """Same arithmetic as ``forward``'s generic path; the bias / DINL / leaky_relu epilogue of
-        the stride-1 convolution writes straight into the padded input of the stride-2 one."""
+        """MIOpen variant (only used when the hand-written MFMA convolutions are disabled): same
+        arithmetic as ``forward``; the bias / DINL / leaky_relu epilogue of the stride-1 convolution
+        writes straight into the padded input of the stride-2 one."""
         feature_maps = as_f32(images, "images")
         outputs = []
         for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):
@@ -219,8 +233,8 @@ class FeaturePyramid(torch.nn.Module):
         return outputs
 
     def forward(self, images):
-        if isinstance(images, torch.Tensor) and images.is_cuda:
-            return self._forward_gpu(images)
+        if isinstance(images, torch.Tensor) and images.is_cuda and (mfma_conv_min_pixels <= 0 or not mfma_conv_encoder):
+            return self._forward_gpu(images)           # MIOpen path
         feature_maps = as_f32(images, "images")
         outputs = []
         for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):

@@ -170,17 +170,18 @@ def pack_conv_weights(kernel_hwio):
     return np.ascontiguousarray(w.transpose(1, 0, 3, 2)), cpad    # [chunk][tap][n][16p]
 
 
-def conv3x3_bias_act(x, wp, bias, cout, cout_pad, slope=0.1):
-    """3x3 stride-1 'SAME' convolution + bias + leaky_relu(slope) on the matrix cores."""
+def conv3x3_bias_act(x, wp, bias, cout, cout_pad, slope=0.1, stride=1):
+    """3x3 TF-'SAME' convolution (stride 1 or 2) + bias + leaky_relu(slope) on the matrix cores."""
     x = as_f32(x, "x")
     b, h, w, cin = x.shape
-    out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    oh, ow = -(-h // stride), -(-w // stride)
+    out = torch.empty((b, oh, ow, cout), dtype=torch.float32, device=x.device)
     ws = None
     ws_floats = 0
-    if b * h * w <= 16384:                               # coarse levels: allow split-K through a workspace
-        ws_floats = int(lib.m4d_conv3x3_workspace_floats(b, h, w, int(cout_pad)))
+    if b * oh * ow <= 16384:                             # coarse levels: allow split-K through a workspace
+        ws_floats = int(lib.m4d_conv3x3_workspace_floats(b, oh, ow, int(cout_pad)))
         ws = _workspace("conv_splitk", 4 * ws_floats, x.device)
-    check(lib.m4d_conv3x3_bias_act_ws(dptr(x, "x"), dptr(wp, "wp"), dptr(bias, "bias"), b, h, w, cin, int(cout),
-                                      int(cout_pad), float(slope), dptr(out), dptr(ws), ws_floats, stream_ptr()),
-          "m4d_conv3x3_bias_act_ws")
+    check(lib.m4d_conv3x3s_bias_act_ws(dptr(x, "x"), dptr(wp, "wp"), dptr(bias, "bias"), b, h, w, cin, int(cout),
+                                       int(cout_pad), int(stride), float(slope), dptr(out), dptr(ws), ws_floats,
+                                       stream_ptr()), "m4d_conv3x3s_bias_act_ws")
     return out

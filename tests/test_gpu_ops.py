@@ -326,11 +326,13 @@ def test_fused_dinl_and_metrics(M, dev):
     assert np.max(rel_err(vals, cls, 1e-6)) < 2e-5
 
 
-@pytest.mark.parametrize("b,h,w,cin,cout,slope", [(1, 16, 32, 16, 32, 0.1), (2, 19, 37, 122, 128, 0.1),
-                                                   (1, 24, 40, 128, 96, 0.1), (1, 9, 17, 64, 5, 1.0),
-                                                   (1, 33, 20, 238, 64, 0.1), (1, 8, 16, 470, 128, 0.1),
-                                                   (1, 40, 48, 32, 16, 0.1)])
-def test_mfma_conv3x3_bias_act(M, dev, b, h, w, cin, cout, slope):
+@pytest.mark.parametrize("b,h,w,cin,cout,slope,stride",
+                         [(1, 16, 32, 16, 32, 0.1, 1), (2, 19, 37, 122, 128, 0.1, 1), (1, 24, 40, 128, 96, 0.1, 1),
+                          (1, 9, 17, 64, 5, 1.0, 1), (1, 33, 20, 238, 64, 0.1, 1), (1, 8, 16, 470, 128, 0.1, 1),
+                          (1, 40, 48, 32, 16, 0.1, 1), (2, 24, 40, 3, 16, 1.0, 1),
+                          (1, 32, 48, 16, 16, 0.1, 2), (2, 19, 37, 64, 64, 0.1, 2), (1, 18, 21, 96, 96, 0.1, 2),
+                          (1, 12, 40, 128, 192, 0.1, 2), (1, 7, 10, 128, 128, 0.1, 2)])
+def test_mfma_conv3x3_bias_act(M, dev, b, h, w, cin, cout, slope, stride):
     """Hand-written fp32-MFMA 3x3 conv + bias + leaky_relu vs the oracle's conv2d_same (tolerance:
     1e-5 of the output scale -- different, but fixed, summation order) incl. ragged tiles, K and N
     padding, and run-to-run determinism."""
@@ -341,10 +343,10 @@ def test_mfma_conv3x3_bias_act(M, dev, b, h, w, cin, cout, slope):
     bias = (0.1 * rng.standard_normal([cout])).astype(F)
     wp, cpad = nops.pack_conv_weights(k)
     xd, wd, bd = to_dev(x, dev), to_dev(wp, dev), to_dev(bias, dev)
-    got = nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, slope)
-    ref = O.conv2d_same(x, k, bias, 1)
+    got = nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, slope, stride=stride)
+    ref = O.conv2d_same(x, k, bias, stride)
     ref = np.where(ref > 0, ref, ref * F(slope)).astype(F)
     err = np.max(np.abs(npy(got) - ref))
     assert err < 1e-5 * max(1.0, np.abs(ref).max()), err
-    again = nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, slope)
+    again = nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, slope, stride=stride)
     assert torch.equal(got, again)
