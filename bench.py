@@ -14,9 +14,11 @@ range 4 / SNCV range 3, batch 1 per GPU.  Inputs are resident in HBM before the
 timed region.  ``value`` = all frames processed by all ranks / max-over-ranks time.
 
 The JSON line also carries
-  roofline     -- the dominant hand-written kernel (level-1 DSCV or SNCV, whichever
-                  costs more time), algorithmic bytes / HIP-event time on the launch
-                  stream, against the 8 TB/s HBM3E peak;
+  roofline     -- the dominant hand-written kernel of the step: the level-1 refiner
+                  128->128 convolution (fp32 MFMA implicit GEMM), algorithmic flops / HIP-event
+                  time on the launch stream, against the 157.3 TFLOP/s fp32-MFMA peak;
+                  roofline_dscv / roofline_sncv: the level-1 cost-volume kernels, algorithmic
+                  bytes / time against the 8 TB/s HBM3E peak;
   cpu_baseline -- the CPU oracle (a numpy restatement of the reference: TensorFlow is
                   not installable here, so kind = "port") timed on a bounded sample.
 Multi-GPU: sequences are independent -> batch sharded across ranks, weights
@@ -36,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+FP32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= fp32 vector peak), MI355X_MICROARCH.md
 
 
 def parse():
@@ -62,12 +65,12 @@ class EventTimer:
 
     def __init__(self, torch, level):
         self.torch = torch
-        self.level = level
+        self.targets = {("dscv", level), ("sncv", level), ("conv", f"lvl{level}.conv1")}
         self.enabled = False
         self.events = {}
 
     def run(self, name, level, thunk):
-        if not self.enabled or level != self.level:
+        if not self.enabled or (name, level) not in self.targets:
             return thunk()
         e0 = self.torch.cuda.Event(enable_timing=True)
         e1 = self.torch.cuda.Event(enable_timing=True)
@@ -223,13 +226,28 @@ def main():
             traffic = tj.get(f"batch{args.batch}", {})
         except Exception:
             pass
-        dom = max(summ, key=lambda k: summ[k][1])
+        # Dominant hand-written kernel of the step: the level-1 128->128 refiner convolution (fp32 MFMA
+        # implicit GEMM; algorithmic flops = 2*9*Cin*Cout per output pixel) -> "roofline"; the two
+        # level-1 cost-volume kernels (HBM-bound by bytes) -> "roofline_dscv" / "roofline_sncv".
+        h1, w1 = args.height >> 1, args.width >> 1
         for name, (n, sec) in summ.items():
+            if name == "conv":
+                flops = 2.0 * 9 * 128 * 128 * h1 * w1 * args.batch
+                tf = flops / sec / 1e12
+                out["roofline"] = {"kernel": "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)",
+                                   "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                   "traffic": traffic.get("conv_l1_128_128"), "algorithmic_flops_per_launch": flops,
+                                   "algorithmic_bytes_per_launch": 4 * (2 * 128 * h1 * w1 * args.batch + 9 * 128 * 128),
+                                   "avg_launch_us": round(sec * 1e6, 2), "launches": n}
+                continue
             gbs = bytes_l1[name] / sec / 1e9
-            rec = {"kernel": f"{name}_level1", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
-                   "algorithmic_bytes_per_launch": bytes_l1[name], "avg_launch_us": round(sec * 1e6, 2), "launches": n}
-            out["roofline" if name == dom else f"roofline_{name}"] = rec
+            out[f"roofline_{name}"] = {"kernel": f"{name}_level1", "bound": "hbm", "achieved": round(gbs, 1),
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                       "traffic": traffic.get(name), "algorithmic_bytes_per_launch": bytes_l1[name],
+                                       "avg_launch_us": round(sec * 1e6, 2), "launches": n}
+        if "roofline" not in out and "roofline_dscv" in out:            # hand-written convolutions disabled
+            out["roofline"] = out["roofline_dscv"]
     if not args.no_cpu_baseline and world == 1:
         cb, (W, samples, cam, ref) = cpu_baseline(args)
         out["cpu_baseline"] = cb

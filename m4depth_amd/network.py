@@ -81,6 +81,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.weight = None
         self.bias = None
         self._packed = None
+        self.tag = None                  # e.g. "lvl1.conv1": lets bench.py bracket one layer with HIP events
         if in_channels is not None:
             self._build(in_channels, None)
 
@@ -129,8 +130,8 @@ class _Conv3x3SameTF(torch.nn.Module):
         if (x_nhwc.is_cuda and self.stride in (1, 2) and mfma_conv_min_pixels > 0 and x_nhwc.shape[-1] >= mfma_conv_min_cin
                 and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= mfma_conv_min_pixels):
             wp, cpad = self._packed_weights()
-            return nops.conv3x3_bias_act(x_nhwc, wp, self.bias, self.out_channels, cpad,
-                                         1.0 if slope is None else slope, stride=self.stride)
+            return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
+                x_nhwc, wp, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope, stride=self.stride))
         x = x_nhwc.permute(0, 3, 1, 2)                   # channels-last NCHW view, no copy
         h, w = x.shape[2:]
         s = self.stride
@@ -292,6 +293,8 @@ class DepthEstimatorLevel(torch.nn.Module):
         self.f_in = f_input_channels(self.nbre_cuts, self.dscv_range, self.sncv_range,
                                      self.ablation.level_memory, self.ablation.SNCV, self.ablation.time_recurr)
         self.disp_refiner = DispRefiner(regularizer_weight=regularizer_weight, in_channels=self.f_in)
+        for i, conv in enumerate(list(self.disp_refiner.prep_conv_layers) + list(self.disp_refiner.est_d_conv_layers)):
+            conv.tag = f"lvl{depth}.conv{i}"
         self.prev_f_maps = None
         self.depth_prev_t = None
         self._spare_f = None
