@@ -243,3 +243,30 @@ def test_fully_deterministic_mode_is_bitwise(dev):
         assert torch.equal(first, last)
     finally:
         net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels = old
+
+
+def test_model_large_search_windows(dev):
+    """BASELINE config 5 geometry at reduced size: DSCV range 6 (13 hypotheses) and SNCV range 6
+    (13x13 = 169 displacements per cut) -- the runtime-window kernels -- against the oracle."""
+    L, H, Wd, T, b, rd, rs = 3, 64, 96, 2, 1, 6, 6
+    W = S.init_weights(L, seed=9, dscv_range=rd, sncv_range=rs)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=55)
+    model = _build(dev, L, rd, rs, W)
+    model([to_dev(samples, dev), to_dev(cam, dev)])
+    omodel = O.M4Depth(W, L, dscv_range=rd, sncv_range=rs)
+    _, seq = omodel(samples, cam)
+    for l in range(L):
+        k = 2 ** ((l + 1) // 2)
+        fo, fg = omodel.levels[l].last_f_input, npy(model.d_estimator.levels[l].last_f_input)
+        assert fo.shape[-1] == 13 * k + 169 * k + 6 == fg.shape[-1]
+        cam_l = {"f": cam["f"] / F(2.0 ** (l + 1)), "c": cam["c"] / F(2.0 ** (l + 1))}
+        est = model.last_estimates[-1][l]
+        check_depth_and_parallax(npy(est["depth"]), npy(est["parallax"]), seq[-1][l]["depth"], seq[-1][l]["parallax"],
+                                 samples[-1]["rot"], samples[-1]["trans"], cam_l, f"r=6 level {l}", frac_ok=0.98)
+    # coarsest level: its cost-volume channels only depend on the encoder features, which differ
+    # from the oracle's in the last bits (convolution order) -> at most one float16 ulp of a DSCV
+    # entry (3e-5 at 1/16) or a float32 ulp-level SNCV difference
+    lc = L - 1
+    fo, fg = omodel.levels[lc].last_f_input, npy(model.d_estimator.levels[lc].last_f_input)
+    err = np.abs(fg - fo).max()
+    assert err < 1e-4, err
