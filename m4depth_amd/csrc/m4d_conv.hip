@@ -40,7 +40,10 @@ constexpr int kKC = 16, kRS = 20;                   // chunk size, LDS row strid
 // TS = taps staged per pipeline stage (3 or 9).  Narrow workgroups (NT <= 2: small layers, coarse
 // levels, K-splits) do little MFMA work per stage, so they stage all 9 taps of a chunk at once:
 // a third of the barriers and global round trips on what is a latency-bound launch.
-template <int NT, int TS, int STRIDE>
+// DB = double-buffered weight stages (wide stride-1 variants): the next stage's weights are written
+// to the other LDS buffer BEFORE the MFMA burst of the current stage and its global loads are issued
+// two stages ahead, so a stage costs one barrier instead of two and the LDS writes hide under MFMAs.
+template <int NT, int TS, int STRIDE, bool DB>
 __global__ void __launch_bounds__(256)
 conv3x3_mfma_kernel(const ConvArgs a) {
   constexpr int kHWT = (kTW - 1) * STRIDE + 3, kHHT = (kTH - 1) * STRIDE + 3, kHP = kHWT * kHHT;   // input halo: 18x10 / 33x17
@@ -106,12 +109,12 @@ conv3x3_mfma_kernel(const ConvArgs a) {
             a.wp + ((((long long)chunk * 9 + TS * s + tl) * a.CoutPad + n0 + n) * kKC + c4 * 4));
     }
   };
-  auto commit_b = [&]() {
+  auto commit_b = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < B_PER; ++u) {
       const int idx = u * 256 + t;
       const int row = idx >> 2, c4 = idx & 3;
-      if (idx < B_F4) *reinterpret_cast<float4*>(lds_b + row * kRS + c4 * 4) = rb[u];
+      if (idx < B_F4) *reinterpret_cast<float4*>(lds_b + buf * (TS * BN * kRS) + row * kRS + c4 * 4) = rb[u];
     }
   };
 
@@ -126,21 +129,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
   const float* a_lane = lds_a + (prow * STRIDE * kHWT + pcol * STRIDE) * kRS + kh * 8;
   const float* b_lane = lds_b + m * kRS + kh * 8;
 
-  load_a(chunk_lo);
-  load_b(chunk_lo, 0);
-  commit_a();
-  commit_b();
-  __syncthreads();
-  const int n_stages = (chunk_hi - chunk_lo) * SPC;
-  for (int st = 0; st < n_stages; ++st) {
-    const int s = st % SPC;
-    const bool has_next = st + 1 < n_stages;
-    const int nchunk = chunk_lo + (st + 1) / SPC, ns = (st + 1) % SPC;
-    if (has_next) {
-      load_b(nchunk, ns);
-      if (ns == 0) load_a(nchunk);
-    }
-    // ---- TS taps x 8 k-steps x NT tiles
+  auto mfma_stage = [&](int s, int buf) {           // TS taps x 8 k-steps x NT tiles
 #pragma unroll
     for (int tl = 0; tl < TS; ++tl) {
       const int ky = TS == 9 ? tl / 3 : s, kx = TS == 9 ? tl % 3 : tl;
@@ -151,7 +140,7 @@ conv3x3_mfma_kernel(const ConvArgs a) {
       float bv[NT][8];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const float* bp = b_lane + (tl * BN + nt * 32) * kRS;
+        const float* bp = b_lane + buf * (TS * BN * kRS) + (tl * BN + nt * 32) * kRS;
         const float4 b0 = *reinterpret_cast<const float4*>(bp);
         const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
         bv[nt][0] = b0.x; bv[nt][1] = b0.y; bv[nt][2] = b0.z; bv[nt][3] = b0.w;
@@ -163,12 +152,47 @@ conv3x3_mfma_kernel(const ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt)
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[nt][ks], acc[nt], 0, 0, 0);
     }
-    __syncthreads();                                   // all waves done with lds_b (and lds_a when ns == 0)
-    if (has_next) {
-      commit_b();
-      if (ns == 0) commit_a();
+  };
+
+  const int n_stages = (chunk_hi - chunk_lo) * SPC;
+  load_a(chunk_lo);
+  load_b(chunk_lo, 0);
+  commit_a();
+  commit_b(0);
+  __syncthreads();
+  if (DB) {
+    if (n_stages > 1) load_b(chunk_lo + 1 / SPC, 1 % SPC);          // stage 1 (registers), committed in stage 0
+    for (int st = 0; st < n_stages; ++st) {
+      const int s = st % SPC, cur = st & 1;
+      const bool has_next = st + 1 < n_stages;
+      const int nchunk = chunk_lo + (st + 1) / SPC, ns = (st + 1) % SPC;
+      if (has_next) commit_b(cur ^ 1);               // buffer last read in stage st-1: free since that barrier
+      if (st + 2 < n_stages) load_b(chunk_lo + (st + 2) / SPC, (st + 2) % SPC);
+      if (has_next && ns == 0) load_a(nchunk);       // next stage opens a new chunk: its halo, committed below
+      mfma_stage(s, cur);
+      if (has_next && ns == 0) {
+        __syncthreads();                             // every wave is done with this chunk's halo
+        commit_a();
+      }
+      __syncthreads();
     }
-    __syncthreads();
+  } else {
+    for (int st = 0; st < n_stages; ++st) {
+      const int s = st % SPC;
+      const bool has_next = st + 1 < n_stages;
+      const int nchunk = chunk_lo + (st + 1) / SPC, ns = (st + 1) % SPC;
+      if (has_next) {
+        load_b(nchunk, ns);
+        if (ns == 0) load_a(nchunk);
+      }
+      mfma_stage(s, 0);
+      __syncthreads();                               // all waves done with lds_b (and lds_a when ns == 0)
+      if (has_next) {
+        commit_b(0);
+        if (ns == 0) commit_a();
+      }
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: + bias, leaky_relu, NHWC store.  C/D map of the 32x32 MFMA:
@@ -222,16 +246,17 @@ conv_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict_
 
 template <int NT, int TS, int STRIDE>
 void launch_conv(const ConvArgs& a, dim3 grid, hipStream_t s) {
+  constexpr bool DB = false;   // double-buffered weight stages: implemented, bit-identical, measured 2-4 % SLOWER (b=1 and b=32) -> off
   constexpr int HP = ((kTW - 1) * STRIDE + 3) * ((kTH - 1) * STRIDE + 3);
-  constexpr size_t lds = (size_t)(HP * kRS + TS * 32 * NT * kRS) * sizeof(float);
+  constexpr size_t lds = (size_t)(HP * kRS + (DB ? 2 : 1) * TS * 32 * NT * kRS) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<NT, TS, STRIDE>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<NT, TS, STRIDE, DB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<NT, TS, STRIDE>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<NT, TS, STRIDE, DB>), grid, dim3(256), lds, s, a);
 }
 
 template <int STRIDE>
