@@ -138,6 +138,32 @@ void m4d_dscv_set_stamps(unsigned long long* device_buffer);
 int m4d_sncv_fwd(const float* c1, const float* c2, int b, int h, int w, int C, int search_range,
                  int dilation_rate, int nbre_cuts, float* out, int out_stride, void* stream);
 
+/* ---- gradients of the cost volumes (train_step, m4depth_network.py:371-399) ------ */
+
+/* Backward of m4d_dscv_fwd: what tf.GradientTape derives from depth_operations.py:224-281.
+ * g_cv: gradient of cv, read at g_cv[p*g_cv_stride + kk*(2r+1)+t]; g_prev_disp (may be NULL)
+ * [b,h,w,2r+1]: gradient of the warped-parallax output.  The float16 product / mean (:276-278)
+ * are differentiated in float16 as TF does; floor has no gradient and the two clip_by_value
+ * pass inside their bounds (dense_image_warp.py:147-154, depth_operations.py:236).
+ * Outputs: g_c1 [b,h,w,C], g_disp [b,h,w,1] (plain stores); g_c2 [b,h,w,C] and the optional
+ * g_disp_prev_t [b,h,w,1] are scatter-adds (zero-filled by the call, float32 atomics: the
+ * summation order varies run to run, as in BackProjectBackward, backproject_op_gpu.cu.cc:108-197).
+ * C % 4 == 0, (C / nbre_cuts) % 4 == 0, C <= 256, 16-byte aligned feature pointers. */
+int m4d_dscv_bwd(const float* c1, const float* c2, const float* disp_prev_t, const float* disp,
+                 const float* rot, int rot_c, const float* trans, const float* cam_f,
+                 const float* cam_c, int b, int h, int w, int C, int search_range, int nbre_cuts,
+                 const float* g_cv, int g_cv_stride, const float* g_prev_disp,
+                 float* g_c1, float* g_c2, float* g_disp, float* g_disp_prev_t, void* stream);
+
+/* Backward of m4d_sncv_fwd (depth_operations.py:284-313).  out = the forward result (decides
+ * the leaky_relu branch), g = its gradient, both read with their own pixel strides.
+ * g_c1 / g_c2 [b,h,w,C] (either may be NULL); when c1 and c2 are the same map (the model's
+ * auto-correlation, m4depth_network.py:232) the caller adds the two.  Deterministic. */
+int m4d_sncv_bwd(const float* c1, const float* c2, const float* out, int out_stride,
+                 const float* g, int g_stride, int b, int h, int w, int C, int search_range,
+                 int dilation_rate, int nbre_cuts, float slope, float* g_c1, float* g_c2,
+                 void* stream);
+
 /* ---- m4depth_network.py: DepthEstimatorLevel glue -------------------------------- */
 
 /* Per-cut L2 normalisation (:179-189, tf.linalg.normalize, no epsilon). */

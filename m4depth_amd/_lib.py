@@ -33,6 +33,11 @@ _SIGNATURES = {
                      _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                      _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_sncv_fwd": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp],
+    "m4d_dscv_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
+                     _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                     _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "m4d_sncv_bwd": [_c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                     _c_int, _c_f, _c_fp, _c_fp, _c_fp],
     "m4d_normalize_cuts": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_resize_bilinear_v1": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_resize_nearest": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],

@@ -141,13 +141,56 @@ def tile_in_batch(map, nbre_copies):
 _CV_ACCUM = {"fp32_round": 0, "fp16_seq": 1}
 
 
+def _dscv_forward(c1, c2, disp_prev_t, disp, rot, trans, f, c, r, nbre_cuts, cv_accum, return_index):
+    b, h, w, C = c1.shape
+    ncp = 2 * r + 1
+    cv = torch.empty((b, h, w, nbre_cuts * ncp), dtype=torch.float32, device=c1.device)
+    prev_disp = torch.empty((b, h, w, ncp), dtype=torch.float32, device=c1.device)
+    idx = torch.empty((b, h, w, ncp, 2), dtype=torch.int32, device=c1.device) if return_index else None
+    check(lib.m4d_dscv_fwd(dptr(c1, "c1"), dptr(c2, "c2"), dptr(disp_prev_t), dptr(disp), dptr(rot, "rot"),
+                           rot.shape[1], dptr(trans), dptr(f), dptr(c), b, h, w, C, r, nbre_cuts,
+                           _CV_ACCUM[cv_accum], dptr(cv), nbre_cuts * ncp, dptr(prev_disp), None, 0, 1.0,
+                           dptr(idx, "index", torch.int32), stream_ptr()), "m4d_dscv_fwd")
+    return cv, prev_disp, idx
+
+
+class _DSCV(torch.autograd.Function):
+    """get_parallax_sweeping_cv with the gradient tf.GradientTape derives from
+    utils/depth_operations.py:224-281 (m4d_dscv_bwd): w.r.t. c1, c2, disp_prev_t and disp."""
+
+    @staticmethod
+    def forward(ctx, c1, c2, disp_prev_t, disp, rot, trans, f, c, r, nbre_cuts, cv_accum):
+        cv, prev_disp, _ = _dscv_forward(c1, c2, disp_prev_t, disp, rot, trans, f, c, r, nbre_cuts, cv_accum, False)
+        ctx.save_for_backward(c1, c2, disp_prev_t, disp, rot, trans, f, c)
+        ctx.cfg = (r, nbre_cuts)
+        return cv, prev_disp
+
+    @staticmethod
+    def backward(ctx, g_cv, g_prev_disp):
+        c1, c2, disp_prev_t, disp, rot, trans, f, c = ctx.saved_tensors
+        r, nbre_cuts = ctx.cfg
+        b, h, w, C = c1.shape
+        g_cv = as_f32(g_cv, "g_cv")
+        g_prev_disp = as_f32(g_prev_disp, "g_prev_disp") if g_prev_disp is not None else None
+        g_c1 = torch.empty_like(c1)
+        g_c2 = torch.empty_like(c2)
+        g_disp = torch.empty_like(disp)
+        g_dpt = torch.empty_like(disp_prev_t) if ctx.needs_input_grad[2] else None
+        check(lib.m4d_dscv_bwd(dptr(c1), dptr(c2), dptr(disp_prev_t), dptr(disp), dptr(rot, "rot"), rot.shape[1],
+                               dptr(trans), dptr(f), dptr(c), b, h, w, C, r, nbre_cuts, dptr(g_cv, "g_cv"),
+                               g_cv.shape[-1], dptr(g_prev_disp, "g_prev_disp"), dptr(g_c1), dptr(g_c2),
+                               dptr(g_disp), dptr(g_dpt), stream_ptr()), "m4d_dscv_bwd")
+        return g_c1, g_c2, g_dpt, g_disp, None, None, None, None, None, None, None
+
+
 def get_parallax_sweeping_cv(c1, c2, disp_prev_t, disp, rot, trans, camera, search_range, nbre_cuts=1,
                              cv_accum="fp32_round", return_index=False, out=None):
     """Computes the DSCV as presented in the paper (utils/depth_operations.py:224-281).
 
     Returns (cv [b,h,w,k*(2r+1)], prev_disp [b,h,w,2r+1]); with ``return_index``
     also the int32 (y0,x0) grid [b,h,w,2r+1,2].  ``cv_accum`` selects how the
-    float16 mean of :277 is accumulated (see the oracle's [UNPINNED] note)."""
+    float16 mean of :277 is accumulated (see the oracle's [UNPINNED] note).
+    Differentiable w.r.t. c1, c2, disp_prev_t and disp when autograd is recording."""
     c1 = as_f32(c1, "c1")
     c2 = as_f32(c2, "c2")
     b, h, w, C = c1.shape
@@ -159,21 +202,52 @@ def get_parallax_sweeping_cv(c1, c2, disp_prev_t, disp, rot, trans, camera, sear
     disp = as_f32(disp, "disp").reshape(b, h, w, 1)
     rot, trans, f, c = _motion_args(rot, trans, camera, b)
     r = int(search_range)
-    ncp = 2 * r + 1
-    cv = torch.empty((b, h, w, nbre_cuts * ncp), dtype=torch.float32, device=c1.device)
-    prev_disp = torch.empty((b, h, w, ncp), dtype=torch.float32, device=c1.device)
-    idx = torch.empty((b, h, w, ncp, 2), dtype=torch.int32, device=c1.device) if return_index else None
-    check(lib.m4d_dscv_fwd(dptr(c1, "c1"), dptr(c2, "c2"), dptr(disp_prev_t), dptr(disp), dptr(rot, "rot"),
-                           rot.shape[1], dptr(trans), dptr(f), dptr(c), b, h, w, C, r, nbre_cuts,
-                           _CV_ACCUM[cv_accum], dptr(cv), nbre_cuts * ncp, dptr(prev_disp), None, 0, 1.0,
-                           dptr(idx, "index", torch.int32), stream_ptr()), "m4d_dscv_fwd")
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (c1, c2, disp_prev_t, disp)):
+        if return_index:
+            raise ValueError("return_index is a debugging output; it is not available while recording gradients")
+        return _DSCV.apply(c1, c2, disp_prev_t, disp, rot, trans, f, c, r, int(nbre_cuts), cv_accum)
+    cv, prev_disp, idx = _dscv_forward(c1, c2, disp_prev_t, disp, rot, trans, f, c, r, int(nbre_cuts), cv_accum,
+                                       return_index)
     return (cv, prev_disp, idx) if return_index else (cv, prev_disp)
+
+
+def _sncv_forward(c1, c2, search_range, dilation_rate, nbre_cuts):
+    b, h, w, C = c1.shape
+    mo = 2 * search_range + 1
+    out = torch.empty((b, h, w, mo * mo * nbre_cuts), dtype=torch.float32, device=c1.device)
+    check(lib.m4d_sncv_fwd(dptr(c1, "c1"), dptr(c2, "c2"), b, h, w, C, search_range, dilation_rate,
+                           nbre_cuts, dptr(out), mo * mo * nbre_cuts, stream_ptr()), "m4d_sncv_fwd")
+    return out
+
+
+class _SNCV(torch.autograd.Function):
+    """cost_volume with its gradient (m4d_sncv_bwd); ``same`` = c1 and c2 are one tensor."""
+
+    @staticmethod
+    def forward(ctx, c1, c2, search_range, dilation_rate, nbre_cuts):
+        out = _sncv_forward(c1, c2, search_range, dilation_rate, nbre_cuts)
+        ctx.save_for_backward(c1, c2, out)
+        ctx.cfg = (search_range, dilation_rate, nbre_cuts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        c1, c2, out = ctx.saved_tensors
+        r, d, k = ctx.cfg
+        b, h, w, C = c1.shape
+        g = as_f32(g, "g")
+        g_c1 = torch.empty_like(c1) if ctx.needs_input_grad[0] else None
+        g_c2 = torch.empty_like(c2) if ctx.needs_input_grad[1] else None
+        check(lib.m4d_sncv_bwd(dptr(c1), dptr(c2), dptr(out), out.shape[-1], dptr(g, "g"), g.shape[-1], b, h, w, C,
+                               r, d, k, 0.1, dptr(g_c1), dptr(g_c2), stream_ptr()), "m4d_sncv_bwd")
+        return g_c1, g_c2, None, None, None
 
 
 def cost_volume(c1, c2, search_range, name="cost_volume", dilation_rate=1, nbre_cuts=1):
     """Build cost volume for associating a pixel from Image1 with its
     corresponding pixels in Image2 -- the SNCV (utils/depth_operations.py:284-313).
-    Returns [b,h,w,(2r+1)^2*k], channel ((y*(2r+1)+x)*k + kk), leaky_relu(0.1)."""
+    Returns [b,h,w,(2r+1)^2*k], channel ((y*(2r+1)+x)*k + kk), leaky_relu(0.1).
+    Differentiable w.r.t. c1 and c2 when autograd is recording."""
     c1 = as_f32(c1, "c1")
     c2 = as_f32(c2, "c2")
     b, h, w, C = c1.shape
@@ -181,8 +255,6 @@ def cost_volume(c1, c2, search_range, name="cost_volume", dilation_rate=1, nbre_
         raise ValueError(f"c1 {tuple(c1.shape)} and c2 {tuple(c2.shape)} must have the same shape")
     if C % nbre_cuts != 0:
         raise ValueError(f"nbre_cuts={nbre_cuts} does not divide the {C} feature channels")
-    mo = 2 * int(search_range) + 1
-    out = torch.empty((b, h, w, mo * mo * nbre_cuts), dtype=torch.float32, device=c1.device)
-    check(lib.m4d_sncv_fwd(dptr(c1, "c1"), dptr(c2, "c2"), b, h, w, C, int(search_range), int(dilation_rate),
-                           int(nbre_cuts), dptr(out), mo * mo * nbre_cuts, stream_ptr()), "m4d_sncv_fwd")
-    return out
+    if torch.is_grad_enabled() and (c1.requires_grad or c2.requires_grad):
+        return _SNCV.apply(c1, c2, int(search_range), int(dilation_rate), int(nbre_cuts))
+    return _sncv_forward(c1, c2, int(search_range), int(dilation_rate), int(nbre_cuts))
