@@ -75,3 +75,24 @@ def barrier(device):
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
+
+
+def all_reduce_gradients(params, average=True):
+    """Data-parallel training (an extension: the reference trains on one GPU): ONE flat
+    all-reduce of every gradient.  The model has ~4.6 M parameters (18 MB), below the size where
+    splitting into buckets overlapped with backward would pay on xGMI (a ring step per link is
+    latency-bound under ~32 MB), so the whole set travels as a single bucket."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n

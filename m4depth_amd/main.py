@@ -1,6 +1,6 @@
-"""Eval / predict driver -- the counterpart of the reference ``main.py --mode=eval``
-(main.py:111-148) and ``--mode=predict`` (:150-172) over a seeded synthetic dataset
-(no dataset or checkpoint exists in the build environment).
+"""Train / eval / predict driver -- the counterpart of the reference ``main.py --mode=train``
+(main.py:73-109), ``--mode=eval`` (:111-148) and ``--mode=predict`` (:150-172) over a seeded
+synthetic dataset (no dataset or checkpoint exists in the build environment).
 
     python -m m4depth_amd.main --mode=eval --arch_depth=6 --seq_len=4 --batch_size=2 \\
            --n_batches=4 --ckpt_dir=/tmp/m4d
@@ -29,7 +29,7 @@ from .network import M4Depth, M4depthAblationParameters, GraphedSequence
 
 def build_parser():
     p = argparse.ArgumentParser(description="M4Depth (MI355X native) eval driver")
-    p.add_argument("--mode", default="eval", choices=["eval", "predict"])
+    p.add_argument("--mode", default="eval", choices=["train", "eval", "predict"])
     p.add_argument("--dataset", default="synthetic")
     p.add_argument("--arch_depth", type=int, default=6, help="number of pyramid levels (m4depth_options.py:64)")
     p.add_argument("--seq_len", type=int, default=4)
@@ -41,6 +41,8 @@ def build_parser():
     p.add_argument("--ckpt_dir", default="ckpt")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--graph", action="store_true", help="replay the sequence forward from a hipGraph")
+    p.add_argument("--learning_rate", type=float, default=1e-4, help="Adam step size (main.py:88)")
+    p.add_argument("--save_every", type=int, default=0, help="train: checkpoint every N steps (0 = at the end)")
     for flag in ("DINL", "SNCV", "time_recurr", "normalize_features", "subdivide_features", "level_memory"):
         p.add_argument(f"--no_{flag}", action="store_true")
     return p
@@ -57,14 +59,84 @@ def synthetic_batches(args, rank, world, dev):
         yield data
 
 
+def _train_dir(args):
+    return os.path.join(args.ckpt_dir, "train")
+
+
+def latest_checkpoint(args):
+    """Newest ``ckpt-<step>.npz`` of <ckpt_dir>/train (the role of tf.train.latest_checkpoint,
+    callbacks.py:84), or None."""
+    d = _train_dir(args)
+    if not os.path.isdir(d):
+        return None
+    steps = sorted(int(f[5:-4]) for f in os.listdir(d) if f.startswith("ckpt-") and f.endswith(".npz"))
+    return (os.path.join(d, f"ckpt-{steps[-1]}.npz"), steps[-1]) if steps else None
+
+
+def load_weights(args, ablation):
+    """Weights for eval / predict: the latest training checkpoint when there is one (callbacks.py:104-111),
+    otherwise the seeded random initialisation."""
+    ck = latest_checkpoint(args)
+    if ck is not None:
+        print("Restoring weights from %s" % ck[0])
+        with np.load(ck[0]) as z:
+            return {k: z[k] for k in z.files if not k.startswith("opt.")}
+    return S.init_weights(args.arch_depth, seed=42, ablation=ablation)
+
+
+def train(args, ablation, rank, world, dev):
+    """main.py:73-109: Adam(1e-4), RMSE_log as the tracked metric, resume from the latest checkpoint.
+    Several ranks = data parallel: the global batch is sharded and the gradients are averaged with
+    one RCCL all-reduce per step (dist.all_reduce_gradients)."""
+    from . import training as TR
+    from .metrics import RootMeanSquaredLogError
+    torch.manual_seed(42)                                                       # tf.random.set_seed(42), main.py:76
+    model = M4Depth(nbre_levels=args.arch_depth, ablation_settings=ablation, is_training=True)
+    model.load_numpy_weights(load_weights(args, ablation), dev)
+    TR.set_trainable(model)
+    opt = torch.optim.Adam(model.parameters(), lr=args.learning_rate, eps=1e-7)   # Keras Adam: epsilon 1e-7
+    model.compile(optimizer=opt, metrics=[RootMeanSquaredLogError()])
+    ck = latest_checkpoint(args)
+    step0 = 0
+    if ck is not None:
+        step0 = ck[1]
+        opt_path = ck[0][:-4] + ".opt.pt"
+        if os.path.isfile(opt_path):
+            opt.load_state_dict(torch.load(opt_path, map_location=dev))
+    sync = D.all_reduce_gradients if world > 1 else None
+
+    def save(step):
+        if rank != 0:
+            return
+        os.makedirs(_train_dir(args), exist_ok=True)
+        path = os.path.join(_train_dir(args), f"ckpt-{step}.npz")
+        np.savez(path, **model.numpy_weights())
+        torch.save(opt.state_dict(), path[:-4] + ".opt.pt")
+        print("saved", path)
+
+    step = step0
+    for data in synthetic_batches(args, rank, world, dev):
+        out = model.train_step(data, grad_sync=sync)
+        step += 1
+        if rank == 0:
+            print(f"step {step}: loss {float(out['loss']):.6f}  RMSE_log {float(out['RMSE_log']):.6f}")
+        if args.save_every and step % args.save_every == 0:
+            save(step)
+    if not args.save_every or step % args.save_every != 0:
+        save(step)
+    return 0
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     rank, world, _, dev = D.init_from_env()
     if dev.type != "cuda":
         raise SystemExit("m4depth_amd.main needs a GPU: the hot path has no CPU fallback")
     ablation = M4depthAblationParameters(**{f: not getattr(args, f"no_{f}") for f in M4depthAblationParameters._fields})
+    if args.mode == "train":
+        return train(args, ablation, rank, world, dev)
     model = M4Depth(nbre_levels=args.arch_depth, ablation_settings=ablation)
-    model.load_numpy_weights(S.init_weights(args.arch_depth, seed=42, ablation=ablation), dev)
+    model.load_numpy_weights(load_weights(args, ablation), dev)
     model.compile(metrics=default_metrics())
     runner = None
     preds = []

@@ -476,13 +476,41 @@ class M4Depth(torch.nn.Module):
                 conv.load_hwio(weights[f"lvl.{lvl.lvl_depth}.conv.{i}.kernel"], weights[f"lvl.{lvl.lvl_depth}.conv.{i}.bias"], device)
         return self
 
+    def numpy_weights(self):
+        """Inverse of ``load_numpy_weights``: the dict of TF-layout (HWIO) arrays, e.g. for a checkpoint."""
+        def hwio(conv):
+            return conv.weight.detach().permute(2, 3, 1, 0).cpu().numpy().copy(), conv.bias.detach().cpu().numpy().copy()
+        out = {}
+        for i in range(self.model_settings["nbre_lvls"]):
+            out[f"enc.s1.{i}.kernel"], out[f"enc.s1.{i}.bias"] = hwio(self.encoder.conv_layers_s1[i])
+            out[f"enc.s2.{i}.kernel"], out[f"enc.s2.{i}.bias"] = hwio(self.encoder.conv_layers_s2[i])
+        dn = self.encoder.dn_layers[0]
+        out["enc.dn.0.scale"] = dn.scale.detach().reshape(-1).cpu().numpy().copy()
+        out["enc.dn.0.bias"] = dn.bias.detach().reshape(-1).cpu().numpy().copy()
+        for lvl in self.d_estimator.levels:
+            convs = list(lvl.disp_refiner.prep_conv_layers) + list(lvl.disp_refiner.est_d_conv_layers)
+            for i, conv in enumerate(convs):
+                out[f"lvl.{lvl.lvl_depth}.conv.{i}.kernel"], out[f"lvl.{lvl.lvl_depth}.conv.{i}.bias"] = hwio(conv)
+        return out
+
     def reset_state(self):
         for lvl in self.d_estimator.levels:
             lvl.reset_state()
 
     # -- forward -------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, data, training=False):
+        """``training=True`` on a model built with ``is_training=True`` and trainable parameters
+        records the autograd graph (training.model_forward_train); everything else runs the
+        fused inference kernels without recording anything."""
+        if training and self.model_settings["is_training"] and torch.is_grad_enabled() \
+                and any(p.requires_grad for p in self.parameters()):
+            from . import training as TR
+            self.step_counter += 1
+            return TR.model_forward_train(self, data[0], data[1])
+        with torch.no_grad():
+            return self._forward_inference(data, training)
+
+    def _forward_inference(self, data, training=False):
         traj_samples, camera = data[0], data[1]
         self.step_counter += 1
         # The encoder is independent per frame (:358-360): run it ONCE on the frames stacked along
@@ -503,8 +531,22 @@ class M4Depth(torch.nn.Module):
         return {"depth": nops.resize_nearest(d_maps_pyrs[-1][0]["depth"], h, w)}
 
     # -- Keras-harness mirror (main.py:127-133) -------------------------------------------
-    def compile(self, metrics=None, **_unused):
+    def compile(self, metrics=None, optimizer=None, **_unused):
         self.compiled_metrics = list(metrics or [])
+        self.optimizer = optimizer
+
+    def m4depth_loss(self, gts, preds):
+        """m4depth_network.py:491-536."""
+        from . import training as TR
+        return TR.m4depth_loss(gts, preds, self.depth_type)
+
+    def train_step(self, data, grad_sync=None):
+        """m4depth_network.py:371-431; needs ``compile(optimizer=...)`` and trainable parameters
+        (``training.set_trainable``)."""
+        from . import training as TR
+        if getattr(self, "optimizer", None) is None:
+            raise RuntimeError("train_step: compile the model with an optimizer first")
+        return TR.train_step(self, data, self.optimizer, grad_sync)
 
     def _update_metrics(self, gt_raw, est_raw, max_d=80.):
         """compiled_metrics.update_state on the clipped maps (:465-470).  With the default

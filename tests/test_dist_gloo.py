@@ -61,3 +61,37 @@ def test_two_rank_metric_allgather():
         assert shape == (2, 7, 2)
         assert np.allclose(res, ref, rtol=1e-6)
         assert tmax == 2.0
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from m4depth_amd import dist as D
+    r, w, _, dev = D.init_from_env(backend="gloo")
+    params = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2))]
+    params[0].grad = torch.full((3, 4), float(r + 1))
+    params[1].grad = torch.arange(5, dtype=torch.float32) * (r + 1)
+    # params[2] has no gradient on any rank (a frozen layer): must be skipped consistently
+    D.all_reduce_gradients(params)
+    q.put((r, params[0].grad.tolist(), params[1].grad.tolist(), params[2].grad is None))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce():
+    """Data-parallel training: gradients of both ranks are averaged by one flat all-reduce."""
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, g0, g1, none2 in outs:
+        assert np.allclose(g0, 1.5)
+        assert np.allclose(g1, 1.5 * np.arange(5))
+        assert none2
