@@ -164,6 +164,42 @@ int m4d_sncv_bwd(const float* c1, const float* c2, const float* out, int out_str
                  int dilation_rate, int nbre_cuts, float slope, float* g_c1, float* g_c2,
                  void* stream);
 
+/* ---- per-pixel glue of the training graph (one kernel per autograd node) ----------- */
+
+/* Adjoint of m4d_resize_bilinear_v1: g_out [b,oh,ow,c] -> g_in [b,ih,iw,c] (gather: deterministic). */
+int m4d_resize_bilinear_v1_bwd(const float* g_out, int b, int ih, int iw, int c, int oh, int ow,
+                               float mul, float* g_in, void* stream);
+/* Backward of m4d_level_post (m4depth_network.py:247-251): gradients of parallax / depth / other
+ * (any may be NULL = zero) -> gradient of the refiner output [b,h,w,5]. */
+int m4d_level_post_bwd(const float* refiner_out, const float* g_parallax, const float* g_depth,
+                       const float* g_other, const float* rot, int rot_c, const float* trans,
+                       const float* cam_f, const float* cam_c, int b, int h, int w, float scale,
+                       float* g_refiner_out, void* stream);
+/* Backward of m4d_normalize_cuts: g_x = g/n - x * sum(g*x)/n^3 per cut. */
+int m4d_normalize_cuts_bwd(const float* x, const float* g, int b, int h, int w, int C, int nbre_cuts,
+                           float* g_x, void* stream);
+/* Backward of the convolution epilogue leaky_relu(conv + bias): g_pre = g * (out > 0 ? 1 : slope)
+ * (tf.nn.leaky_relu's gradient), g_bias[c] = sum over rows of g_pre (two-stage, fixed order).
+ * workspace: m4d_bias_act_bwd_workspace_floats(rows, C) floats. */
+long long m4d_bias_act_bwd_workspace_floats(long long rows, int C);
+int m4d_bias_act_bwd(const float* g, const float* out, long long rows, int C, float slope,
+                     float* g_pre, float* g_bias, float* workspace, void* stream);
+/* Device-side weight packing for m4d_conv3x3*_bias_act*: w_ohwi = [O][3][3][I] (the channels-last
+ * memory of an OIHW parameter) -> [ceil(K/16)][9][Npad][16]; transpose = 0: K = I, N = O (forward),
+ * 1: K = O, N = I with the taps rotated by 180 degrees (data gradient of the stride-1 layer). */
+int m4d_pack_conv_weights(const float* w_ohwi, int O, int I, int transpose, float* wp, void* stream);
+/* One level's term of m4depth_loss (m4depth_network.py:491-536), unweighted:
+ * mean |resize(log clip(gt)) - log clip(pred)| ('map': tf.image.resize bilinear, :532) or the
+ * hole-aware block mean of velodyne ground truth (:514-527).  out2 = (term, point count);
+ * workspace: m4d_loss_workspace_floats() floats.  Backward: g_pred [b,h,w,1] from the scalar
+ * gradient g_out (device) and out2 of the forward. */
+long long m4d_loss_workspace_floats(void);
+int m4d_loss_level_fwd(const float* pred_depth, const float* gt_depth, int b, int h, int w, int H, int W,
+                       int velodyne, float* workspace, float* out2, void* stream);
+int m4d_loss_level_bwd(const float* pred_depth, const float* gt_depth, const float* stats2,
+                       const float* g_out, int b, int h, int w, int H, int W, int velodyne,
+                       float* g_pred, void* stream);
+
 /* ---- m4depth_network.py: DepthEstimatorLevel glue -------------------------------- */
 
 /* Per-cut L2 normalisation (:179-189, tf.linalg.normalize, no epsilon). */

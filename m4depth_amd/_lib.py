@@ -38,6 +38,14 @@ _SIGNATURES = {
                      _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "m4d_sncv_bwd": [_c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                      _c_int, _c_f, _c_fp, _c_fp, _c_fp],
+    "m4d_resize_bilinear_v1_bwd": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
+    "m4d_level_post_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
+                           _c_fp, _c_fp],
+    "m4d_normalize_cuts_bwd": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_bias_act_bwd": [_c_fp, _c_fp, ctypes.c_longlong, _c_int, _c_f, _c_fp, _c_fp, _c_fp, _c_fp],
+    "m4d_pack_conv_weights": [_c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_loss_level_fwd": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
+    "m4d_loss_level_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_normalize_cuts": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_resize_bilinear_v1": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_resize_nearest": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
@@ -59,7 +67,8 @@ _SIGNATURES = {
 }
 
 _LL_SIGNATURES = {"m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
-                  "m4d_dinl_workspace_floats": [_c_int, _c_int], "m4d_metrics_workspace_bytes": []}
+                  "m4d_dinl_workspace_floats": [_c_int, _c_int], "m4d_metrics_workspace_bytes": [],
+                  "m4d_bias_act_bwd_workspace_floats": [ctypes.c_longlong, _c_int], "m4d_loss_workspace_floats": []}
 _VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
                     "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp]}
 

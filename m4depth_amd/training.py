@@ -23,28 +23,30 @@ import torch
 import torch.nn.functional as F
 
 from . import network_ops as nops
-from ._lib import as_f32
+from ._lib import lib, dptr, stream_ptr, check, as_f32
 from .depth_operations import get_parallax_sweeping_cv, cost_volume, prev_d2para, depth2parallax
-
-_PERM16 = [0, 2, 4, 6, 8, 10, 12, 14, 1, 3, 5, 7, 9, 11, 13, 15]
-
-
-def pack_conv_weights_device(kernel_hwio):
-    """Device-side twin of network_ops.pack_conv_weights (same layout, torch ops): the weights
-    change every optimizer step, so training re-packs them on the GPU instead of on the host."""
-    cin, cout = kernel_hwio.shape[2], kernel_hwio.shape[3]
-    nch = -(-cin // 16)
-    cpad = -(-cout // 32) * 32
-    full = kernel_hwio.new_zeros((9, nch * 16, cpad))
-    full[:, :cin, :cout] = kernel_hwio.reshape(9, cin, cout)
-    w = full.reshape(9, nch, 16, cpad)[:, :, _PERM16, :]
-    return w.permute(1, 0, 3, 2).contiguous(), cpad
-
 
 def _same_pads(h, w, s):
     ph = max((-(-h // s) - 1) * s + 3 - h, 0)
     pw = max((-(-w // s) - 1) * s + 3 - w, 0)
     return ph // 2, ph - ph // 2, pw // 2, pw - pw // 2
+
+
+def _packed(cache, weight, transpose):
+    """(wp, n_pad) of the live parameter, re-packed by one HIP kernel per optimizer step."""
+    key = ("bwd" if transpose else "fwd", weight.data_ptr(), weight._version)
+    hit = cache.get(key)
+    if hit is None:
+        O, I = weight.shape[0], weight.shape[1]
+        w_ohwi = weight.detach().permute(0, 2, 3, 1).contiguous()      # a view of the channels-last parameter
+        K, N = (O, I) if transpose else (I, O)
+        n_pad = -(-N // 32) * 32
+        wp = torch.empty((-(-K // 16), 9, n_pad, 16), dtype=torch.float32, device=weight.device)
+        check(lib.m4d_pack_conv_weights(dptr(w_ohwi, "weight"), O, I, int(transpose), dptr(wp), stream_ptr()),
+              "m4d_pack_conv_weights")
+        hit = (wp, n_pad)
+        cache[key] = hit
+    return hit
 
 
 class _ConvBiasAct(torch.autograd.Function):
@@ -54,14 +56,9 @@ class _ConvBiasAct(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, slope, cache):
         b, h, w, cin = x.shape
         cout = weight.shape[0]
-        use_mfma = cin >= 8
-        if use_mfma:
-            key = ("fwd", weight.data_ptr(), weight._version)
-            packed = cache.get(key)
-            if packed is None:
-                packed = pack_conv_weights_device(weight.detach().permute(2, 3, 1, 0))
-                cache[key] = packed
-            out = nops.conv3x3_bias_act(x, packed[0], bias.detach(), cout, packed[1], slope, stride=stride)
+        if cin >= 8:
+            wp, n_pad = _packed(cache, weight, False)
+            out = nops.conv3x3_bias_act(x, wp, bias.detach(), cout, n_pad, slope, stride=stride)
         else:
             pt, pb, pl, pr = _same_pads(h, w, stride)
             xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
@@ -78,24 +75,25 @@ class _ConvBiasAct(torch.autograd.Function):
         b, h, w, cin = x.shape
         cout = weight.shape[0]
         g = as_f32(g, "grad")
-        if slope != 1.0:
-            g = g * torch.where(out > 0, 1.0, slope)          # tf.nn.leaky_relu gradient: features > 0 ? g : alpha*g
-        g_bias = g.sum(dim=(0, 1, 2)) if ctx.needs_input_grad[2] else None
+        rows = g.numel() // cout
+        # epilogue backward: leaky_relu mask (tf.nn.leaky_relu: features > 0 ? g : alpha*g) + bias gradient, one pass
+        gp = torch.empty_like(g)
+        g_bias = torch.empty(cout, dtype=torch.float32, device=g.device)
+        ws = nops._workspace("bias_bwd", 4 * int(lib.m4d_bias_act_bwd_workspace_floats(rows, cout)), g.device)
+        check(lib.m4d_bias_act_bwd(dptr(g, "grad"), dptr(out), rows, cout, float(slope), dptr(gp), dptr(g_bias), dptr(ws),
+                                   stream_ptr()), "m4d_bias_act_bwd")
+        g = gp
         need_x = ctx.needs_input_grad[0]
         g_x = None
         mfma_dgrad = need_x and stride == 1 and cout >= 8
         if mfma_dgrad:
             # adjoint of a stride-1 'SAME' 3x3 correlation = the same correlation with k'[ky,kx,o,i] = k[2-ky,2-kx,i,o]
-            key = ("bwd", weight.data_ptr(), weight._version)
-            packed = cache.get(key)
-            if packed is None:
-                packed = pack_conv_weights_device(weight.detach().flip(2, 3).permute(2, 3, 0, 1))
-                cache[key] = packed
+            wp, n_pad = _packed(cache, weight, True)
             zero = cache.get(("zero", cin))
             if zero is None:
                 zero = torch.zeros(cin, dtype=torch.float32, device=x.device)
                 cache[("zero", cin)] = zero
-            g_x = nops.conv3x3_bias_act(g, packed[0], zero, cin, packed[1], 1.0, stride=1)
+            g_x = nops.conv3x3_bias_act(g, wp, zero, cin, n_pad, 1.0, stride=1)
         pt, pb, pl, pr = _same_pads(h, w, stride)
         xn = x.permute(0, 3, 1, 2)
         if pt or pb or pl or pr:
@@ -118,61 +116,100 @@ def conv_bias_act(conv, x, slope, cache):
 
 
 # ------------------------------------------------------------------------------- glue
-def _upsample2_v1(x, h, w):
-    """tf.compat.v1.image.resize_bilinear(x, [h, w]) (legacy coordinates, m4depth_network.py:202-204)
-    with differentiable torch ops: src = dst * in/out, lower = floor, upper = min(ceil, in-1)."""
-    b, ih, iw, c = x.shape
+class _UpsampleV1(torch.autograd.Function):
+    """tf.compat.v1.image.resize_bilinear(x, [h, w]) * mul (legacy coordinates, m4depth_network.py:202-204)."""
 
-    def weights(out_n, in_n):
-        src = torch.arange(out_n, dtype=torch.float32, device=x.device) * (np.float32(in_n) / np.float32(out_n))
-        fl = torch.floor(src)
-        lo = fl.to(torch.int64).clamp_(0, in_n - 1)
-        hi = torch.ceil(src).to(torch.int64).clamp_(0, in_n - 1)
-        return lo, hi, src - fl
+    @staticmethod
+    def forward(ctx, x, h, w, mul):
+        ctx.cfg = (tuple(x.shape), h, w, mul)
+        return nops.resize_bilinear_v1(x, h, w, mul)
 
-    ylo, yhi, yl = weights(h, ih)
-    xlo, xhi, xl = weights(w, iw)
-    xl = xl.reshape(1, 1, w, 1)
-    yl = yl.reshape(1, h, 1, 1)
-    top_rows, bot_rows = x[:, ylo], x[:, yhi]
-    tl, tr = top_rows[:, :, xlo], top_rows[:, :, xhi]
-    bl, br = bot_rows[:, :, xlo], bot_rows[:, :, xhi]
-    top = tl + (tr - tl) * xl
-    bot = bl + (br - bl) * xl
-    return top + (bot - top) * yl
+    @staticmethod
+    def backward(ctx, g):
+        (b, ih, iw, c), h, w, mul = ctx.cfg
+        g = as_f32(g, "grad")
+        g_in = torch.empty((b, ih, iw, c), dtype=torch.float32, device=g.device)
+        check(lib.m4d_resize_bilinear_v1_bwd(dptr(g, "grad"), b, ih, iw, c, h, w, float(mul), dptr(g_in), stream_ptr()),
+              "m4d_resize_bilinear_v1_bwd")
+        return g_in, None, None, None
+
+
+def _upsample2_v1(x, h, w, mul=1.0):
+    return _UpsampleV1.apply(as_f32(x, "x"), int(h), int(w), float(mul))
+
+
+class _NormalizeCuts(torch.autograd.Function):
+    """Per-cut tf.linalg.normalize (m4depth_network.py:179-189)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.save_for_backward(x)
+        ctx.k = k
+        return nops.normalize_cuts(x, k)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        b, h, w, c = x.shape
+        g = as_f32(g, "grad")
+        gx = torch.empty_like(x)
+        check(lib.m4d_normalize_cuts_bwd(dptr(x), dptr(g, "grad"), b, h, w, c, ctx.k, dptr(gx), stream_ptr()),
+              "m4d_normalize_cuts_bwd")
+        return gx, None
 
 
 def _normalize_cuts(x, k):
-    b, h, w, c = x.shape
-    xr = x.reshape(b, h, w, k, c // k)
-    return (xr / torch.sqrt((xr * xr).sum(dim=-1, keepdim=True))).reshape(b, h, w, c)
+    return _NormalizeCuts.apply(as_f32(x, "x"), int(k))
 
 
-def _parallax_factors(b, h, w, rot, trans, camera):
-    """(s, tz, alpha) of parallax2depth (utils/depth_operations.py:146-162) as [b,h,w,1] maps, in the
-    operand order of the HIP converter (m4d_common.h: m4d_pixel_factors).  They depend on the camera
-    motion only, not on the network, so nothing here records a gradient."""
-    dev = trans.device
-    f = as_f32(camera["f"], "camera['f']").reshape(b, 2)
-    c = as_f32(camera["c"], "camera['c']").reshape(b, 2)
-    t = as_f32(trans, "trans").reshape(b, 3)
-    from .depth_operations import get_rot_mat
-    R = get_rot_mat(as_f32(rot, "rot"))
-    fx, fy = f[:, 0].reshape(b, 1, 1), f[:, 1].reshape(b, 1, 1)
-    x = ((torch.arange(w, dtype=torch.float32, device=dev) + 0.5).reshape(1, 1, w) - c[:, 0].reshape(b, 1, 1)) / fx
-    y = ((torch.arange(h, dtype=torch.float32, device=dev) + 0.5).reshape(1, h, 1) - c[:, 1].reshape(b, 1, 1)) / fy
+class _LevelPost(torch.autograd.Function):
+    """The level tail (m4depth_network.py:247-251): refiner output -> parallax = exp(clip)/2^m,
+    depth = parallax2depth(parallax), other."""
 
-    def row(k):
-        return (R[:, k, 0].reshape(b, 1, 1) * x + R[:, k, 1].reshape(b, 1, 1) * y) + R[:, k, 2].reshape(b, 1, 1)
+    @staticmethod
+    def forward(ctx, ro, rot, trans, f, c, scale):
+        para, depth, other = nops.level_post(ro, rot, trans, {"f": f, "c": c}, scale)
+        ctx.save_for_backward(ro, rot, trans, f, c)
+        ctx.scale = scale
+        return para, depth, other
 
-    rcx, rcy, alpha = row(0), row(1), row(2)
-    proj_x = (rcx * fx) / alpha
-    proj_y = (rcy * fy) / alpha
-    tz = t[:, 2].reshape(b, 1, 1)
-    dx = (t[:, 0] * f[:, 0]).reshape(b, 1, 1) - tz * proj_x
-    dy = (t[:, 1] * f[:, 1]).reshape(b, 1, 1) - tz * proj_y
-    s = torch.sqrt(dx * dx + dy * dy)
-    return s.unsqueeze(-1), tz.unsqueeze(-1), alpha.unsqueeze(-1)
+    @staticmethod
+    def backward(ctx, g_para, g_depth, g_other):
+        ro, rot, trans, f, c = ctx.saved_tensors
+        b, h, w, _ = ro.shape
+        gs = [None if g is None else as_f32(g, "grad") for g in (g_para, g_depth, g_other)]
+        g_ro = torch.empty_like(ro)
+        check(lib.m4d_level_post_bwd(dptr(ro), dptr(gs[0]), dptr(gs[1]), dptr(gs[2]), dptr(rot, "rot"), rot.shape[1],
+                                     dptr(trans), dptr(f), dptr(c), b, h, w, float(ctx.scale), dptr(g_ro), stream_ptr()),
+              "m4d_level_post_bwd")
+        return g_ro, None, None, None, None, None
+
+
+class _LevelL1(torch.autograd.Function):
+    """One level's unweighted term of m4depth_loss (m4depth_network.py:503-533)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, velodyne):
+        b, h, w, _ = pred.shape
+        H, W = gt.shape[1:3]
+        ws = nops._workspace("loss", 4 * int(lib.m4d_loss_workspace_floats()), pred.device)
+        out2 = torch.empty(2, dtype=torch.float32, device=pred.device)
+        check(lib.m4d_loss_level_fwd(dptr(pred, "pred"), dptr(gt, "gt"), b, h, w, H, W, int(velodyne), dptr(ws), dptr(out2),
+                                     stream_ptr()), "m4d_loss_level_fwd")
+        ctx.save_for_backward(pred, gt, out2)
+        ctx.velodyne = velodyne
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt, out2 = ctx.saved_tensors
+        b, h, w, _ = pred.shape
+        H, W = gt.shape[1:3]
+        g = as_f32(g, "grad").reshape(1)
+        g_pred = torch.empty_like(pred)
+        check(lib.m4d_loss_level_bwd(dptr(pred), dptr(gt), dptr(out2), dptr(g, "grad"), b, h, w, H, W, int(ctx.velodyne),
+                                     dptr(g_pred), stream_ptr()), "m4d_loss_level_bwd")
+        return g_pred, None, None
 
 
 def level_forward_train(level, curr_f_maps, prev_l_est, rot, trans, camera, prev_f_maps, prev_t_depth, cache):
@@ -188,7 +225,7 @@ def level_forward_train(level, curr_f_maps, prev_l_est, rot, trans, camera, prev
         other_prev_l = torch.zeros((b, h, w, 4), device=dev)
     else:                                                                            # :202-204
         other_prev_l = _upsample2_v1(prev_l_est["other"], h, w)
-        para_prev_l = _upsample2_v1(prev_l_est["parallax"], h, w) * 2.
+        para_prev_l = _upsample2_v1(prev_l_est["parallax"], h, w, 2.)
         depth_prev_l = _upsample2_v1(prev_l_est["depth"], h, w)
     if prev_t_depth is None:                                                         # :208-214
         return {"depth": depth_prev_l, "parallax": para_prev_l, "other": other_prev_l}
@@ -212,10 +249,10 @@ def level_forward_train(level, curr_f_maps, prev_l_est, rot, trans, camera, prev
     convs = list(level.disp_refiner.prep_conv_layers) + list(level.disp_refiner.est_d_conv_layers)
     for i, conv in enumerate(convs):
         x = conv_bias_act(conv, x, 0.1 if i < len(convs) - 1 else None, cache)
-    para, other = x[..., :1], x[..., 1:]
-    para_curr = torch.exp(torch.clamp(para, -7., 7.)) / scale                        # :250
-    s, tz, alpha = _parallax_factors(b, h, w, rot, trans, camera)
-    depth = (s / para_curr - tz) / alpha                                             # parallax2depth, :251
+    rot_t = as_f32(rot, "rot")
+    para_curr, depth, other = _LevelPost.apply(x, rot_t, as_f32(trans, "trans").reshape(b, 3),
+                                               as_f32(camera["f"], "f").reshape(b, 2),
+                                               as_f32(camera["c"], "c").reshape(b, 2), scale)   # :247-251
     return {"other": other, "depth": depth, "parallax": para_curr}
 
 
@@ -263,53 +300,16 @@ def model_forward_train(model, traj_samples, camera):
     return d_est_seq
 
 
-def _resize_half_pixel(x, h, w):
-    """tf.image.resize(x, [h, w]) (bilinear, half-pixel centres, no antialias; m4depth_network.py:532)."""
-    b, ih, iw, c = x.shape
-
-    def weights(out_n, in_n):
-        src = (torch.arange(out_n, dtype=torch.float32, device=x.device) + 0.5) * (in_n / out_n) - 0.5
-        fl = torch.floor(src)
-        return fl.to(torch.int64).clamp_(0, in_n - 1), torch.ceil(src).to(torch.int64).clamp_(0, in_n - 1), src - fl
-
-    ylo, yhi, yl = weights(h, ih)
-    xlo, xhi, xl = weights(w, iw)
-    xl = xl.reshape(1, 1, w, 1)
-    yl = yl.reshape(1, h, 1, 1)
-    tl, tr = x[:, ylo][:, :, xlo], x[:, ylo][:, :, xhi]
-    bl, br = x[:, yhi][:, :, xlo], x[:, yhi][:, :, xhi]
-    top = tl + (tr - tl) * xl
-    bot = bl + (br - bl) * xl
-    return top + (bot - top) * yl
-
-
 def m4depth_loss(gts, preds, depth_type="map"):
     """M4Depth.m4depth_loss (m4depth_network.py:491-536): log-depth L1 over every level of every
-    frame but the first, level i weighted 0.64 / 2**(i-1)."""
-    def preprocess(x):
-        return torch.log(torch.clamp(x, 0.01, 200.))
-
-    def masked_reduce_mean(array, mask, dims=None):
-        if dims is None:
-            return (array * mask).sum() / (mask.sum() + 1e-12)
-        return (array * mask).sum(dim=dims) / (mask.sum(dim=dims) + 1e-12)
-
+    frame but the first, level i weighted 0.64 / 2**(i-1); one fused HIP kernel per level."""
     l1_loss = 0.
+    velodyne = depth_type == "velodyne"
     for gt, pred_pyr in zip(gts[1:], preds[1:]):
-        gt_pre = preprocess(gt["depth"])
+        gt_d = as_f32(gt["depth"], "gt depth")
         for i, pred in enumerate(pred_pyr):
-            pred_depth = preprocess(pred["depth"])
-            b, h, w = pred_depth.shape[:3]
-            if depth_type == "velodyne":
-                h_g, w_g = gt_pre.shape[1:3]
-                mask = (gt["depth"].reshape(b, h, h_g // h, w, w_g // w, 1) > 0).float()
-                gt_resized = masked_reduce_mean(gt_pre.reshape(b, h, h_g // h, w, w_g // w, 1), mask, dims=(2, 4))
-                new_mask = (mask.sum(dim=(2, 4)) > 0.).float()
-                term = (0.64 / (2. ** (i - 1))) * masked_reduce_mean(torch.abs(gt_resized - pred_depth), new_mask)
-            else:
-                gt_resized = _resize_half_pixel(gt_pre, h, w)
-                term = (0.64 / (2. ** (i - 1))) * torch.abs(gt_resized - pred_depth).mean()
-            l1_loss = l1_loss + term / float(len(gts) - 1)
+            term = _LevelL1.apply(as_f32(pred["depth"], "pred depth"), gt_d, velodyne)
+            l1_loss = l1_loss + term * ((0.64 / (2. ** (i - 1))) / float(len(gts) - 1))
     return l1_loss
 
 
@@ -362,3 +362,69 @@ def train_step(model, data, optimizer, grad_sync=None):
     out = {m.name: m.result() for m in model.compiled_metrics}
     out["loss"] = loss.detach()
     return out
+
+
+class GraphedTrainStep:
+    """One whole ``train_step`` -- forward, loss, backward, Adam update -- captured in a hipGraph.
+
+    Eagerly a 384x384 / batch-3 / 4-frame step is several thousand kernel launches (most of them
+    the few-microsecond elementwise nodes of the autograd graph) and the GPU idles two thirds of
+    the time waiting for the host (profiles/r01_train_steady_state_eager.txt).  The step has no
+    host synchronisation and fixed shapes, so it is captured once and replayed: the host then
+    only copies the next batch into the static input buffers.
+
+    Requirements: an optimizer whose step is capturable (``torch.optim.Adam(..., capturable=True)``),
+    the batch layout of ``example`` for every later call, ``new_traj`` = first frame only (it is
+    host-side control flow baked into the capture).  The eager warm-up steps (MIOpen solver search,
+    workspace allocation) are REAL optimizer steps on ``example``."""
+
+    def __init__(self, model, example, optimizer, warmup=3, grad_sync=None):
+        self.model, self.optimizer = model, optimizer
+        self.static = {k: example[k].clone() for k in ("depth", "RGB_im", "rot", "trans")}
+        self.camera = {k: v.clone() for k, v in example["camera"].items()}
+        self.new_traj = example["new_traj"]
+        self.grad_sync = grad_sync
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.est = self._step()
+
+    def _data(self):
+        d = dict(self.static)
+        d["new_traj"] = self.new_traj
+        d["camera"] = self.camera
+        return d
+
+    def _step(self):
+        data = self._data()
+        samples = unstack_sequence(data)
+        gts = [{"depth": s["depth"]} for s in samples]
+        preds = model_forward_train(self.model, samples, self.camera)
+        loss = m4depth_loss(gts, preds, self.model.depth_type)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync([p for g in self.optimizer.param_groups for p in g["params"]])
+        self.optimizer.step()
+        return loss.detach(), preds[-1][0]["depth"].detach()
+
+    def __call__(self, data=None):
+        """Copies ``data`` into the static buffers, replays the step; returns (loss, finest depth
+        estimate of the last frame) -- static device tensors, overwritten by the next replay."""
+        if data is not None:
+            for k in self.static:
+                if data[k].data_ptr() != self.static[k].data_ptr():
+                    self.static[k].copy_(data[k], non_blocking=True)
+            for k in self.camera:
+                if data["camera"][k].data_ptr() != self.camera[k].data_ptr():
+                    self.camera[k].copy_(data["camera"][k], non_blocking=True)
+        self.graph.replay()
+        self.model.step_counter += 1
+        return self.loss, self.est

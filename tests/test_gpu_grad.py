@@ -91,3 +91,87 @@ def test_dscv_backward_no_grad_paths(M, dev):
     with torch.no_grad():
         cv2, _ = M.get_parallax_sweeping_cv(c1, c2, dpt, disp, to_dev(rot, dev), to_dev(trans, dev), cam, r)
     assert not cv2.requires_grad and torch.equal(cv2, cv.detach())
+
+
+# ------------------------------------------------------------------ training glue kernels
+def test_pack_conv_weights_kernel_matches_host_packer(M, dev):
+    from m4depth_amd import network_ops as nops, training as TR
+    rng = np.random.default_rng(0)
+    for O, I in ((45, 37), (128, 122), (5, 16)):
+        w = torch.from_numpy(rng.normal(size=[O, I, 3, 3]).astype(F)).to(dev).contiguous(memory_format=torch.channels_last)
+        hwio = npy(w).transpose(2, 3, 1, 0)
+        want, cpad = nops.pack_conv_weights(hwio)
+        got, npad = TR._packed({}, w, False)
+        assert npad == cpad and np.array_equal(npy(got), want)
+        want_t, cpad_t = nops.pack_conv_weights(np.ascontiguousarray(hwio[::-1, ::-1].transpose(0, 1, 3, 2)))
+        got_t, npad_t = TR._packed({}, w, True)
+        assert npad_t == cpad_t and np.array_equal(npy(got_t), want_t)
+
+
+def test_glue_backward_kernels_match_autodiff_of_the_restatement(M, dev):
+    from m4depth_amd import training as TR
+    rng = np.random.default_rng(4)
+    b, h, w = 2, 6, 9
+    # x2 legacy upsample
+    x = rng.normal(size=[b, h, w, 4]).astype(F)
+    g = rng.normal(size=[b, 2 * h, 2 * w, 4]).astype(F)
+    tx = torch.from_numpy(x).requires_grad_(True)
+    (OT.resize_bilinear(tx, 2 * h, 2 * w, False) * 2.0 * torch.from_numpy(g)).sum().backward()
+    dx = to_dev(x, dev).requires_grad_(True)
+    (TR._upsample2_v1(dx, 2 * h, 2 * w, 2.0) * to_dev(g, dev)).sum().backward()
+    _close(npy(dx.grad), tx.grad.numpy(), 1e-6, "upsample adjoint")
+    # per-cut normalisation
+    x = rng.normal(size=[b, h, w, 32]).astype(F)
+    g = rng.normal(size=[b, h, w, 32]).astype(F)
+    tx = torch.from_numpy(x).requires_grad_(True)
+    (OT.normalize_cuts(tx, 2) * torch.from_numpy(g)).sum().backward()
+    dx = to_dev(x, dev).requires_grad_(True)
+    (TR._normalize_cuts(dx, 2) * to_dev(g, dev)).sum().backward()
+    _close(npy(dx.grad), tx.grad.numpy(), 1e-5, "normalize_cuts backward")
+    # level tail
+    ro = rng.normal(0, 3.0, size=[b, h, w, 5]).astype(F)
+    ro[0, 0, 0, 0] = 9.0                                   # outside the clip: no gradient
+    rot, trans = motion_np(rng, b)
+    cam = camera_np(b, h, w)
+    gs = [rng.normal(size=[b, h, w, n]).astype(F) for n in (1, 1, 4)]
+    tro = torch.from_numpy(ro).requires_grad_(True)
+    para = torch.exp(torch.clamp(tro[..., :1], -7., 7.)) / 0.5
+    depth = OT.parallax2depth(para, rot, trans, cam)
+    ((para * torch.from_numpy(gs[0])).sum() + (depth * torch.from_numpy(gs[1])).sum()
+     + (tro[..., 1:] * torch.from_numpy(gs[2])).sum()).backward()
+    dro = to_dev(ro, dev).requires_grad_(True)
+    dcam = to_dev(cam, dev)
+    p_d, d_d, o_d = TR._LevelPost.apply(dro, to_dev(rot, dev), to_dev(trans, dev), dcam["f"], dcam["c"], 0.5)
+    ((p_d * to_dev(gs[0], dev)).sum() + (d_d * to_dev(gs[1], dev)).sum() + (o_d * to_dev(gs[2], dev)).sum()).backward()
+    _close(npy(dro.grad), tro.grad.numpy(), 1e-5, "level tail backward")
+    assert npy(dro.grad)[0, 0, 0, 0] == 0.0
+    # loss term of one level, both ground-truth kinds
+    gt = rng.uniform(1, 80, size=[b, 4 * h, 4 * w, 1]).astype(F)
+    pred = rng.uniform(0.005, 250, size=[b, h, w, 1]).astype(F)
+    for kind in ("map", "velodyne"):
+        gtk = gt * (rng.random(gt.shape) > 0.8) if kind == "velodyne" else gt
+        gtk = gtk.astype(F)
+        tp = torch.from_numpy(pred).requires_grad_(True)
+        ref = OT.m4depth_loss([None, {"depth": torch.from_numpy(gtk)}], [None, [{"depth": tp}]], kind)
+        ref.backward()
+        dp = to_dev(pred, dev).requires_grad_(True)
+        got = TR.m4depth_loss([None, {"depth": to_dev(gtk, dev)}], [None, [{"depth": dp}]], kind)
+        got.backward()
+        assert abs(got.item() - ref.item()) <= 2e-6 * abs(ref.item()), (kind, got.item(), ref.item())
+        _close(npy(dp.grad), tp.grad.numpy(), 1e-5, f"loss backward ({kind})")
+
+
+def test_bias_act_backward_kernel(M, dev):
+    from m4depth_amd._lib import lib, dptr, stream_ptr, check
+    rng = np.random.default_rng(8)
+    for rows, C in ((1000, 5), (777, 96), (300, 128), (64, 470)):
+        g = rng.normal(size=[rows, C]).astype(F)
+        out = rng.normal(size=[rows, C]).astype(F)
+        dg, dout = to_dev(g, dev), to_dev(out, dev)
+        gp = torch.empty_like(dg)
+        gb = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.m4d_bias_act_bwd_workspace_floats(rows, C)), dtype=torch.float32, device=dev)
+        check(lib.m4d_bias_act_bwd(dptr(dg), dptr(dout), rows, C, 0.1, dptr(gp), dptr(gb), dptr(ws), stream_ptr()), "bwd")
+        want = g * np.where(out > 0, F(1.0), F(0.1))
+        assert np.array_equal(npy(gp), want)
+        np.testing.assert_allclose(npy(gb), want.sum(axis=0, dtype=np.float64), rtol=1e-5, atol=1e-4)

@@ -23,11 +23,31 @@ def main(path, out=None):
     names = [r["Kernel_Name"] for r in rows]
     n = len(names)
     period = None
-    for P in range(40, n // 2):
-        if names[n - P:] == names[n - 2 * P:n - P]:
-            period = P
+    for trail in range(0, 4):          # a few trailing launches (e.g. the final loss read-back) may follow the last step
+        m = n - trail
+        for P in range(40, m // 2):
+            if names[m - P:m] == names[m - 2 * P:m - P]:
+                period = P
+                break
+        if period is not None:
+            rows, names, n = rows[:m], names[:m], m
             break
     lines = []
+    if period is None:
+        # fuzzy fallback (e.g. MIOpen picks a different split for one call): candidate periods are the
+        # distances to earlier occurrences of the last kernel; accept >= 97 % position-wise agreement
+        last = names[-1]
+        for pos in range(n - 41, n // 2 - 1, -1):
+            if names[pos] != last:
+                continue
+            P = n - 1 - pos
+            if 2 * P > n:
+                break
+            same = sum(1 for a, b in zip(names[n - P:], names[n - 2 * P:n - P]) if a == b)
+            if same >= 0.97 * P:
+                period = P
+                lines.append(f"approximately repeating pattern ({same}/{P} launches identical to the previous period)")
+                break
     if period is None:
         lines.append("no repeating pattern found")
         period = min(n, 2000)
