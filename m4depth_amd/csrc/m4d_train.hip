@@ -154,13 +154,15 @@ bias_act_bwd_wide_kernel(const float* __restrict__ g, const float* __restrict__ 
     partial[(long long)blockIdx.x * C + c] = acc;
   }
 }
-__global__ void __launch_bounds__(256)
+// one wave per channel: lane t sums the partials of blocks t, t+64, ... in block order, then a fixed
+// butterfly combines the 64 lanes -- deterministic, and 16x shorter than one serial chain per channel
+__global__ void __launch_bounds__(64)
 bias_grad_finalize_kernel(const float* __restrict__ partial, int blocks, int C, float* __restrict__ g_bias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(long long)b * C + c];      // block order: deterministic
-  g_bias[c] = s;
+  for (int b = threadIdx.x; b < blocks; b += 64) s += partial[(long long)b * C + c];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (threadIdx.x == 0) g_bias[c] = s;
 }
 
 // ---- weight re-packing for conv3x3_mfma_kernel -----------------------------------------
@@ -337,7 +339,7 @@ extern "C" int m4d_bias_act_bwd(const float* g, const float* out, long long rows
     hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(blocks), dim3(256), 0, s, g, out, rows, C, slope, rpb, g_pre, workspace);
   else
     hipLaunchKernelGGL(bias_act_bwd_wide_kernel, dim3(blocks), dim3(256), 0, s, g, out, rows, C, slope, rpb, g_pre, workspace);
-  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, workspace, blocks, C, g_bias);
+  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, blocks, C, g_bias);
   return M4D_LAUNCH_RESULT();
 }
 
