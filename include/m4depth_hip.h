@@ -292,6 +292,22 @@ long long m4d_metrics_workspace_bytes(void);
 int m4d_depth_metrics(const float* gt, const float* est, long long n, float max_d, void* workspace,
                       float* out7, void* stream);
 
+/* ---- dataloaders (midair / kitti / tartanair .py): _decode_samples after decompression ----------------------- */
+
+/* RGB frames as the JPEG decoder leaves them, [n,ih,iw,3] uint8 -> [n,oh,ow,3] float32 =
+ * tf.image.resize(cast(image)/255, [oh,ow]) (bilinear, half-pixel centres; midair.py:35-45,
+ * kitti.py:25-36, tartanair.py:21-33). */
+int m4d_decode_rgb8_resize(const uint8_t* images, int n, int ih, int iw, int oh, int ow, float* out,
+                           void* stream);
+/* Ground-truth maps [n,ih,iw] -> [n,oh,ow,1] float32.
+ * kind 0  Mid-Air: uint16 bit patterns of float16 disparity, depth = 512/x, bilinear (midair.py:49-55)
+ * kind 1  KITTI: uint16/256, nearest; crop (may be NULL) = {y0,y1,x0,x1} keeps [y0,y1)x[x0,x1) and
+ *         zeroes the rest -- the Garg/Eigen evaluation mask (kitti.py:14-20,43-50)
+ * kind 2  TartanAir: float32, nearest; rgb_resized (may be NULL) [n,oh,ow,3]: pixels whose colour
+ *         is exactly black are zeroed (tartanair.py:37-45). */
+int m4d_decode_depth_resize(const void* raw, int kind, int n, int ih, int iw, int oh, int ow,
+                            const float* rgb_resized, const int crop[4], float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,9 @@ _SIGNATURES = {
     "m4d_pack_conv_weights": [_c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_loss_level_fwd": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
     "m4d_loss_level_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_decode_rgb8_resize": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_decode_depth_resize": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, ctypes.POINTER(_c_int),
+                                _c_fp, _c_fp],
     "m4d_normalize_cuts": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_resize_bilinear_v1": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_resize_nearest": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],

@@ -52,3 +52,51 @@ def assert_bits_equal(a, b, what=""):
         bad = np.argwhere(~same)
         i = tuple(bad[0])
         raise AssertionError(f"{what}: {len(bad)} / {a.size} elements differ bitwise; first at {i}: {a[i]!r} vs {b[i]!r}")
+
+
+def make_fake_dataset(root, kind, n_traj=2, n_frames=7, size=(48, 64), seed=0):
+    """A miniature dataset in the on-disk format of the reference's dataloaders: JPEG frames, the
+    dataset's ground-truth encoding, tab-separated trajectory csv files.  Returns (db_path, records_path)."""
+    import os
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    h, w = size
+    db = os.path.join(root, "db")
+    rec = os.path.join(root, "records")
+    for t in range(n_traj):
+        tdir = os.path.join(db, f"traj_{t}")
+        os.makedirs(os.path.join(tdir, "color"), exist_ok=True)
+        os.makedirs(os.path.join(tdir, "gt"), exist_ok=True)
+        os.makedirs(os.path.join(rec, f"set_{t}"), exist_ok=True)
+        cols = ["id", "camera_l", "disp" if kind == "midair" else "depth", "qw", "qx", "qy", "qz", "tx", "ty", "tz"]
+        if kind == "kitti-raw":
+            cols += ["fx", "fy", "cx", "cy"]
+        lines = ["\t".join(cols)]
+        for i in range(n_frames):
+            img = (rng.random([h, w, 3]) * 255).astype(np.uint8)
+            img[: h // 8, : w // 8] = 0                                # a black corner (TartanAir mask)
+            cpath = os.path.join(f"traj_{t}", "color", f"{i:06d}.JPEG")
+            Image.fromarray(img).save(os.path.join(db, cpath), format="JPEG", quality=95)
+            depth = rng.uniform(2.0, 60.0, [h, w]).astype(np.float32)
+            if kind == "midair":
+                gpath = os.path.join(f"traj_{t}", "gt", f"{i:06d}.PNG")
+                bits = (np.float32(512.0) / depth).astype(np.float16).view(np.uint16)
+                Image.fromarray(bits).save(os.path.join(db, gpath), format="PNG")
+            elif kind == "kitti-raw":
+                gpath = os.path.join(f"traj_{t}", "gt", f"{i:06d}.png")
+                sparse = np.where(rng.random([h, w]) > 0.7, depth, 0.0)
+                Image.fromarray((sparse * 256.0).astype(np.uint16)).save(os.path.join(db, gpath), format="PNG")
+            else:
+                gpath = os.path.join(f"traj_{t}", "gt", f"{i:06d}.npy")
+                np.save(os.path.join(db, gpath), depth)
+            aa = rng.normal(0.0, 0.01, 3)
+            ang = np.linalg.norm(aa)
+            q = np.concatenate([[np.cos(ang / 2)], aa / max(ang, 1e-12) * np.sin(ang / 2)])
+            tr = rng.normal([0.0, 0.0, 0.3], 0.05, 3)
+            vals = [str(i), cpath, gpath] + [repr(float(v)) for v in q] + [repr(float(v)) for v in tr]
+            if kind == "kitti-raw":
+                vals += ["0.58", "1.92", "0.49", "0.51"]
+            lines.append("\t".join(vals))
+        with open(os.path.join(rec, f"set_{t}", f"traj_{t:04d}.csv"), "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+    return db, rec
