@@ -14,7 +14,7 @@ hardware suggests:
            torch ops on the device tensors.
 
 Batches come out as the dict ``M4Depth.train_step / test_step`` take: RGB_im [b,T,H,W,3],
-depth [b,T,H,W,1], rot [b,T,4], trans [b,T,3] on the device, new_traj [b,T] (host bools: it steers
+depth [b,T,H,W,1], rot [b,T,4], trans [b,T,3] on the device, new_traj [b,T] (host bool tensor: it steers
 control flow), camera {f [b,2], c [b,2]}.  Streaming evaluation (db_seq_len None) yields single
 frames without the T axis, batch 1, like the reference.
 """
@@ -249,7 +249,7 @@ class DataLoaderGeneric():
             if key == "camera":
                 batch[key] = {k: torch.stack([s["camera"][k] for s in seqs]) for k in ("f", "c")}
             elif key == "new_traj":
-                batch[key] = np.stack([np.asarray(s[key]) for s in seqs])
+                batch[key] = torch.from_numpy(np.stack([np.asarray(s[key]) for s in seqs]))     # stays on the host
             else:
                 batch[key] = torch.stack([s[key] for s in seqs])
         return batch

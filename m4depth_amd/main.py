@@ -28,35 +28,76 @@ from .network import M4Depth, M4depthAblationParameters, GraphedSequence
 
 
 def build_parser():
-    p = argparse.ArgumentParser(description="M4Depth (MI355X native) eval driver")
-    p.add_argument("--mode", default="eval", choices=["train", "eval", "predict"])
-    p.add_argument("--dataset", default="synthetic")
+    p = argparse.ArgumentParser(description="M4Depth (MI355X native) train / eval / predict driver")
+    p.add_argument("--mode", default="eval", choices=["train", "finetune", "eval", "validation", "predict"])
+    p.add_argument("--dataset", default="synthetic", choices=["synthetic", "midair", "tartanair", "kitti-raw"],
+                   help="a dataset of the reference (m4depth_options.py:11-14) or the seeded synthetic one")
+    p.add_argument("--db_path_config", default=None, help="json file with the dataset roots (m4depth_options.py:27-29)")
+    p.add_argument("--records_path", default=None, help="directory of trajectory csv files (m4depth_options.py:33-35)")
+    p.add_argument("--no_augmentation", action="store_true")
+    p.add_argument("--epochs", type=int, default=1, help="train on a real dataset: passes over the records")
     p.add_argument("--arch_depth", type=int, default=6, help="number of pyramid levels (m4depth_options.py:64)")
     p.add_argument("--seq_len", type=int, default=4)
     p.add_argument("--db_seq_len", type=int, default=None)
     p.add_argument("--batch_size", type=int, default=1, help="GLOBAL batch (sharded over ranks)")
-    p.add_argument("--n_batches", type=int, default=2)
-    p.add_argument("--height", type=int, default=384)
-    p.add_argument("--width", type=int, default=1280)
+    p.add_argument("--n_batches", type=int, default=2, help="synthetic dataset: batches to generate")
+    p.add_argument("--height", type=int, default=None, help="frame height (default: 384 synthetic, else the dataset's)")
+    p.add_argument("--width", type=int, default=None)
     p.add_argument("--ckpt_dir", default="ckpt")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--graph", action="store_true", help="replay the sequence forward from a hipGraph")
     p.add_argument("--learning_rate", type=float, default=1e-4, help="Adam step size (main.py:88)")
     p.add_argument("--save_every", type=int, default=0, help="train: checkpoint every N steps (0 = at the end)")
-    for flag in ("DINL", "SNCV", "time_recurr", "normalize_features", "subdivide_features", "level_memory"):
+    # ablation flags, spelled as in m4depth_options.py:67-84
+    for flag in ("DINL", "SNCV", "time_recurr", "feature_normalization", "feature_subdivision", "level_memory"):
         p.add_argument(f"--no_{flag}", action="store_true")
     return p
 
 
+def ablation_from_args(args):
+    return M4depthAblationParameters(not args.no_DINL, not args.no_SNCV, not args.no_time_recurr,
+                                     not args.no_feature_normalization, not args.no_feature_subdivision,
+                                     not args.no_level_memory)                  # m4depth_options.py:96-98
+
+
 def synthetic_batches(args, rank, world, dev):
     lo, hi = D.shard_range(args.batch_size, rank, world)
+    h, w = args.height or 384, args.width or 1280
     for i in range(args.n_batches):
-        samples, cam = S.make_sequence(args.batch_size, args.seq_len, args.height, args.width, seed=args.seed + i)
+        samples, cam = S.make_sequence(args.batch_size, args.seq_len, h, w, seed=args.seed + i)
         data = {k: torch.from_numpy(np.stack([s[k][lo:hi] for s in samples], axis=1)).to(dev)
                 for k in ("depth", "RGB_im", "rot", "trans")}
         data["new_traj"] = torch.from_numpy(np.stack([s["new_traj"][lo:hi] for s in samples], axis=1))
         data["camera"] = {k: torch.from_numpy(v[lo:hi]).to(dev) for k, v in cam.items()}
         yield data
+
+
+def dataset_batches(args, usecase, rank, world, dev):
+    """Batches of one of the reference's datasets (main.py:67,77,120,152).  Returns (iterable, depth_type).
+    With several ranks the PER-RANK batch is batch_size / world and rank r takes every world-th batch
+    (sequences are independent); streaming evaluation is inherently sequential and stays single-rank."""
+    import json
+    from . import dataloaders as dl
+    if args.db_path_config is None or args.records_path is None:
+        raise SystemExit("--dataset %s needs --db_path_config and --records_path" % args.dataset)
+    cfg_dir = os.path.dirname(os.path.abspath(args.db_path_config))
+    with open(args.db_path_config) as fh:
+        roots = {k: (v if os.path.isabs(v) else os.path.normpath(os.path.join(cfg_dir, v)))
+                 for k, v in json.load(fh).items() if not k.startswith("_")}    # m4depth_options.py:88-94
+    loader = dl.get_loader(args.dataset)
+    settings = dl.DataloaderParameters(roots, args.records_path, args.db_seq_len, args.seq_len, not args.no_augmentation)
+    streaming = usecase in ("eval", "predict") and args.db_seq_len is None
+    if streaming and world > 1:
+        raise SystemExit("streaming evaluation (no --db_seq_len) is sequential: run it on one rank")
+    per_rank = 1 if streaming else D.shard_range(args.batch_size, rank, world)[1] - D.shard_range(args.batch_size, rank, world)[0]
+    kw = {"out_size": [args.height, args.width]} if args.height and args.width else {}
+    ds = loader.get_dataset(usecase, settings, batch_size=per_rank, device=dev, seed=args.seed, **kw)
+
+    def it():
+        for i, batch in enumerate(ds):
+            if i % world == rank:
+                yield batch
+    return it(), loader.depth_type
 
 
 def _train_dir(args):
@@ -91,7 +132,8 @@ def train(args, ablation, rank, world, dev):
     from . import training as TR
     from .metrics import RootMeanSquaredLogError
     torch.manual_seed(42)                                                       # tf.random.set_seed(42), main.py:76
-    model = M4Depth(nbre_levels=args.arch_depth, ablation_settings=ablation, is_training=True)
+    depth_type = {"kitti-raw": "velodyne"}.get(args.dataset, "map")              # the loader's depth_type (main.py:79)
+    model = M4Depth(depth_type=depth_type, nbre_levels=args.arch_depth, ablation_settings=ablation, is_training=True)
     model.load_numpy_weights(load_weights(args, ablation), dev)
     TR.set_trainable(model)
     opt = torch.optim.Adam(model.parameters(), lr=args.learning_rate, eps=1e-7)   # Keras Adam: epsilon 1e-7
@@ -115,13 +157,18 @@ def train(args, ablation, rank, world, dev):
         print("saved", path)
 
     step = step0
-    for data in synthetic_batches(args, rank, world, dev):
-        out = model.train_step(data, grad_sync=sync)
-        step += 1
-        if rank == 0:
-            print(f"step {step}: loss {float(out['loss']):.6f}  RMSE_log {float(out['RMSE_log']):.6f}")
-        if args.save_every and step % args.save_every == 0:
-            save(step)
+    for epoch in range(args.epochs if args.dataset != "synthetic" else 1):
+        if args.dataset == "synthetic":
+            batches = synthetic_batches(args, rank, world, dev)
+        else:
+            batches, _ = dataset_batches(args, args.mode, rank, world, dev)
+        for data in batches:
+            out = model.train_step(data, grad_sync=sync)
+            step += 1
+            if rank == 0:
+                print(f"step {step}: loss {float(out['loss']):.6f}  RMSE_log {float(out['RMSE_log']):.6f}")
+            if args.save_every and step % args.save_every == 0:
+                save(step)
     if not args.save_every or step % args.save_every != 0:
         save(step)
     return 0
@@ -132,17 +179,27 @@ def main(argv=None):
     rank, world, _, dev = D.init_from_env()
     if dev.type != "cuda":
         raise SystemExit("m4depth_amd.main needs a GPU: the hot path has no CPU fallback")
-    ablation = M4depthAblationParameters(**{f: not getattr(args, f"no_{f}") for f in M4depthAblationParameters._fields})
-    if args.mode == "train":
+    ablation = ablation_from_args(args)
+    if args.mode in ("train", "finetune"):
         return train(args, ablation, rank, world, dev)
     model = M4Depth(nbre_levels=args.arch_depth, ablation_settings=ablation)
     model.load_numpy_weights(load_weights(args, ablation), dev)
     model.compile(metrics=default_metrics())
     runner = None
     preds = []
-    for data in synthetic_batches(args, rank, world, dev):
+    if args.dataset == "synthetic":
+        batches = synthetic_batches(args, rank, world, dev)
+    else:
+        batches, _ = dataset_batches(args, "predict" if args.mode == "predict" else "eval", rank, world, dev)
+    for data in batches:
+        if data["RGB_im"].dim() == 4:            # streaming frame of a real dataset (db_seq_len None)
+            if args.mode == "predict":
+                preds.append(model.predict_step(data)["depth"].cpu().numpy())
+            else:
+                model.test_step(data)
+            continue
         if args.mode == "predict":
-            for t in range(args.seq_len):
+            for t in range(data["RGB_im"].shape[1]):
                 frame = {k: data[k][:, t] for k in ("depth", "RGB_im", "rot", "trans", "new_traj")}
                 frame["camera"] = data["camera"]
                 preds.append(model.predict_step(frame)["depth"].cpu().numpy())

@@ -165,3 +165,28 @@ def test_training_batches_are_augmented_and_consumable(dev, tmp_path):
         assert np.isfinite(float(out["loss"]))
         n += 1
     assert n == ds.cardinality() == 2
+
+
+def test_main_driver_on_a_dataset_in_the_reference_format(dev, tmp_path):
+    """python -m m4depth_amd.main --dataset=midair: train (checkpoint), eval on subsequences, streaming eval,
+    predict -- the four ways the reference's main.py consumes a dataloader."""
+    import json
+    import os
+    from m4depth_amd import main as MAIN
+    db, rec = make_fake_dataset(str(tmp_path), "midair", n_traj=2, n_frames=8, size=(64, 64))
+    cfg = os.path.join(str(tmp_path), "datasets_location.json")
+    with open(cfg, "w") as fh:
+        json.dump({"_comment": "relative to this file", "midair": "./db"}, fh)
+    ck = os.path.join(str(tmp_path), "ckpt")
+    common = ["--dataset", "midair", "--db_path_config", cfg, "--records_path", rec, "--arch_depth", "2",
+              "--height", "64", "--width", "64", "--ckpt_dir", ck]
+    assert MAIN.main(["--mode", "train", "--db_seq_len", "4", "--seq_len", "3", "--batch_size", "2", "--epochs", "2"] + common) == 0
+    assert os.path.isfile(os.path.join(ck, "train", "ckpt-4.npz"))                 # 2 batches x 2 epochs
+    assert MAIN.main(["--mode", "eval", "--db_seq_len", "4", "--batch_size", "2"] + common) == 0
+    perfs = np.loadtxt(os.path.join(ck, "perfs-midair.txt"))
+    assert perfs.shape == (7,) and np.all(np.isfinite(perfs))
+    assert MAIN.main(["--mode", "eval"] + common) == 0                              # streaming, one frame at a time
+    stream = np.loadtxt(os.path.join(ck, "perfs-midair.txt"))
+    assert np.all(np.isfinite(stream)) and not np.allclose(stream, perfs)
+    assert MAIN.main(["--mode", "predict"] + common) == 0
+    assert np.load(os.path.join(ck, "predictions.npy")).shape == (16, 64, 64, 1)
