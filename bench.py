@@ -212,7 +212,8 @@ def main():
                    "conv_backend": "stride-1 3x3 convs: hand-written fp32-MFMA implicit GEMM with fused bias+leaky-relu "
                                    "(libm4depth_hip.so); stride-2 / 3-channel encoder convs: MIOpen fp32",
                    "hot_path": "libm4depth_hip.so (HIP, gfx950)"},
-        "AbsRel": round(metrics[0], 6), "launch": "eager" if args.eager else "hipGraph replay of the sequence forward",
+        "AbsRel": round(metrics[0], 6), "launch": "eager" if args.eager else "hipGraph replay of the sequence forward; frames pipelined over the decoder "
+                                                  "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)",
     }
     if timer.events:
         summ = timer.summary()

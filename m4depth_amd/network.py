@@ -54,6 +54,14 @@ mfma_conv_encoder = _os.environ.get("M4D_MFMA_CONV_ENCODER", "1") == "1"
 # bench.py installs an object with ``run(name, level, thunk)`` here to bracket the
 # hand-written kernels with HIP events on the launch stream; None = no overhead.
 kernel_timer = None
+# Frame pipeline of the decoder: level l of frame t+1 depends on level l+1 of its own frame and on
+# level l of frame t only, so consecutive frames of a sequence run on two HIP streams as a
+# wavefront: the launch-latency-bound coarse levels of frame t+1 execute underneath the
+# chip-filling level-1/2 convolutions of frame t.  One stream per frame (up to this many), so that
+# dependencies only ever flow from stream t to stream t+1: ROCm 7.2's hipStreamEndCapture segfaults on a
+# capture in which two streams wait on each other's events alternately (tools/debug_multistream_capture.py).
+# 0 disables (single stream).
+level_pipeline_streams = int(_os.environ.get("M4D_LEVEL_PIPELINE", "8"))
 
 
 def _timed(name, level, thunk):
@@ -412,6 +420,15 @@ class DepthEstimatorPyramid(torch.nn.Module):
         # level-local intrinsics camera / 2**depth (:300-302): the same for every sequence step
         local_cameras = [{"f": camera["f"] / 2. ** (lvl + 1), "c": camera["c"] / 2. ** (lvl + 1)}
                          for lvl in range(n_lvls)]
+        dev = f_maps_pyrs[0][0].device
+        n_streams = level_pipeline_streams if (dev.type == "cuda" and not self.is_training and len(traj_samples) > 1
+                                               and not (kernel_timer is not None and getattr(kernel_timer, "enabled", True))) else 0
+        if n_streams >= 2:
+            frames = len(traj_samples)
+            if frames <= n_streams:
+                return self._forward_pipelined(f_maps_pyrs, traj_samples, local_cameras, frames)
+            if not torch.cuda.is_current_stream_capturing():      # eager: streams may be reused round-robin
+                return self._forward_pipelined(f_maps_pyrs, traj_samples, local_cameras, n_streams)
         for seq_i, (f_pyr_curr, sample) in enumerate(zip(f_maps_pyrs, traj_samples)):
             rot = sample['rot']
             trans = sample['trans']
@@ -432,6 +449,55 @@ class DepthEstimatorPyramid(torch.nn.Module):
                 d_est_curr = [est] if d_est_curr is None else d_est_curr + [est]
                 cnter -= 1.
             d_est_seq.append(d_est_curr[::-1])
+        return d_est_seq
+
+    def _forward_pipelined(self, f_maps_pyrs, traj_samples, local_cameras, n_streams):
+        """The same loop as a wavefront over (frame, level) on ``n_streams`` HIP streams: frame t runs on
+        stream t % n; before level l of frame t it waits for the event recorded after level l of frame
+        t-1 (the level's temporal memory).  Inside a stream the levels stay in coarse-to-fine order.
+        Works eagerly and under hipGraph capture (the side streams fork from / join the capturing one;
+        under capture the caller guarantees one stream per frame)."""
+        n_lvls = len(self.levels)
+        main = torch.cuda.current_stream()
+        if getattr(self, "_streams", None) is None or len(self._streams) < n_streams:
+            self._streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        streams = self._streams[:n_streams]
+        keep = []                                     # events must outlive a hipGraph capture they are part of
+        fork = torch.cuda.Event()
+        fork.record(main)
+        keep.append(fork)
+        for st in streams:
+            st.wait_event(fork)                       # encoder outputs / inputs are produced on the main stream
+        done = {}
+        d_est_seq = []
+        for seq_i, (f_pyr_curr, sample) in enumerate(zip(f_maps_pyrs, traj_samples)):
+            st = streams[seq_i % n_streams]
+            with torch.cuda.stream(st):
+                d_est_curr = None
+                for l in range(n_lvls):
+                    lvl = n_lvls - 1 - l
+                    if seq_i > 0:
+                        st.wait_event(done[(seq_i - 1, lvl)])
+                    d_est = None if d_est_curr is None else dict(d_est_curr[-1])
+                    est = self.levels[lvl](f_pyr_curr[lvl], d_est, sample['rot'], sample['trans'], local_cameras[lvl],
+                                           sample["new_traj"])
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    done[(seq_i, lvl)] = ev
+                    d_est_curr = [est] if d_est_curr is None else d_est_curr + [est]
+            d_est_seq.append(d_est_curr[::-1])
+        for st in streams:                            # join
+            ev = torch.cuda.Event()
+            ev.record(st)
+            main.wait_event(ev)
+            keep.append(ev)
+        keep.extend(done.values())
+        self._events = keep
+        if not torch.cuda.is_current_stream_capturing():
+            for ests in d_est_seq:                    # results are consumed on the main stream from here on
+                for est in ests:
+                    for t in est.values():
+                        t.record_stream(main)
         return d_est_seq
 
 

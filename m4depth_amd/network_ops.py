@@ -107,10 +107,13 @@ _ws_cache = {}
 
 
 def _workspace(key, nbytes, device):
-    ws = _ws_cache.get((key, device))
+    """Scratch buffer per (purpose, device, stream): kernels of different streams may run
+    concurrently (the level pipeline of DepthEstimatorPyramid), so they must not share scratch."""
+    k = (key, device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    ws = _ws_cache.get(k)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _ws_cache[(key, device)] = ws
+        _ws_cache[k] = ws
     return ws
 
 
