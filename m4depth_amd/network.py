@@ -62,6 +62,9 @@ kernel_timer = None
 # capture in which two streams wait on each other's events alternately (tools/debug_multistream_capture.py).
 # 0 disables (single stream).
 level_pipeline_streams = int(_os.environ.get("M4D_LEVEL_PIPELINE", "8"))
+# Encoding every frame on its own stream too (instead of one encoder pass batched over the frames, before the
+# decoder) was measured slightly slower (633 vs 643 frames/s at batch 1): the batched pass has 4x fewer launches.
+pipeline_encoder_per_frame = _os.environ.get("M4D_PIPELINE_ENCODER", "0") == "1"
 
 
 def _timed(name, level, thunk):
@@ -414,21 +417,31 @@ class DepthEstimatorPyramid(torch.nn.Module):
         self.is_training = settings["is_training"]
         self.is_unsupervised = False
 
-    def forward(self, f_maps_pyrs, traj_samples, camera, training=False):
+    def pipeline_streams_for(self, traj_samples, dev):
+        """Number of HIP streams the (frame, level) wavefront would use for this call; 0 = single stream."""
+        n_streams = level_pipeline_streams if (dev.type == "cuda" and not self.is_training and len(traj_samples) > 1
+                                               and not (kernel_timer is not None and getattr(kernel_timer, "enabled", True))) else 0
+        if n_streams < 2:
+            return 0
+        frames = len(traj_samples)
+        if frames <= n_streams:
+            return frames
+        return 0 if torch.cuda.is_current_stream_capturing() else n_streams      # eager: streams reused round-robin
+
+    def forward(self, f_maps_pyrs, traj_samples, camera, training=False, encoder=None):
+        """``f_maps_pyrs`` = per-frame feature pyramids, or None with ``encoder`` given: the pipelined path then
+        encodes every frame on that frame's stream (overlapping with the decoder of the frames before it)."""
         d_est_seq = []
         n_lvls = len(self.levels)
         # level-local intrinsics camera / 2**depth (:300-302): the same for every sequence step
         local_cameras = [{"f": camera["f"] / 2. ** (lvl + 1), "c": camera["c"] / 2. ** (lvl + 1)}
                          for lvl in range(n_lvls)]
-        dev = f_maps_pyrs[0][0].device
-        n_streams = level_pipeline_streams if (dev.type == "cuda" and not self.is_training and len(traj_samples) > 1
-                                               and not (kernel_timer is not None and getattr(kernel_timer, "enabled", True))) else 0
-        if n_streams >= 2:
-            frames = len(traj_samples)
-            if frames <= n_streams:
-                return self._forward_pipelined(f_maps_pyrs, traj_samples, local_cameras, frames)
-            if not torch.cuda.is_current_stream_capturing():      # eager: streams may be reused round-robin
-                return self._forward_pipelined(f_maps_pyrs, traj_samples, local_cameras, n_streams)
+        dev = camera["f"].device
+        n_pipe = self.pipeline_streams_for(traj_samples, dev)
+        if n_pipe >= 2:
+            return self._forward_pipelined(f_maps_pyrs, traj_samples, local_cameras, n_pipe, encoder)
+        if f_maps_pyrs is None:
+            f_maps_pyrs = [encoder(sample['RGB_im']) for sample in traj_samples]
         for seq_i, (f_pyr_curr, sample) in enumerate(zip(f_maps_pyrs, traj_samples)):
             rot = sample['rot']
             trans = sample['trans']
@@ -451,7 +464,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
             d_est_seq.append(d_est_curr[::-1])
         return d_est_seq
 
-    def _forward_pipelined(self, f_maps_pyrs, traj_samples, local_cameras, n_streams):
+    def _forward_pipelined(self, f_maps_pyrs, traj_samples, local_cameras, n_streams, encoder=None):
         """The same loop as a wavefront over (frame, level) on ``n_streams`` HIP streams: frame t runs on
         stream t % n; before level l of frame t it waits for the event recorded after level l of frame
         t-1 (the level's temporal memory).  Inside a stream the levels stay in coarse-to-fine order.
@@ -470,9 +483,11 @@ class DepthEstimatorPyramid(torch.nn.Module):
             st.wait_event(fork)                       # encoder outputs / inputs are produced on the main stream
         done = {}
         d_est_seq = []
-        for seq_i, (f_pyr_curr, sample) in enumerate(zip(f_maps_pyrs, traj_samples)):
+        for seq_i, sample in enumerate(traj_samples):
             st = streams[seq_i % n_streams]
             with torch.cuda.stream(st):
+                # frame t's encoder runs on frame t's stream: it overlaps with the decoder of the frames before it
+                f_pyr_curr = f_maps_pyrs[seq_i] if f_maps_pyrs is not None else encoder(sample['RGB_im'])
                 d_est_curr = None
                 for l in range(n_lvls):
                     lvl = n_lvls - 1 - l
@@ -583,13 +598,16 @@ class M4Depth(torch.nn.Module):
         # the batch axis (same per-sample arithmetic incl. the per-sample DINL statistics, a
         # quarter of the launches, larger MIOpen problems), then hand each frame its slice.
         n_fr = len(traj_samples)
-        if n_fr > 1 and all(s['RGB_im'].shape == traj_samples[0]['RGB_im'].shape for s in traj_samples):
+        dev = camera["f"].device
+        if pipeline_encoder_per_frame and self.d_estimator.pipeline_streams_for(traj_samples, dev) >= 2:
+            f_maps_pyrs = None                     # encoded per frame, on the frame's stream, inside the decoder pipeline
+        elif n_fr > 1 and all(s['RGB_im'].shape == traj_samples[0]['RGB_im'].shape for s in traj_samples):
             bsz = traj_samples[0]['RGB_im'].shape[0]
             stacked = self.encoder(torch.cat([s['RGB_im'] for s in traj_samples], dim=0))
             f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in stacked] for t in range(n_fr)]
         else:
             f_maps_pyrs = [self.encoder(sample['RGB_im']) for sample in traj_samples]
-        d_maps_pyrs = self.d_estimator(f_maps_pyrs, traj_samples, camera, training)
+        d_maps_pyrs = self.d_estimator(f_maps_pyrs, traj_samples, camera, training, encoder=self.encoder)
         self.last_estimates = d_maps_pyrs          # per step, per level {depth, parallax, other} (fine -> coarse)
         if training:
             return d_maps_pyrs
