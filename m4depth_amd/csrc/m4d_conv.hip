@@ -18,6 +18,7 @@
 //   ds_read_b128; rows are padded to 20 floats (conflict-free 16-byte reads).
 //   The global loads of the NEXT stage are issued into registers before the MFMAs of the
 //   current one (software pipeline), so one workgroup per SIMD already hides memory latency.
+#include <cstdlib>
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
 
@@ -32,6 +33,7 @@ struct ConvArgs {
   float slope;
   int ksplit, chunks_per_split;       // split-K (coarse pyramid levels): partial sums -> ws, reduced in order
   float* ws;
+  int ablate;                         // profiling only (M4D_CONV_ABLATE): 1 = no re-staging after the first stage, 2 = no MFMAs
 };
 
 constexpr int kTW = 16, kTH = 8;                    // output tile
@@ -43,8 +45,13 @@ constexpr int kKC = 16, kRS = 20;                   // chunk size, LDS row strid
 // DB = double-buffered weight stages (wide stride-1 variants): the next stage's weights are written
 // to the other LDS buffer BEFORE the MFMA burst of the current stage and its global loads are issued
 // two stages ahead, so a stage costs one barrier instead of two and the LDS writes hide under MFMAs.
-template <int NT, int TS, int STRIDE, bool DB>
-__global__ void __launch_bounds__(256)
+// MINB = workgroups per CU the register allocation must allow.  The widest variant needs 190 registers
+// (2 waves per SIMD) when left alone; bounded to 168 (accumulators in VGPRs, no scratch) a third workgroup per
+// CU fits and fills the barrier / staging bubbles of the other two: +8 % at batch 32 (9.84 -> 9.08 ms for the
+// level-1 128->128 layer), but at batch 1 the 960 workgroups of that layer then run as 768 + 192 (a 25 %-full
+// second round) and the launch gets slower -- so the host picks MINB = 3 only for grids of >= 4 full rounds.
+template <int NT, int TS, int STRIDE, bool DB, int MINB>
+__global__ void __launch_bounds__(256, MINB)
 conv3x3_mfma_kernel(const ConvArgs a) {
   constexpr int kHWT = (kTW - 1) * STRIDE + 3, kHHT = (kTH - 1) * STRIDE + 3, kHP = kHWT * kHHT;   // input halo: 18x10 / 33x17
   constexpr int BN = 32 * NT;
@@ -129,28 +136,66 @@ conv3x3_mfma_kernel(const ConvArgs a) {
   const float* a_lane = lds_a + (prow * STRIDE * kHWT + pcol * STRIDE) * kRS + kh * 8;
   const float* b_lane = lds_b + m * kRS + kh * 8;
 
+  // Operand fragments of one tap: 8 k-steps of A (this lane's pixel) and of B (this lane's output channel, NT tiles).
+  struct Frag { float av[8]; float bv[NT][8]; };
+  auto read_frag = [&](int s, int buf, int tl, Frag& f) {
+    const int ky = TS == 9 ? tl / 3 : s, kx = TS == 9 ? tl % 3 : tl;
+    const float* ap = a_lane + (ky * kHWT + kx) * kRS;
+    const float4 a0 = *reinterpret_cast<const float4*>(ap);
+    const float4 a1 = *reinterpret_cast<const float4*>(ap + 4);
+    f.av[0] = a0.x; f.av[1] = a0.y; f.av[2] = a0.z; f.av[3] = a0.w;
+    f.av[4] = a1.x; f.av[5] = a1.y; f.av[6] = a1.z; f.av[7] = a1.w;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float* bp = b_lane + buf * (TS * BN * kRS) + (tl * BN + nt * 32) * kRS;
+      const float4 b0 = *reinterpret_cast<const float4*>(bp);
+      const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
+      f.bv[nt][0] = b0.x; f.bv[nt][1] = b0.y; f.bv[nt][2] = b0.z; f.bv[nt][3] = b0.w;
+      f.bv[nt][4] = b1.x; f.bv[nt][5] = b1.y; f.bv[nt][6] = b1.z; f.bv[nt][7] = b1.w;
+    }
+  };
+  auto mfma_frag = [&](const Frag& f) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.av[ks], f.bv[nt][ks], acc[nt], 0, 0, 0);
+  };
+  // PIPE: the LDS reads of tap t+1 are issued before the MFMA burst of tap t (two fragment sets live), so the
+  // ~150-cycle LDS round trip of a tap hides under 8*NT MFMAs instead of stalling the wave between bursts.
+  constexpr bool PIPE = (MINB == 2) && (NT == 4) && (STRIDE == 1);
   auto mfma_stage = [&](int s, int buf) {           // TS taps x 8 k-steps x NT tiles
+    if constexpr (PIPE) {
+      Frag f[2];
+      read_frag(s, buf, 0, f[0]);
 #pragma unroll
-    for (int tl = 0; tl < TS; ++tl) {
-      const int ky = TS == 9 ? tl / 3 : s, kx = TS == 9 ? tl % 3 : tl;
-      const float* ap = a_lane + (ky * kHWT + kx) * kRS;
-      const float4 a0 = *reinterpret_cast<const float4*>(ap);
-      const float4 a1 = *reinterpret_cast<const float4*>(ap + 4);
-      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      float bv[NT][8];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float* bp = b_lane + buf * (TS * BN * kRS) + (tl * BN + nt * 32) * kRS;
-        const float4 b0 = *reinterpret_cast<const float4*>(bp);
-        const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
-        bv[nt][0] = b0.x; bv[nt][1] = b0.y; bv[nt][2] = b0.z; bv[nt][3] = b0.w;
-        bv[nt][4] = b1.x; bv[nt][5] = b1.y; bv[nt][6] = b1.z; bv[nt][7] = b1.w;
+      for (int tl = 0; tl < TS; ++tl) {
+        if (tl + 1 < TS) read_frag(s, buf, tl + 1, f[(tl + 1) & 1]);
+        mfma_frag(f[tl & 1]);
       }
+    } else {
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
+      for (int tl = 0; tl < TS; ++tl) {
+        const int ky = TS == 9 ? tl / 3 : s, kx = TS == 9 ? tl % 3 : tl;
+        const float* ap = a_lane + (ky * kHWT + kx) * kRS;
+        const float4 a0 = *reinterpret_cast<const float4*>(ap);
+        const float4 a1 = *reinterpret_cast<const float4*>(ap + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        float bv[NT][8];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[nt][ks], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          const float* bp = b_lane + buf * (TS * BN * kRS) + (tl * BN + nt * 32) * kRS;
+          const float4 b0 = *reinterpret_cast<const float4*>(bp);
+          const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
+          bv[nt][0] = b0.x; bv[nt][1] = b0.y; bv[nt][2] = b0.z; bv[nt][3] = b0.w;
+          bv[nt][4] = b1.x; bv[nt][5] = b1.y; bv[nt][6] = b1.z; bv[nt][7] = b1.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[nt][ks], acc[nt], 0, 0, 0);
+      }
     }
   };
 
@@ -181,13 +226,14 @@ conv3x3_mfma_kernel(const ConvArgs a) {
       const int s = st % SPC;
       const bool has_next = st + 1 < n_stages;
       const int nchunk = chunk_lo + (st + 1) / SPC, ns = (st + 1) % SPC;
-      if (has_next) {
+      const bool restage = has_next && !(a.ablate & 1);
+      if (restage) {
         load_b(nchunk, ns);
         if (ns == 0) load_a(nchunk);
       }
-      mfma_stage(s, 0);
+      if (!(a.ablate & 2)) mfma_stage(s, 0);
       __syncthreads();                               // all waves done with lds_b (and lds_a when ns == 0)
-      if (has_next) {
+      if (restage) {
         commit_b(0);
         if (ns == 0) commit_a();
       }
@@ -244,7 +290,7 @@ conv_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict_
   }
 }
 
-template <int NT, int TS, int STRIDE>
+template <int NT, int TS, int STRIDE, int MINB>
 void launch_conv(const ConvArgs& a, dim3 grid, hipStream_t s) {
   constexpr bool DB = false;   // double-buffered weight stages: implemented, bit-identical, measured 2-4 % SLOWER (b=1 and b=32) -> off
   constexpr int HP = ((kTW - 1) * STRIDE + 3) * ((kTH - 1) * STRIDE + 3);
@@ -252,20 +298,28 @@ void launch_conv(const ConvArgs& a, dim3 grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<NT, TS, STRIDE, DB>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<NT, TS, STRIDE, DB, MINB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<NT, TS, STRIDE, DB>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<NT, TS, STRIDE, DB, MINB>), grid, dim3(256), lds, s, a);
 }
 
 template <int STRIDE>
 void dispatch_conv(const ConvArgs& a, int nt, dim3 grid, hipStream_t s) {
+  const long long blocks = (long long)grid.x * grid.y * grid.z;
+  static long long occ3_min_blocks = -1;       // M4D_CONV_OCC3_MIN_BLOCKS: A/B switch for the 3-workgroups-per-CU variant
+  if (occ3_min_blocks < 0) { const char* e = getenv("M4D_CONV_OCC3_MIN_BLOCKS"); occ3_min_blocks = e ? atoll(e) : 4 * 768; }
+  // MINB pins each variant to the occupancy its natural register allocation had (2-3-3-4 workgroups per CU at
+  // stride 1, 1-2-2-2 at stride 2) -- an explicit bound of 1 would let the scheduler hoist loads until only one fits.
   switch (nt) {
-    case 4: launch_conv<4, 3, STRIDE>(a, grid, s); break;
-    case 3: launch_conv<3, 3, STRIDE>(a, grid, s); break;
-    case 2: launch_conv<2, STRIDE == 1 ? 9 : 3, STRIDE>(a, grid, s); break;
-    default: launch_conv<1, 9, STRIDE>(a, grid, s); break;
+    case 4:
+      if (STRIDE == 1 && blocks >= occ3_min_blocks) launch_conv<4, 3, STRIDE, STRIDE == 1 ? 3 : 1>(a, grid, s);
+      else launch_conv<4, 3, STRIDE, STRIDE == 1 ? 2 : 1>(a, grid, s);
+      break;
+    case 3: launch_conv<3, 3, STRIDE, STRIDE == 1 ? 3 : 2>(a, grid, s); break;
+    case 2: launch_conv<2, STRIDE == 1 ? 9 : 3, STRIDE, STRIDE == 1 ? 3 : 2>(a, grid, s); break;
+    default: launch_conv<1, 9, STRIDE, STRIDE == 1 ? 4 : 2>(a, grid, s); break;
   }
 }
 
@@ -296,6 +350,9 @@ extern "C" int m4d_conv3x3s_bias_act_ws(const float* x, const float* wp, const f
   ConvArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
   a.CoutPad = CoutPad; a.n_chunks = (Cin + kKC - 1) / kKC;
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("M4D_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
+  a.ablate = ablate;
   // TensorFlow 'SAME': out = ceil(in / stride), total pad = max((out-1)*stride + 3 - in, 0), before = total / 2
   a.oh = (h + stride - 1) / stride; a.ow = (w + stride - 1) / stride;
   const int tph = (a.oh - 1) * stride + 3 - h, tpw = (a.ow - 1) * stride + 3 - w;
