@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--eager", action="store_true", help="do not replay the step from a hipGraph")
+    p.add_argument("--launch", default="graph", choices=["tasks", "graph"],
+                   help="tasks: one hipGraph per (frame, level) task on one stream per frame; graph: one hipGraph per step")
     return p.parse_args()
 
 
@@ -164,7 +166,7 @@ def main():
         model.test_step(data)
     runner = None
     if not args.eager:
-        runner = net.GraphedSequence(model, data)
+        runner = net.TaskGraphSequence(model, data) if args.launch == "tasks" and args.seq_len > 1 else net.GraphedSequence(model, data)
         step = lambda: model.graphed_test_step(data, runner)
         for _ in range(args.warmup):
             step()

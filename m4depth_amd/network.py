@@ -65,6 +65,8 @@ level_pipeline_streams = int(_os.environ.get("M4D_LEVEL_PIPELINE", "8"))
 # Encoding every frame on its own stream too (instead of one encoder pass batched over the frames, before the
 # decoder) was measured slightly slower (633 vs 643 frames/s at batch 1): the batched pass has 4x fewer launches.
 pipeline_encoder_per_frame = _os.environ.get("M4D_PIPELINE_ENCODER", "0") == "1"
+# Encoder in two batches instead: frames [0, split) before the decoder, frames [split, T) on frame `split`'s stream.
+pipeline_encoder_split = int(_os.environ.get("M4D_PIPELINE_ENCODER_SPLIT", "2"))
 
 
 def _timed(name, level, thunk):
@@ -434,9 +436,18 @@ class DepthEstimatorPyramid(torch.nn.Module):
         d_est_seq = []
         n_lvls = len(self.levels)
         # level-local intrinsics camera / 2**depth (:300-302): the same for every sequence step
-        local_cameras = [{"f": camera["f"] / 2. ** (lvl + 1), "c": camera["c"] / 2. ** (lvl + 1)}
-                         for lvl in range(n_lvls)]
         dev = camera["f"].device
+        if isinstance(camera["f"], torch.Tensor) and camera["f"].is_cuda:
+            # all levels in two launches instead of 2 * n_lvls: x * 2^-k is exactly x / 2^k in float32
+            sc = getattr(self, "_cam_scales", None)
+            if sc is None or sc.device != dev or sc.shape[0] != n_lvls:
+                sc = torch.tensor([2.0 ** -(lvl + 1) for lvl in range(n_lvls)], dtype=torch.float32, device=dev).reshape(-1, 1, 1)
+                self._cam_scales = sc
+            f_all, c_all = camera["f"].unsqueeze(0) * sc, camera["c"].unsqueeze(0) * sc
+            local_cameras = [{"f": f_all[lvl], "c": c_all[lvl]} for lvl in range(n_lvls)]
+        else:
+            local_cameras = [{"f": camera["f"] / 2. ** (lvl + 1), "c": camera["c"] / 2. ** (lvl + 1)}
+                             for lvl in range(n_lvls)]
         n_pipe = self.pipeline_streams_for(traj_samples, dev)
         if n_pipe >= 2:
             return self._forward_pipelined(f_maps_pyrs, traj_samples, local_cameras, n_pipe, encoder)
@@ -482,25 +493,47 @@ class DepthEstimatorPyramid(torch.nn.Module):
         for st in streams:
             st.wait_event(fork)                       # encoder outputs / inputs are produced on the main stream
         done = {}
-        d_est_seq = []
-        for seq_i, sample in enumerate(traj_samples):
-            st = streams[seq_i % n_streams]
-            with torch.cuda.stream(st):
-                # frame t's encoder runs on frame t's stream: it overlaps with the decoder of the frames before it
-                f_pyr_curr = f_maps_pyrs[seq_i] if f_maps_pyrs is not None else encoder(sample['RGB_im'])
-                d_est_curr = None
-                for l in range(n_lvls):
-                    lvl = n_lvls - 1 - l
+        late_encoder = None
+        n_fr = len(traj_samples)
+        f_pyrs = [None] * n_fr
+        d_est = [None] * n_fr                         # per frame: estimates so far, coarse -> fine
+        # Issue order = anti-diagonals of the (frame, level) grid: level l of frame t right after level l of frame
+        # t-1.  Every stream still sees its own frame coarse -> fine, but the launch (and hipGraph node) order puts
+        # the next frame's coarse levels ahead of the current frame's fine ones.
+        for diag in range(n_fr + n_lvls - 1):
+            for seq_i in range(max(0, diag - n_lvls + 1), min(n_fr, diag + 1)):
+                l = diag - seq_i
+                lvl = n_lvls - 1 - l
+                sample = traj_samples[seq_i]
+                st = streams[seq_i % n_streams]
+                with torch.cuda.stream(st):
+                    if l == 0:
+                        if f_maps_pyrs is None:          # per-frame encoder on the frame's own stream
+                            f_pyrs[seq_i] = encoder(sample['RGB_im'])
+                        elif f_maps_pyrs[seq_i] is not None:
+                            f_pyrs[seq_i] = f_maps_pyrs[seq_i]
+                        elif f_pyrs[seq_i] is None:      # first frame of the late encoder batch: encode all remaining frames here
+                            rest = [i for i in range(seq_i, n_fr) if f_maps_pyrs[i] is None]
+                            bsz = sample['RGB_im'].shape[0]
+                            tail = encoder(torch.cat([traj_samples[i]['RGB_im'] for i in rest], dim=0))
+                            for j, i in enumerate(rest):
+                                f_pyrs[i] = [lvl[j * bsz:(j + 1) * bsz] for lvl in tail]
+                            enc_done = torch.cuda.Event()
+                            enc_done.record(st)
+                            keep.append(enc_done)
+                            late_encoder = (seq_i, enc_done)
+                        else:                            # a later frame of that batch: its features come from another stream
+                            st.wait_event(late_encoder[1])
                     if seq_i > 0:
                         st.wait_event(done[(seq_i - 1, lvl)])
-                    d_est = None if d_est_curr is None else dict(d_est_curr[-1])
-                    est = self.levels[lvl](f_pyr_curr[lvl], d_est, sample['rot'], sample['trans'], local_cameras[lvl],
+                    prev = None if d_est[seq_i] is None else dict(d_est[seq_i][-1])
+                    est = self.levels[lvl](f_pyrs[seq_i][lvl], prev, sample['rot'], sample['trans'], local_cameras[lvl],
                                            sample["new_traj"])
                     ev = torch.cuda.Event()
                     ev.record(st)
                     done[(seq_i, lvl)] = ev
-                    d_est_curr = [est] if d_est_curr is None else d_est_curr + [est]
-            d_est_seq.append(d_est_curr[::-1])
+                    d_est[seq_i] = [est] if d_est[seq_i] is None else d_est[seq_i] + [est]
+        d_est_seq = [ests[::-1] for ests in d_est]
         for st in streams:                            # join
             ev = torch.cuda.Event()
             ev.record(st)
@@ -599,9 +632,18 @@ class M4Depth(torch.nn.Module):
         # quarter of the launches, larger MIOpen problems), then hand each frame its slice.
         n_fr = len(traj_samples)
         dev = camera["f"].device
+        same_shape = all(s['RGB_im'].shape == traj_samples[0]['RGB_im'].shape for s in traj_samples)
         if pipeline_encoder_per_frame and self.d_estimator.pipeline_streams_for(traj_samples, dev) >= 2:
             f_maps_pyrs = None                     # encoded per frame, on the frame's stream, inside the decoder pipeline
-        elif n_fr > 1 and all(s['RGB_im'].shape == traj_samples[0]['RGB_im'].shape for s in traj_samples):
+        elif pipeline_encoder_split > 0 and n_fr > pipeline_encoder_split and same_shape \
+                and self.d_estimator.pipeline_streams_for(traj_samples, dev) >= 2:
+            # frames [0, split) now, the rest on the stream of frame `split`: the second encoder batch runs underneath
+            # the (launch-latency-bound) coarse levels of the first full frame instead of in front of them
+            k = pipeline_encoder_split
+            bsz = traj_samples[0]['RGB_im'].shape[0]
+            head = self.encoder(torch.cat([s['RGB_im'] for s in traj_samples[:k]], dim=0))
+            f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in head] for t in range(k)] + [None] * (n_fr - k)
+        elif n_fr > 1 and same_shape:
             bsz = traj_samples[0]['RGB_im'].shape[0]
             stacked = self.encoder(torch.cat([s['RGB_im'] for s in traj_samples], dim=0))
             f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in stacked] for t in range(n_fr)]
@@ -744,4 +786,124 @@ class GraphedSequence:
                 if data["camera"][k].data_ptr() != self.camera[k].data_ptr():
                     self.camera[k].copy_(data["camera"][k], non_blocking=True)
         self.graph.replay()
+        return self.depth
+
+
+class TaskGraphSequence:
+    """A sequence forward as ONE hipGraph PER TASK -- the batched encoder, every (frame, level) of the decoder, the
+    final upsample -- replayed by the host on one real HIP stream per frame, ordered by events.
+
+    Why not one big graph (``GraphedSequence``): captured from several streams it has the right dependencies, but
+    ROCm 7.2's graph executor starts the next frame's coarse levels only when the current frame reaches level 1
+    (profiles/r01_timeline_b1_pipelined.txt), so most of the possible overlap is lost.  With the tasks as separate
+    graphs the (frame, level) wavefront runs on real streams: level l of frame t+1 starts the moment level l of
+    frame t has signalled its event, and later frames' streams get a higher priority so that their small kernels
+    slip into the workgroup slots a chip-filling level-1 convolution of the frame before frees.  Per step the host
+    issues ~30 graph launches and ~50 event operations (< 0.5 ms) instead of ~700 kernel launches.
+
+    Streams share nothing but the level state buffers (event ordered); every frame-stream captures into its own
+    memory pool, so tasks that run concurrently never alias scratch memory."""
+
+    def __init__(self, model, example, warmup=2, use_priorities=False):
+        # MEASURED (tools/debug_taskgraph.py, batch 1): 6.45 ms/step, the same as the single multi-stream graph
+        # (6.25 ms) -- the per-task event timeline shows the wavefront overlapping exactly as designed, the step is
+        # simply throughput-bound by then.  With stream priorities it is 10.7 ms/step (high-priority queues starve the
+        # chip-filling convolutions), hence use_priorities=False.  Kept as the instrument that produced that timeline.
+        self.model = model
+        self.new_traj = example["new_traj"].clone() if isinstance(example["new_traj"], torch.Tensor) else example["new_traj"]
+        self.static = {k: example[k].clone() for k in ("RGB_im", "rot", "trans")}
+        self.camera = {k: v.clone() for k, v in example["camera"].items()}
+        T = self.seq_len = self.static["RGB_im"].shape[1]
+        pyr = model.d_estimator
+        L = self.n_lvls = len(pyr.levels)
+        if pyr.is_training:
+            raise ValueError("TaskGraphSequence replays the inference path")
+        # later frames = higher priority (numerically lower); clamp to what the device offers
+        def make_stream(t):
+            if use_priorities:
+                for prio in (min(0, 1 - t), -1 if t >= 2 else 0, 0):
+                    try:
+                        return torch.cuda.Stream(priority=prio)
+                    except Exception:
+                        continue
+            return torch.cuda.Stream()
+        self.streams = [make_stream(t) for t in range(T)]
+        self.main = torch.cuda.Stream()
+        pyr._streams = self.streams                      # the eager warm-up allocates per-stream scratch on the same streams
+        self.main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.main):
+            for _ in range(warmup):
+                model([self._samples(), self.camera])
+        torch.cuda.synchronize()
+
+        nt = torch.unbind(self.new_traj, dim=1) if isinstance(self.new_traj, torch.Tensor) else list(self.new_traj.T)
+        bsz = self.static["RGB_im"].shape[0]
+        # -- task 0: encoder, batched over the frames, + the level-local intrinsics
+        self.g_enc = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_enc, stream=self.main):
+            stacked = model.encoder(torch.cat([self.static["RGB_im"][:, t] for t in range(T)], dim=0))
+            self.f_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in stacked] for t in range(T)]
+            self.cams = [{"f": self.camera["f"] / 2. ** (lvl + 1), "c": self.camera["c"] / 2. ** (lvl + 1)} for lvl in range(L)]
+        # -- one task per (frame, level), captured in wavefront order on the frame's stream and pool
+        pools = [torch.cuda.graph_pool_handle() for _ in range(T)]
+        self.tasks = {}
+        ests = [None] * T
+        for diag in range(T + L - 1):
+            for t in range(max(0, diag - L + 1), min(T, diag + 1)):
+                l = diag - t
+                lvl = L - 1 - l
+                g = torch.cuda.CUDAGraph()
+                prev = None if ests[t] is None else dict(ests[t][-1])
+                with torch.cuda.graph(g, pool=pools[t], stream=self.streams[t]):
+                    est = pyr.levels[lvl](self.f_pyrs[t][lvl], prev, self.static["rot"][:, t], self.static["trans"][:, t],
+                                          self.cams[lvl], nt[t])
+                ests[t] = [est] if ests[t] is None else ests[t] + [est]
+                self.tasks[(t, lvl)] = g
+        self.estimates = [e[::-1] for e in ests]
+        h, w = self.static["RGB_im"].shape[2:4]
+        self.g_out = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_out, stream=self.main):
+            self.depth = nops.resize_nearest(self.estimates[-1][0]["depth"], h, w)
+        self.ev_enc = torch.cuda.Event()
+        self.ev = {k: torch.cuda.Event() for k in self.tasks}
+        model.last_estimates = self.estimates
+        torch.cuda.synchronize()
+
+    def _samples(self):
+        nt = torch.unbind(self.new_traj, dim=1) if isinstance(self.new_traj, torch.Tensor) else list(self.new_traj.T)
+        return [{"RGB_im": self.static["RGB_im"][:, t], "rot": self.static["rot"][:, t],
+                 "trans": self.static["trans"][:, t], "new_traj": nt[t]} for t in range(self.seq_len)]
+
+    def __call__(self, data=None):
+        caller = torch.cuda.current_stream()
+        main = self.main
+        main.wait_stream(caller)
+        with torch.cuda.stream(main):
+            if data is not None:
+                for k in self.static:
+                    if data[k].data_ptr() != self.static[k].data_ptr():
+                        self.static[k].copy_(data[k], non_blocking=True)
+                for k in self.camera:
+                    if data["camera"][k].data_ptr() != self.camera[k].data_ptr():
+                        self.camera[k].copy_(data["camera"][k], non_blocking=True)
+            self.g_enc.replay()
+            self.ev_enc.record(main)
+        T, L = self.seq_len, self.n_lvls
+        for st in self.streams:
+            st.wait_event(self.ev_enc)
+        for diag in range(T + L - 1):
+            for t in range(max(0, diag - L + 1), min(T, diag + 1)):
+                lvl = L - 1 - (diag - t)
+                st = self.streams[t]
+                with torch.cuda.stream(st):
+                    if t > 0:
+                        st.wait_event(self.ev[(t - 1, lvl)])
+                    self.tasks[(t, lvl)].replay()
+                    self.ev[(t, lvl)].record(st)
+        for t in range(T):
+            main.wait_event(self.ev[(t, 0)])              # join: the finest level is every stream's last task
+        with torch.cuda.stream(main):
+            self.g_out.replay()
+        caller.wait_stream(main)
+        self.model.step_counter += 1
         return self.depth
