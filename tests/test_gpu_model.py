@@ -270,3 +270,38 @@ def test_model_large_search_windows(dev):
     fo, fg = omodel.levels[lc].last_f_input, npy(model.d_estimator.levels[lc].last_f_input)
     err = np.abs(fg - fo).max()
     assert err < 1e-4, err
+
+
+def test_frame_pipeline_is_bitwise_neutral(dev):
+    """The (frame, level) wavefront on one stream per frame -- eager, round-robin over 8 streams for a
+    10-frame sequence, and captured in the hipGraph for 4 frames -- gives bit-identical depth to the
+    single-stream loop (deterministic mode: no MIOpen kernel in the model)."""
+    from m4depth_amd import network as net
+    old = (net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels, net.level_pipeline_streams)
+    net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels = True, 1, 1
+    try:
+        L, H, Wd, b = 3, 64, 96, 2
+        W = S.init_weights(L, seed=6)
+        for T in (4, 10):
+            samples, cam = S.make_sequence(b, T, H, Wd, seed=100 + T)
+            ds, dc = to_dev(samples, dev), to_dev(cam, dev)
+            net.level_pipeline_streams = 0
+            model = _build(dev, L, 4, 3, W)
+            ref = model([ds, dc])["depth"].clone()
+            net.level_pipeline_streams = 8
+            model = _build(dev, L, 4, 3, W)
+            assert model.d_estimator.pipeline_streams_for(ds, dev) == min(T, 8)
+            got = model([ds, dc])["depth"].clone()
+            assert torch.equal(ref, got), f"eager pipeline differs at T={T}"
+            if T == 4:
+                data = {k: torch.stack([s[k] for s in ds], dim=1) for k in ("depth", "RGB_im", "rot", "trans")}
+                data["new_traj"] = torch.stack([torch.from_numpy(s["new_traj"]) for s in samples], dim=1)
+                data["camera"] = dc
+                model = _build(dev, L, 4, 3, W)
+                runner = net.GraphedSequence(model, data)
+                for _ in range(2):
+                    out = runner(data).clone()
+                    torch.cuda.synchronize()
+                    assert torch.equal(ref, out), "captured pipeline differs"
+    finally:
+        net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels, net.level_pipeline_streams = old
