@@ -312,21 +312,14 @@ void dispatch_conv(const ConvArgs& a, int nt, dim3 grid, hipStream_t s) {
   if (occ3_min_blocks < 0) { const char* e = getenv("M4D_CONV_OCC3_MIN_BLOCKS"); occ3_min_blocks = e ? atoll(e) : 4 * 768; }
   // MINB pins each variant to the occupancy its natural register allocation had (2-3-3-4 workgroups per CU at
   // stride 1, 1-2-2-2 at stride 2) -- an explicit bound of 1 would let the scheduler hoist loads until only one fits.
-  static long long occ2_max_blocks = -1;       // M4D_CONV_OCC2_MAX_BLOCKS: small grids of the 96/64-wide variants at 2 per CU
-  if (occ2_max_blocks < 0) { const char* e = getenv("M4D_CONV_OCC2_MAX_BLOCKS"); occ2_max_blocks = e ? atoll(e) : 0; }
   switch (nt) {
     case 4:
       if (STRIDE == 1 && blocks >= occ3_min_blocks) launch_conv<4, 3, STRIDE, STRIDE == 1 ? 3 : 1>(a, grid, s);
       else launch_conv<4, 3, STRIDE, STRIDE == 1 ? 2 : 1>(a, grid, s);
       break;
-    case 3:
-      if (STRIDE == 1 && blocks < occ2_max_blocks) launch_conv<3, 3, STRIDE, 2>(a, grid, s);
-      else launch_conv<3, 3, STRIDE, STRIDE == 1 ? 3 : 2>(a, grid, s);
-      break;
-    case 2:
-      if (STRIDE == 1 && blocks < occ2_max_blocks) launch_conv<2, STRIDE == 1 ? 9 : 3, STRIDE, 2>(a, grid, s);
-      else launch_conv<2, STRIDE == 1 ? 9 : 3, STRIDE, STRIDE == 1 ? 3 : 2>(a, grid, s);
-      break;
+    // (2 workgroups per CU for small grids of the 96/64-wide variants was tried too: no measurable difference)
+    case 3: launch_conv<3, 3, STRIDE, STRIDE == 1 ? 3 : 2>(a, grid, s); break;
+    case 2: launch_conv<2, STRIDE == 1 ? 9 : 3, STRIDE, STRIDE == 1 ? 3 : 2>(a, grid, s); break;
     default: launch_conv<1, 9, STRIDE, STRIDE == 1 ? 4 : 2>(a, grid, s); break;
   }
 }

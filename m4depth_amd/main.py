@@ -44,6 +44,9 @@ def build_parser():
     p.add_argument("--height", type=int, default=None, help="frame height (default: 384 synthetic, else the dataset's)")
     p.add_argument("--width", type=int, default=None)
     p.add_argument("--ckpt_dir", default="ckpt")
+    p.add_argument("--tf_checkpoint", default=None,
+                   help="TensorFlow checkpoint of the reference model (prefix, or a directory holding a 'checkpoint' state "
+                        "file, e.g. pretrained_weights/midair): used instead of <ckpt_dir>/train for the initial weights")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--graph", action="store_true", help="replay the sequence forward from a hipGraph")
     p.add_argument("--learning_rate", type=float, default=1e-4, help="Adam step size (main.py:88)")
@@ -117,6 +120,13 @@ def latest_checkpoint(args):
 def load_weights(args, ablation):
     """Weights for eval / predict: the latest training checkpoint when there is one (callbacks.py:104-111),
     otherwise the seeded random initialisation."""
+    if args.tf_checkpoint:
+        from . import tf_checkpoint as TC
+        prefix = TC.latest_checkpoint(args.tf_checkpoint) if os.path.isdir(args.tf_checkpoint) else args.tf_checkpoint
+        if prefix is None:
+            raise SystemExit("no TensorFlow checkpoint found in %s" % args.tf_checkpoint)
+        print("Restoring weights from TensorFlow checkpoint %s" % prefix)
+        return TC.load_m4depth_weights(prefix, args.arch_depth)
     ck = latest_checkpoint(args)
     if ck is not None:
         print("Restoring weights from %s" % ck[0])

@@ -590,6 +590,17 @@ class M4Depth(torch.nn.Module):
                 conv.load_hwio(weights[f"lvl.{lvl.lvl_depth}.conv.{i}.kernel"], weights[f"lvl.{lvl.lvl_depth}.conv.{i}.bias"], device)
         return self
 
+    def load_tf_checkpoint(self, prefix_or_dir, device):
+        """Weights from a TensorFlow object-based checkpoint of the reference model (callbacks.py:98-111,
+        the published pretrained weights): a checkpoint prefix, or a directory with a ``checkpoint`` state file."""
+        from . import tf_checkpoint as TC
+        prefix = prefix_or_dir
+        if _os.path.isdir(prefix_or_dir):
+            prefix = TC.latest_checkpoint(prefix_or_dir)
+            if prefix is None:
+                raise FileNotFoundError(f"no checkpoint state in {prefix_or_dir}")
+        return self.load_numpy_weights(TC.load_m4depth_weights(prefix, self.model_settings["nbre_lvls"]), device)
+
     def numpy_weights(self):
         """Inverse of ``load_numpy_weights``: the dict of TF-layout (HWIO) arrays, e.g. for a checkpoint."""
         def hwio(conv):
