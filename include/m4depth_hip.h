@@ -138,6 +138,13 @@ void m4d_dscv_set_stamps(unsigned long long* device_buffer);
 int m4d_sncv_fwd(const float* c1, const float* c2, int b, int h, int w, int C, int search_range,
                  int dilation_rate, int nbre_cuts, float* out, int out_stride, void* stream);
 
+/* The same stride-1 layer by Winograd F(2x2,3x3) on the fp32 matrix cores: 2.25x fewer multiply-adds, result
+ * equal to the direct convolution up to float32 rounding (the transforms only add and halve).  wu = the filter
+ * transformed on the host, U = G g G^T, packed [ceil(Cin/16)][16 positions][CoutPad][16 channels]
+ * (network_ops.pack_conv_weights_winograd); CoutPad a multiple of 32.  Deterministic. */
+int m4d_conv3x3_wino_bias_act(const float* x, const float* wu, const float* bias, int b, int h, int w,
+                              int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
+
 /* ---- gradients of the cost volumes (train_step, m4depth_network.py:371-399) ------ */
 
 /* Backward of m4d_dscv_fwd: what tf.GradientTape derives from depth_operations.py:224-281.

@@ -1,0 +1,274 @@
+// 3x3 stride-1 'SAME' convolution + bias + leaky_relu, Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+// The wide refiner / encoder layers are MFMA-bound (m4d_conv.hip runs them at 0.6-0.8 of the 157 TFLOP/s
+// fp32 peak), so the remaining lever is arithmetic: F(2x2,3x3) computes a 2x2 output tile from a 4x4 input
+// tile with 16 multiplies per (input channel, output channel) instead of 36 -- 2.25x fewer MFMA flops for the
+// same result up to float32 rounding (measured error 1.5-1.8x that of direct float32 summation; the
+// transforms only add and halve: B^T, A^T have entries in {0, +-1}, G in {0, +-1/2, 1}).
+//
+//   V = B^T d B        (4x4 input tile d, per input channel)          -- computed in the kernel, through LDS
+//   U = G g G^T        (3x3 filter g, per (cin, cout))                -- computed once on the host (pack)
+//   M[p] = sum_c V[p][c] * U[p][c]          for the 16 positions p    -- 16 independent GEMMs on MFMA
+//   Y = A^T M A        (2x2 outputs) + bias, leaky_relu               -- epilogue, through LDS
+//
+// Workgroup = 4 waves = one 16x8 output tile (32 Winograd tiles = one MFMA M-tile) x BN = 32*NT output
+// channels.  Wave w owns positions 4w..4w+3: it needs every tile (A operand: V, shared through LDS) but its
+// own slice of U (B operand), which therefore goes global -> registers directly (L2-resident, prefetched
+// one position ahead) and never occupies LDS.  K is walked in chunks of 16 input channels: raw halo
+// (18x10 pixels) -> LDS, transform (one (tile, channel pair) per lane) -> V in LDS, 4 positions x 8 k-steps
+// x NT MFMAs per wave.  After the K loop the 16 positions of a (tile, cout) live in four waves; they meet in
+// LDS (two passes of 16 tiles per N-tile) for the output transform.
+// Deterministic: fixed summation order, no atomics.
+#include <cstdlib>
+#include "m4d_common.h"
+#include "../../include/m4depth_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WinoArgs {
+  const float* x; const float* wu; const float* bias; float* out;
+  int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
+  float slope;
+  int ablate;      // profiling only (M4D_WINO_ABLATE): 1 = weights loaded once, 2 = no MFMAs, 4 = no input transform, 8 = no epilogue
+};
+
+constexpr int kTW = 16, kTH = 8;                 // output tile (pixels)
+constexpr int kHW = kTW + 2, kHH = kTH + 2;      // input halo 18 x 10
+constexpr int kHP = kHW * kHH;                   // 180 halo pixels
+constexpr int kKC = 16;                          // input channels per chunk
+constexpr int kRS = 20;                          // LDS row stride (floats): 16 + 4 pad, conflict-free 16-byte reads
+constexpr int kNT32 = 32;                        // Winograd tiles per workgroup (8 x 4) = one MFMA M-tile
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2)
+conv3x3_wino_kernel(const WinoArgs a) {
+  constexpr int BN = 32 * NT;
+  constexpr int A_F2 = kHP * (kKC / 2);          // float2 loads per halo chunk (1440)
+  constexpr int A_PER = (A_F2 + 255) / 256;      // 6
+  extern __shared__ __align__(16) float lds[];
+  float* raw = lds;                              // [kHP][kRS]           14.4 KB
+  float* V = lds + kHP * kRS;                    // [16][32][kRS]        40 KB   (epilogue: M[16][16][32+1] reuses lds)
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // XCD-aware order: workgroup L runs on XCD L % 8; give every XCD a contiguous band of tiles and put the N-groups of
+  // a tile next to each other inside it, so that a halo (and its neighbours') is fetched into that XCD's L2 once.
+  const int n_tiles = a.tiles_x * a.tiles_y, n_groups = a.CoutPad / BN;
+  int tile, ng;
+  {
+    const int L = blockIdx.x;
+    if ((n_tiles & 7) == 0) {
+      const int xcd = L & 7, idx = L >> 3;
+      tile = xcd * (n_tiles >> 3) + idx / n_groups;
+      ng = idx % n_groups;
+    } else {
+      tile = L / n_groups;
+      ng = L % n_groups;
+    }
+  }
+  const int tile_y = (tile / a.tiles_x) * kTH, tile_x = (tile % a.tiles_x) * kTW;
+  const int n0 = ng * BN;
+  const int bi = blockIdx.y;
+  const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
+
+  // Raw halo of the next chunk: one register set, issued right after the commit of the current one so that the loads fly
+  // during the transform AND the MFMA phase.  (Tried: two register sets / two chunks ahead -- spills at 256 VGPRs, 2x slower;
+  // 32 channels per round trip -- 256 VGPRs, 8 % slower.)
+  float2 ra[A_PER];
+  auto load_raw = [&](int chunk) {
+    const int c0 = chunk * kKC;
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const int idx = u * 256 + t;
+      const int hp = idx >> 3, k2 = (idx & 7) * 2;
+      const int gy = tile_y - 1 + hp / kHW, gx = tile_x - 1 + hp % kHW;
+      ra[u] = make_float2(0.f, 0.f);
+      if (idx < A_F2 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && c0 + k2 < a.Cin) {
+        const float* px = ximg + ((long long)gy * a.w + gx) * a.Cin + c0 + k2;
+        if (a.Cin & 1) { ra[u].x = px[0]; if (c0 + k2 + 1 < a.Cin) ra[u].y = px[1]; }
+        else ra[u] = *reinterpret_cast<const float2*>(px);
+      }
+    }
+  };
+  auto commit_raw = [&]() {
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const int idx = u * 256 + t;
+      if (idx < A_F2) *reinterpret_cast<float2*>(raw + (idx >> 3) * kRS + (idx & 7) * 2) = ra[u];
+    }
+  };
+  // input transform: V[p][tile][c] = (B^T d B)[p]; 32 tiles x 16 channels = 512 items, two per lane (item = (tile, channel),
+  // one after the other: 24 live values instead of 48 with channel pairs -- the register file is the scarce resource here).
+  // Column transform first, row by row as the inputs arrive.
+  auto transform = [&]() {
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+      const int item = it * 256 + t;
+      const int tt = item >> 4, ch = item & 15;
+      const int tty = tt >> 3, ttx = tt & 7;
+      float c[4][4];                               // c = d B
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* rp = raw + ((2 * tty + i) * kHW + 2 * ttx) * kRS + ch;
+        const float d0 = rp[0], d1 = rp[kRS], d2 = rp[2 * kRS], d3 = rp[3 * kRS];
+        c[i][0] = d0 - d2; c[i][1] = d1 + d2; c[i][2] = d2 - d1; c[i][3] = d1 - d3;
+      }
+      float* vp = V + tt * kRS + ch;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                // rows: B^T (d B); position p = i * 4 + j
+        vp[(0 + j) * kNT32 * kRS] = c[0][j] - c[2][j];
+        vp[(4 + j) * kNT32 * kRS] = c[1][j] + c[2][j];
+        vp[(8 + j) * kNT32 * kRS] = c[2][j] - c[1][j];
+        vp[(12 + j) * kNT32 * kRS] = c[1][j] - c[3][j];
+      }
+    }
+  };
+
+  f32x16 acc[4][NT];
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pi][nt][r] = 0.f;
+
+  const int m = lane & 31, kh = lane >> 5;
+  // B operand: wu[chunk][pos][CoutPad][16] (natural channel order); this lane reads channels 8kh..8kh+7 of cout n0+nt*32+m
+  const float* wlane = a.wu + ((long long)(4 * wave) * a.CoutPad + n0 + m) * kKC + kh * 8;
+  const long long w_pos = (long long)a.CoutPad * kKC;            // stride between positions
+  const long long w_chunk = 16 * w_pos;
+  const float* vlane = V + ((4 * wave) * kNT32 + m) * kRS + kh * 8;
+
+  // weights: ring of 4 buffers of one (position, N-tile) fragment each (2 float4), walked in the order the MFMAs use
+  // them and loaded 3 fragments ahead (an L2 round trip is longer than one fragment's 8 MFMAs = 512 cycles).  The ring
+  // index (NT * (4 * chunk + pi) + nt) % 4 does not depend on the chunk: every register index below is a constant.
+  float4 bq[4][2];
+  const int n_frag = a.n_chunks * 4 * NT;
+  auto load_b = [&](int q, int buf) {              // q = NT * (4 * chunk + pi) + nt
+    const int step = q / NT, nt = q % NT;
+    const float* wp = wlane + (step >> 2) * w_chunk + (step & 3) * w_pos + nt * 32 * kKC;
+    bq[buf][0] = *reinterpret_cast<const float4*>(wp);
+    bq[buf][1] = *reinterpret_cast<const float4*>(wp + 4);
+  };
+
+  load_raw(0);
+  load_b(0, 0);
+  if (n_frag > 1) load_b(1, 1);
+  if (n_frag > 2) load_b(2, 2);
+  for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+    if (!(a.ablate & 32) || chunk == 0) commit_raw();
+    if (chunk + 1 < a.n_chunks && !(a.ablate & 16)) load_raw(chunk + 1);
+    __syncthreads();                               // raw visible; every wave is done with V
+    if (!(a.ablate & 4)) transform();
+    __syncthreads();
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi) {
+      const float* ap = vlane + pi * kNT32 * kRS;
+      const float4 a0 = *reinterpret_cast<const float4*>(ap);
+      const float4 a1 = *reinterpret_cast<const float4*>(ap + 4);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ring = (NT * pi + nt) % 4;
+        const int q = NT * (4 * chunk + pi) + nt;
+        if (q + 3 < n_frag && !(a.ablate & 1)) load_b(q + 3, (ring + 3) % 4);
+        const float4 b0 = bq[ring][0], b1 = bq[ring][1];
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        if (!(a.ablate & 2)) {
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+            acc[pi][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[ks], acc[pi][nt], 0, 0, 0);
+        } else {
+          acc[pi][nt][0] += av[0] * bv[0];
+        }
+      }
+    }
+  }
+  __syncthreads();                                 // the epilogue's M buffer aliases raw / V
+  if ((a.ablate & 8) && acc[0][0][0] != 1.2345e-30f) return;
+
+  // ---- output transform.  C/D map: col (cout) = lane & 31, row (tile) = (reg & 3) + 8 * (reg >> 2) + 4 * kh.
+  // Pass (nt, half): the 16 tiles with (tile >> 2) & 1... are chosen so that each pass takes 8 registers per lane:
+  // registers 8*half .. 8*half+7 hold tiles {0-3, 8-11} + 16*half (kh = 0) and {4-7, 12-15} + 16*half (kh = 1).
+  constexpr int kMS = 33;                          // M row stride (floats): 32 couts + 1 pad
+  float* Mb = lds;                                 // [16 pos][16 tiles][kMS] = 33.8 KB
+  float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = 8 * half + rr;
+          const int trow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh;      // tile index inside this half (0..15)
+          Mb[((4 * wave + pi) * 16 + trow) * kMS + m] = acc[pi][nt][r];
+        }
+      }
+      __syncthreads();
+      // 16 tiles x 32 couts = 512 (tile, cout) items, 2 per lane
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int item = it * 256 + t;
+        const int co_l = item & 31, tl = item >> 5;                    // tile inside the half
+        const int tg = 16 * half + tl;                                 // Winograd tile 0..31 of the workgroup
+        const int ty2 = tg >> 3, tx2 = tg & 7;
+        float mm[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mm[i][j] = Mb[((i * 4 + j) * 16 + tl) * kMS + co_l];
+        float s[2][4];                                                 // A^T M
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[0][j] = (mm[0][j] + mm[1][j]) + mm[2][j];
+          s[1][j] = (mm[1][j] - mm[2][j]) - mm[3][j];
+        }
+        const int co = n0 + nt * 32 + co_l;
+        if (co < a.Cout) {
+          const float bias = a.bias[co];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float y0 = (s[i][0] + s[i][1]) + s[i][2];            // (A^T M) A
+            const float y1 = (s[i][1] - s[i][2]) - s[i][3];
+            const int oy = tile_y + 2 * ty2 + i, ox = tile_x + 2 * tx2;
+            if (oy < a.h) {
+              if (ox < a.w) { float v = y0 + bias; oimg[((long long)oy * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
+              if (ox + 1 < a.w) { float v = y1 + bias; oimg[((long long)oy * a.w + ox + 1) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int NT>
+void launch_wino(const WinoArgs& a, hipStream_t s) {
+  constexpr size_t lds = (size_t)(kHP * kRS + 16 * kNT32 * kRS) * sizeof(float);       // 14.4 + 40 KB
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (a.CoutPad / (32 * NT))), (unsigned)a.b);
+  hipLaunchKernelGGL((conv3x3_wino_kernel<NT>), grid, dim3(256), lds, s, a);
+}
+
+}  // namespace
+
+extern "C" int m4d_conv3x3_wino_bias_act(const float* x, const float* wu, const float* bias, int b, int h, int w,
+                                         int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  M4D_CHECK_ARG(x && wu && bias && out && b > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0);
+  M4D_CHECK_ARG(CoutPad % 32 == 0 && CoutPad >= Cout);
+  M4D_CHECK_ARG(((((uintptr_t)x) & (Cin % 2 == 0 ? 7u : 3u)) == 0) && ((((uintptr_t)wu) & 15u) == 0));
+  WinoArgs a;
+  a.x = x; a.wu = wu; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
+  a.CoutPad = CoutPad; a.n_chunks = (Cin + kKC - 1) / kKC; a.slope = slope;
+  a.tiles_x = (w + kTW - 1) / kTW; a.tiles_y = (h + kTH - 1) / kTH;
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("M4D_WINO_ABLATE"); ablate = e ? atoi(e) : 0; }
+  a.ablate = ablate;
+  hipStream_t s = (hipStream_t)stream;
+  if ((CoutPad / 32) % 2 == 0) launch_wino<2>(a, s);
+  else launch_wino<1>(a, s);
+  return M4D_LAUNCH_RESULT();
+}

@@ -54,6 +54,21 @@ mfma_conv_encoder = _os.environ.get("M4D_MFMA_CONV_ENCODER", "1") == "1"
 # bench.py installs an object with ``run(name, level, thunk)`` here to bracket the
 # hand-written kernels with HIP events on the launch stream; None = no overhead.
 kernel_timer = None
+# Winograd F(2x2,3x3) for the wide stride-1 layers (csrc/m4d_wino.hip): 2.25x fewer MFMA flops, equal to the direct
+# convolution up to float32 rounding (max difference ~1e-6 of the output range).  Measured per layer (tools/bench_wino.py):
+# 1.26-1.49x at batch 1, 1.16-1.39x at batch 8 for 64/128 output channels; the 96- and 32-wide layers (one N-tile per
+# workgroup) gain only on small grids.  0 = always the direct convolution.
+winograd_conv = _os.environ.get("M4D_WINOGRAD", "1") == "1"
+
+
+def _use_winograd(b, h, w, cin, cout, stride):
+    if not winograd_conv or stride != 1 or cin < 16 or h * w < 4096:
+        return False
+    if cout % 64 == 0:
+        return True
+    return cout >= 96 and b * h * w <= 200000        # one N-tile per workgroup: only ahead on small grids
+
+
 # Frame pipeline of the decoder: level l of frame t+1 depends on level l+1 of its own frame and on
 # level l of frame t only, so consecutive frames of a sequence run on two HIP streams as a
 # wavefront: the launch-latency-bound coarse levels of frame t+1 execute underneath the
@@ -104,6 +119,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.bias = torch.nn.Parameter(torch.zeros(self.out_channels, device=device), requires_grad=False)
         self._packed = None
+        self._packed_wino = None
 
     def load_hwio(self, kernel, bias, device):
         """Load a TF-layout [3,3,Cin,Cout] kernel."""
@@ -111,6 +127,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.bias = torch.nn.Parameter(_to_device_f32(bias, device).contiguous(), requires_grad=False)
         self._packed = None
+        self._packed_wino = None
 
     def _packed_weights(self):
         """(wp, CoutPad) for m4d_conv3x3_bias_act, packed once from the OIHW parameter."""
@@ -119,6 +136,14 @@ class _Conv3x3SameTF(torch.nn.Module):
             wp, cpad = nops.pack_conv_weights(hwio)
             self._packed = (torch.from_numpy(wp).to(self.weight.device), cpad)
         return self._packed
+
+    def _packed_weights_winograd(self):
+        """(wu, CoutPad) for m4d_conv3x3_wino_bias_act: U = G g G^T, transformed once on the host."""
+        if getattr(self, "_packed_wino", None) is None or self._packed_wino[0].device != self.weight.device:
+            hwio = self.weight.detach().permute(2, 3, 1, 0).cpu().numpy()
+            wu, cpad = nops.pack_conv_weights_winograd(hwio)
+            self._packed_wino = (torch.from_numpy(wu).to(self.weight.device), cpad)
+        return self._packed_wino
 
     def same_pads(self, h, w):
         """TF 'SAME' (before, after) pads for rows and columns at this stride."""
@@ -142,6 +167,11 @@ class _Conv3x3SameTF(torch.nn.Module):
             self._build(x_nhwc.shape[-1], x_nhwc.device)
         if (x_nhwc.is_cuda and self.stride in (1, 2) and mfma_conv_min_pixels > 0 and x_nhwc.shape[-1] >= mfma_conv_min_cin
                 and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= mfma_conv_min_pixels):
+            b_, h_, w_, cin_ = x_nhwc.shape
+            if _use_winograd(b_, h_, w_, cin_, self.out_channels, self.stride):
+                wu, cpad = self._packed_weights_winograd()
+                return _timed("conv", self.tag, lambda: nops.conv3x3_wino_bias_act(
+                    x_nhwc, wu, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope))
             wp, cpad = self._packed_weights()
             return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
                 x_nhwc, wp, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope, stride=self.stride))

@@ -43,5 +43,7 @@ int main() {
   run<4>("4 acc/wave, 2 waves/SIMD", 512, 20000);
   run<4>("4 acc/wave, 2 waves/SIMD, long", 512, 200000); // ~0.7 s: sustained clocks
   run<1>("1 acc/wave (dependent chain), 2 waves/SIMD", 512, 20000);
+  run<1>("1 acc/wave (dependent chain), 1 wave/SIMD", 256, 20000);
+  run<2>("2 acc/wave, 1 wave/SIMD", 256, 20000);
   return 0;
 }
