@@ -31,6 +31,8 @@ struct WinoArgs {
   const float* x; const float* wu; const float* bias; float* out;
   int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
   float slope;
+  unsigned long long* stamps;   // profiling only (m4d_wino_set_stamps): per workgroup, per chunk, 5 cycle counters of wave 0
+  int prio_shift;
   int ablate;      // profiling only (M4D_WINO_ABLATE): 1 = weights loaded once, 2 = no MFMAs, 4 = no input transform, 8 = no epilogue
 };
 
@@ -60,13 +62,16 @@ conv3x3_wino_kernel(const WinoArgs a) {
     const int L = blockIdx.x;
     if ((n_tiles & 7) == 0) {
       const int xcd = L & 7, idx = L >> 3;
-      tile = xcd * (n_tiles >> 3) + idx / n_groups;
-      ng = idx % n_groups;
+      const int tpx = n_tiles >> 3;
+      if (a.ablate & 64) { tile = xcd * tpx + idx / n_groups; ng = idx % n_groups; }
+      else { ng = idx / tpx; tile = xcd * tpx + idx % tpx; }          // an XCD walks its band once per N-group
     } else {
       tile = L / n_groups;
       ng = L % n_groups;
     }
   }
+  // experiment knob (M4D_WINO_PRIO): raise the wave priority of every second workgroup (by a chosen bit of its id)
+  if (a.prio_shift >= 0 && ((blockIdx.x >> a.prio_shift) & 1)) __builtin_amdgcn_s_setprio(2);
   const int tile_y = (tile / a.tiles_x) * kTH, tile_x = (tile % a.tiles_x) * kTW;
   const int n0 = ng * BN;
   const int bi = blockIdx.y;
@@ -75,27 +80,32 @@ conv3x3_wino_kernel(const WinoArgs a) {
   // Raw halo of the next chunk: one register set, issued right after the commit of the current one so that the loads fly
   // during the transform AND the MFMA phase.  (Tried: two register sets / two chunks ahead -- spills at 256 VGPRs, 2x slower;
   // 32 channels per round trip -- 256 VGPRs, 8 % slower.)
+  // The loads are UNCONDITIONAL (coordinates clamped into the image, validity kept as a bit mask and applied at the
+  // commit): with `if (inside) r = load` hipcc branches around every load and waits vmcnt(0) at each merge -- six
+  // dependent round trips, measured 4.9 k cycles per chunk for this block of code, a third of the chunk period.
   float2 ra[A_PER];
+  unsigned ra_valid = 0;
   auto load_raw = [&](int chunk) {
     const int c0 = chunk * kKC;
+    ra_valid = 0;
 #pragma unroll
     for (int u = 0; u < A_PER; ++u) {
       const int idx = u * 256 + t;
-      const int hp = idx >> 3, k2 = (idx & 7) * 2;
+      const int hp = min(idx >> 3, kHP - 1), k2 = (idx & 7) * 2;
       const int gy = tile_y - 1 + hp / kHW, gx = tile_x - 1 + hp % kHW;
-      ra[u] = make_float2(0.f, 0.f);
-      if (idx < A_F2 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && c0 + k2 < a.Cin) {
-        const float* px = ximg + ((long long)gy * a.w + gx) * a.Cin + c0 + k2;
-        if (a.Cin & 1) { ra[u].x = px[0]; if (c0 + k2 + 1 < a.Cin) ra[u].y = px[1]; }
-        else ra[u] = *reinterpret_cast<const float2*>(px);
-      }
+      const bool ok = idx < A_F2 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && c0 + k2 < a.Cin;
+      ra_valid |= ok ? (1u << u) : 0u;
+      const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1), cc = min(c0 + k2, a.Cin - 2);
+      ra[u] = *reinterpret_cast<const float2*>(ximg + ((long long)cy * a.w + cx) * a.Cin + cc);
     }
   };
   auto commit_raw = [&]() {
 #pragma unroll
     for (int u = 0; u < A_PER; ++u) {
       const int idx = u * 256 + t;
-      if (idx < A_F2) *reinterpret_cast<float2*>(raw + (idx >> 3) * kRS + (idx & 7) * 2) = ra[u];
+      const bool ok = (ra_valid >> u) & 1u;
+      const float2 v = make_float2(ok ? ra[u].x : 0.f, ok ? ra[u].y : 0.f);
+      if (idx < A_F2) *reinterpret_cast<float2*>(raw + (idx >> 3) * kRS + (idx & 7) * 2) = v;
     }
   };
   // input transform: V[p][tile][c] = (B^T d B)[p]; 32 tiles x 16 channels = 512 items, two per lane (item = (tile, channel),
@@ -156,12 +166,21 @@ conv3x3_wino_kernel(const WinoArgs a) {
   load_b(0, 0);
   if (n_frag > 1) load_b(1, 1);
   if (n_frag > 2) load_b(2, 2);
+  unsigned long long* st = (a.stamps != nullptr && t == 0 && blockIdx.y == 0 && blockIdx.x < 512)
+                               ? a.stamps + (long long)blockIdx.x * (5 * 40 + 2) : nullptr;
+  if (st) st[0] = __builtin_readcyclecounter();
   for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+    if (st && chunk < 40) st[2 + chunk * 5 + 0] = __builtin_readcyclecounter();
     if (!(a.ablate & 32) || chunk == 0) commit_raw();
+    if (st && chunk < 40 && (a.ablate & 128)) st[2 + chunk * 5 + 1] = __builtin_readcyclecounter();     // variant: stamp 1 = after the commit
     if (chunk + 1 < a.n_chunks && !(a.ablate & 16)) load_raw(chunk + 1);
+    if (st && chunk < 40 && (a.ablate & 256)) st[2 + chunk * 5 + 1] = __builtin_readcyclecounter();     // variant: stamp 1 = after the load issue
     __syncthreads();                               // raw visible; every wave is done with V
+    if (st && chunk < 40 && !(a.ablate & 384)) st[2 + chunk * 5 + 1] = __builtin_readcyclecounter();
     if (!(a.ablate & 4)) transform();
+    if (st && chunk < 40) st[2 + chunk * 5 + 2] = __builtin_readcyclecounter();
     __syncthreads();
+    if (st && chunk < 40) st[2 + chunk * 5 + 3] = __builtin_readcyclecounter();
 #pragma unroll
     for (int pi = 0; pi < 4; ++pi) {
       const float* ap = vlane + pi * kNT32 * kRS;
@@ -184,66 +203,57 @@ conv3x3_wino_kernel(const WinoArgs a) {
         }
       }
     }
+    if (st && chunk < 40) st[2 + chunk * 5 + 4] = __builtin_readcyclecounter();
   }
+  if (st) st[2 + (a.n_chunks < 40 ? a.n_chunks : 40) * 5 - 1] = __builtin_readcyclecounter();
   __syncthreads();                                 // the epilogue's M buffer aliases raw / V
   if ((a.ablate & 8) && acc[0][0][0] != 1.2345e-30f) return;
 
-  // ---- output transform.  C/D map: col (cout) = lane & 31, row (tile) = (reg & 3) + 8 * (reg >> 2) + 4 * kh.
-  // Pass (nt, half): the 16 tiles with (tile >> 2) & 1... are chosen so that each pass takes 8 registers per lane:
-  // registers 8*half .. 8*half+7 hold tiles {0-3, 8-11} + 16*half (kh = 0) and {4-7, 12-15} + 16*half (kh = 1).
-  constexpr int kMS = 33;                          // M row stride (floats): 32 couts + 1 pad
-  float* Mb = lds;                                 // [16 pos][16 tiles][kMS] = 33.8 KB
+  // ---- output transform Y = A^T M A.  Wave w holds row i = w of the 4x4 position grid (positions 4w..4w+3 = columns
+  // j = 0..3), so the column half, R[i][k] = (M A)[i][k], is done in registers; only the two R values per (tile, cout)
+  // and wave meet in LDS, where Y[0][k] = R[0][k] + R[1][k] + R[2][k], Y[1][k] = R[1][k] - R[2][k] - R[3][k].
+  // C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (reg & 3) + 8 * (reg >> 2) + 4 * kh.
+  constexpr int kMS = 33;                          // row stride (floats): 32 couts + 1 pad
+  float* Rb = lds;                                 // [4 rows i][2 k][32 tiles][kMS] = 33.8 KB
   float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      Rb[((wave * 2 + 0) * kNT32 + trow) * kMS + m] = (m0 + m1) + m2;
+      Rb[((wave * 2 + 1) * kNT32 + trow) * kMS + m] = (m1 - m2) - m3;
+    }
+    __syncthreads();
 #pragma unroll
-      for (int pi = 0; pi < 4; ++pi) {
+    for (int it = 0; it < 4; ++it) {               // 32 tiles x 32 couts = 1024 (tile, cout) items, 4 per lane
+      const int item = it * 256 + t;
+      const int co_l = item & 31, tg = item >> 5;  // Winograd tile 0..31 of the workgroup
+      const int ty2 = tg >> 3, tx2 = tg & 7;
+      const int co = n0 + nt * 32 + co_l;
+      float rv[4][2];
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          const int r = 8 * half + rr;
-          const int trow = (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh;      // tile index inside this half (0..15)
-          Mb[((4 * wave + pi) * 16 + trow) * kMS + m] = acc[pi][nt][r];
-        }
-      }
-      __syncthreads();
-      // 16 tiles x 32 couts = 512 (tile, cout) items, 2 per lane
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int item = it * 256 + t;
-        const int co_l = item & 31, tl = item >> 5;                    // tile inside the half
-        const int tg = 16 * half + tl;                                 // Winograd tile 0..31 of the workgroup
-        const int ty2 = tg >> 3, tx2 = tg & 7;
-        float mm[4][4];
+        for (int k = 0; k < 2; ++k) rv[i][k] = Rb[((i * 2 + k) * kNT32 + tg) * kMS + co_l];
+      if (co < a.Cout) {
+        const float bias = a.bias[co];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) mm[i][j] = Mb[((i * 4 + j) * 16 + tl) * kMS + co_l];
-        float s[2][4];                                                 // A^T M
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          s[0][j] = (mm[0][j] + mm[1][j]) + mm[2][j];
-          s[1][j] = (mm[1][j] - mm[2][j]) - mm[3][j];
-        }
-        const int co = n0 + nt * 32 + co_l;
-        if (co < a.Cout) {
-          const float bias = a.bias[co];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const float y0 = (s[i][0] + s[i][1]) + s[i][2];            // (A^T M) A
-            const float y1 = (s[i][1] - s[i][2]) - s[i][3];
-            const int oy = tile_y + 2 * ty2 + i, ox = tile_x + 2 * tx2;
-            if (oy < a.h) {
-              if (ox < a.w) { float v = y0 + bias; oimg[((long long)oy * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
-              if (ox + 1 < a.w) { float v = y1 + bias; oimg[((long long)oy * a.w + ox + 1) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
-            }
+        for (int k = 0; k < 2; ++k) {
+          const float y0 = (rv[0][k] + rv[1][k]) + rv[2][k];
+          const float y1 = (rv[1][k] - rv[2][k]) - rv[3][k];
+          const int ox = tile_x + 2 * tx2 + k, oy = tile_y + 2 * ty2;
+          if (ox < a.w) {
+            if (oy < a.h) { float v = y0 + bias; oimg[((long long)oy * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
+            if (oy + 1 < a.h) { float v = y1 + bias; oimg[((long long)(oy + 1) * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
           }
         }
       }
-      __syncthreads();
     }
+    if (nt + 1 < NT) __syncthreads();
   }
+  if (st) st[1] = __builtin_readcyclecounter();
 }
 
 template <int NT>
@@ -255,11 +265,14 @@ void launch_wino(const WinoArgs& a, hipStream_t s) {
 
 }  // namespace
 
+static unsigned long long* g_wino_stamps = nullptr;
+extern "C" void m4d_wino_set_stamps(unsigned long long* device_buffer) { g_wino_stamps = device_buffer; }
+
 extern "C" int m4d_conv3x3_wino_bias_act(const float* x, const float* wu, const float* bias, int b, int h, int w,
                                          int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
   M4D_CHECK_ARG(x && wu && bias && out && b > 0 && h > 0 && w > 0 && Cin > 0 && Cout > 0);
   M4D_CHECK_ARG(CoutPad % 32 == 0 && CoutPad >= Cout);
-  M4D_CHECK_ARG(((((uintptr_t)x) & (Cin % 2 == 0 ? 7u : 3u)) == 0) && ((((uintptr_t)wu) & 15u) == 0));
+  M4D_CHECK_ARG(Cin % 2 == 0 && ((((uintptr_t)x) & 7u) == 0) && ((((uintptr_t)wu) & 15u) == 0));
   WinoArgs a;
   a.x = x; a.wu = wu; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
   a.CoutPad = CoutPad; a.n_chunks = (Cin + kKC - 1) / kKC; a.slope = slope;
@@ -267,6 +280,10 @@ extern "C" int m4d_conv3x3_wino_bias_act(const float* x, const float* wu, const 
   static int ablate = -1;
   if (ablate < 0) { const char* e = getenv("M4D_WINO_ABLATE"); ablate = e ? atoi(e) : 0; }
   a.ablate = ablate;
+  a.stamps = g_wino_stamps;
+  static int prio_shift = -2;
+  if (prio_shift == -2) { const char* e = getenv("M4D_WINO_PRIO"); prio_shift = e ? atoi(e) : -1; }
+  a.prio_shift = prio_shift;
   hipStream_t s = (hipStream_t)stream;
   if ((CoutPad / 32) % 2 == 0) launch_wino<2>(a, s);
   else launch_wino<1>(a, s);
