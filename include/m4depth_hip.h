@@ -144,6 +144,10 @@ int m4d_sncv_fwd(const float* c1, const float* c2, int b, int h, int w, int C, i
  * (network_ops.pack_conv_weights_winograd); CoutPad a multiple of 32.  Deterministic. */
 int m4d_conv3x3_wino_bias_act(const float* x, const float* wu, const float* bias, int b, int h, int w,
                               int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
+/* Variant with half the weight traffic per flop (16x16-pixel workgroup tile, 8-channel K chunks): wu8 packed
+ * [ceil(Cin/8)][16 positions][CoutPad][8 channels]; Cin % 4 == 0, x 16-byte aligned. */
+int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, const float* bias, int b, int h, int w,
+                               int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
 /* Profiling only: 202 uint64 per workgroup (first 512 of batch item 0) = cycle counter of wave 0 at kernel entry / exit and,
  * per K chunk (first 40), at chunk start / after the first barrier / after the input transform / after the second barrier /
  * after the MFMA loop.  NULL switches it off. */

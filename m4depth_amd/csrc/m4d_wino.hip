@@ -265,6 +265,194 @@ void launch_wino(const WinoArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant 2: the per-phase stamps of the kernel above show its MFMA loop waiting on the weight fragments -- every
+// fragment (2 KB per wave) feeds only 8 MFMAs, ~20 TB/s of L2 traffic at the full MFMA rate, more than L2 delivers.
+// Here a wave keeps 4 positions x TWO M-tiles (a 16x16-pixel workgroup tile = 64 Winograd tiles) x one N-tile, so a
+// fragment feeds 16 MFMAs: half the weight traffic per flop.  To keep V (16 positions x 64 tiles) within 48 KB of LDS
+// the K chunk is 8 channels; the weight ring is 8 fragments deep (4 VGPRs each, 6 fragments of lookahead).
+constexpr int kT2 = 16;                          // output tile 16 x 16
+constexpr int kH2 = kT2 + 2;                     // halo 18 x 18
+constexpr int kHP2 = kH2 * kH2;                  // 324 halo pixels
+constexpr int kC2 = 8;                           // channels per chunk
+constexpr int kRS2 = 12;                         // LDS row stride (floats): 8 + 4 pad (48 B: conflict-free 16-byte reads)
+constexpr int kNT64 = 64;                        // Winograd tiles per workgroup (8 x 8) = two MFMA M-tiles
+
+__global__ void __launch_bounds__(256, 2)
+conv3x3_wino2_kernel(const WinoArgs a) {
+  constexpr int A_F4 = kHP2 * 2;                 // float4 loads per halo chunk (648)
+  constexpr int A_PER = (A_F4 + 255) / 256;      // 3
+  extern __shared__ __align__(16) float lds[];
+  float* raw = lds;                              // [kHP2][kRS2]         15.2 KB
+  float* V = lds + kHP2 * kRS2;                  // [16][64][kRS2]       48 KB
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n_tiles = a.tiles_x * a.tiles_y, n_groups = a.CoutPad / 32;
+  int tile, ng;
+  {
+    const int L = blockIdx.x;
+    if ((n_tiles & 7) == 0) {
+      const int xcd = L & 7, idx = L >> 3;
+      tile = xcd * (n_tiles >> 3) + idx / n_groups;
+      ng = idx % n_groups;
+    } else {
+      tile = L / n_groups;
+      ng = L % n_groups;
+    }
+  }
+  const int tile_y = (tile / a.tiles_x) * kT2, tile_x = (tile % a.tiles_x) * kT2;
+  const int n0 = ng * 32;
+  const int bi = blockIdx.y;
+  const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
+
+  float4 ra[A_PER];
+  unsigned ra_valid = 0;
+  auto load_raw = [&](int chunk) {               // unconditional loads, validity applied at the commit (see above)
+    const int c0 = chunk * kC2;
+    ra_valid = 0;
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const int idx = u * 256 + t;
+      const int hp = min(idx >> 1, kHP2 - 1), k4 = (idx & 1) * 4;
+      const int gy = tile_y - 1 + hp / kH2, gx = tile_x - 1 + hp % kH2;
+      const bool ok = idx < A_F4 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && c0 + k4 < a.Cin;
+      ra_valid |= ok ? (1u << u) : 0u;
+      const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1), cc = min(c0 + k4, a.Cin - 4);
+      ra[u] = *reinterpret_cast<const float4*>(ximg + ((long long)cy * a.w + cx) * a.Cin + cc);
+    }
+  };
+  auto commit_raw = [&]() {
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const int idx = u * 256 + t;
+      const bool ok = (ra_valid >> u) & 1u;
+      const float4 v = ok ? ra[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < A_F4) *reinterpret_cast<float4*>(raw + (idx >> 1) * kRS2 + (idx & 1) * 4) = v;
+    }
+  };
+  // input transform: lane = (tile, channel pair): 64 tiles x 4 pairs = 256 items, float2 arithmetic
+  const int tt = t >> 2, cp = t & 3;
+  const int tty = tt >> 3, ttx = tt & 7;
+  auto transform = [&]() {
+    float2 c[4][4];                                // c = d B, row by row as the inputs arrive
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* rp = raw + ((2 * tty + i) * kH2 + 2 * ttx) * kRS2 + 2 * cp;
+      const float2 d0 = *reinterpret_cast<const float2*>(rp), d1 = *reinterpret_cast<const float2*>(rp + kRS2);
+      const float2 d2 = *reinterpret_cast<const float2*>(rp + 2 * kRS2), d3 = *reinterpret_cast<const float2*>(rp + 3 * kRS2);
+      c[i][0] = make_float2(d0.x - d2.x, d0.y - d2.y);
+      c[i][1] = make_float2(d1.x + d2.x, d1.y + d2.y);
+      c[i][2] = make_float2(d2.x - d1.x, d2.y - d1.y);
+      c[i][3] = make_float2(d1.x - d3.x, d1.y - d3.y);
+    }
+    float* vp = V + tt * kRS2 + 2 * cp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                  // rows: B^T (d B); position p = i * 4 + j
+      *reinterpret_cast<float2*>(vp + (0 + j) * kNT64 * kRS2) = make_float2(c[0][j].x - c[2][j].x, c[0][j].y - c[2][j].y);
+      *reinterpret_cast<float2*>(vp + (4 + j) * kNT64 * kRS2) = make_float2(c[1][j].x + c[2][j].x, c[1][j].y + c[2][j].y);
+      *reinterpret_cast<float2*>(vp + (8 + j) * kNT64 * kRS2) = make_float2(c[2][j].x - c[1][j].x, c[2][j].y - c[1][j].y);
+      *reinterpret_cast<float2*>(vp + (12 + j) * kNT64 * kRS2) = make_float2(c[1][j].x - c[3][j].x, c[1][j].y - c[3][j].y);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[pi][mt][r] = 0.f;
+
+  const int m = lane & 31, kh = lane >> 5;
+  // weights: wu[chunk][pos][CoutPad][8]; this lane reads channels 4kh..4kh+3 of cout n0 + m
+  const float* wlane = a.wu + ((long long)(4 * wave) * a.CoutPad + n0 + m) * kC2 + kh * 4;
+  const long long w_pos = (long long)a.CoutPad * kC2;
+  const long long w_chunk = 16 * w_pos;
+  const float* vlane = V + ((4 * wave) * kNT64 + m) * kRS2 + kh * 4;
+
+  float4 bq[8];
+  const int n_frag = a.n_chunks * 4;
+  auto load_b = [&](int q, int buf) { bq[buf] = *reinterpret_cast<const float4*>(wlane + (q >> 2) * w_chunk + (q & 3) * w_pos); };
+
+  load_raw(0);
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+    if (q < n_frag) load_b(q, q);
+  for (int chunk0 = 0; chunk0 < a.n_chunks; chunk0 += 2) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {               // two chunks per iteration: the ring index (4 * chunk + pi) % 8 is static
+      const int chunk = chunk0 + cc;
+      if (chunk < a.n_chunks) {
+        commit_raw();
+        if (chunk + 1 < a.n_chunks) load_raw(chunk + 1);
+        __syncthreads();                           // raw visible; every wave is done with V
+        transform();
+        __syncthreads();
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+          const int ring = cc * 4 + pi;
+          const int q = chunk * 4 + pi;
+          if (q + 6 < n_frag) load_b(q + 6, (ring + 6) % 8);
+          const float4 b0 = bq[ring];
+          const float bv[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const float4 a0 = *reinterpret_cast<const float4*>(vlane + (pi * kNT64 + mt * 32) * kRS2);
+            const float av[4] = {a0.x, a0.y, a0.z, a0.w};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+              acc[pi][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[ks], acc[pi][mt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();                                 // the epilogue buffer aliases raw / V
+
+  // ---- output transform, as above; one pass per M-tile
+  constexpr int kMS = 33;
+  float* Rb = lds;                                 // [4 rows i][2 k][32 tiles][kMS] = 33.8 KB
+  float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][mt][r], m1 = acc[1][mt][r], m2 = acc[2][mt][r], m3 = acc[3][mt][r];
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      Rb[((wave * 2 + 0) * 32 + trow) * kMS + m] = (m0 + m1) + m2;
+      Rb[((wave * 2 + 1) * 32 + trow) * kMS + m] = (m1 - m2) - m3;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int item = it * 256 + t;
+      const int co_l = item & 31, tl = item >> 5;  // tile inside this M-tile
+      const int tg = mt * 32 + tl;                 // Winograd tile 0..63 of the workgroup (8 x 8)
+      const int ty2 = tg >> 3, tx2 = tg & 7;
+      const int co = n0 + co_l;
+      float rv[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) rv[i][k] = Rb[((i * 2 + k) * 32 + tl) * kMS + co_l];
+      if (co < a.Cout) {
+        const float bias = a.bias[co];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float y0 = (rv[0][k] + rv[1][k]) + rv[2][k];
+          const float y1 = (rv[1][k] - rv[2][k]) - rv[3][k];
+          const int ox = tile_x + 2 * tx2 + k, oy = tile_y + 2 * ty2;
+          if (ox < a.w) {
+            if (oy < a.h) { float v = y0 + bias; oimg[((long long)oy * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
+            if (oy + 1 < a.h) { float v = y1 + bias; oimg[((long long)(oy + 1) * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
+          }
+        }
+      }
+    }
+    if (mt == 0) __syncthreads();
+  }
+}
+
 static unsigned long long* g_wino_stamps = nullptr;
 extern "C" void m4d_wino_set_stamps(unsigned long long* device_buffer) { g_wino_stamps = device_buffer; }
 
@@ -287,5 +475,21 @@ extern "C" int m4d_conv3x3_wino_bias_act(const float* x, const float* wu, const 
   hipStream_t s = (hipStream_t)stream;
   if ((CoutPad / 32) % 2 == 0) launch_wino<2>(a, s);
   else launch_wino<1>(a, s);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, const float* bias, int b, int h, int w,
+                                          int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  M4D_CHECK_ARG(x && wu8 && bias && out && b > 0 && h > 0 && w > 0 && Cin >= 4 && Cout > 0);
+  M4D_CHECK_ARG(CoutPad % 32 == 0 && CoutPad >= Cout);
+  M4D_CHECK_ARG(Cin % 4 == 0 && ((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu8) & 15u) == 0));
+  WinoArgs a;
+  a.x = x; a.wu = wu8; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
+  a.CoutPad = CoutPad; a.n_chunks = (Cin + kC2 - 1) / kC2; a.slope = slope;
+  a.tiles_x = (w + kT2 - 1) / kT2; a.tiles_y = (h + kT2 - 1) / kT2;
+  a.ablate = 0; a.stamps = nullptr; a.prio_shift = -1;
+  constexpr size_t lds = (size_t)(kHP2 * kRS2 + 16 * kNT64 * kRS2) * sizeof(float);     // 15.2 + 48 KB
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 32)), (unsigned)b);
+  hipLaunchKernelGGL(conv3x3_wino2_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -62,11 +62,15 @@ winograd_conv = _os.environ.get("M4D_WINOGRAD", "1") == "1"
 
 
 def _use_winograd(b, h, w, cin, cout, stride):
-    if not winograd_conv or stride != 1 or cin < 16 or h * w < 4096:
-        return False
+    """0 = direct convolution; 1 = Winograd kernel 1 (16x8 tile, 16-channel chunks, 2 N-tiles per workgroup);
+    2 = kernel 2 (16x16 tile, 8-channel chunks: half the weight traffic per flop -- ahead on the large maps)."""
+    if not winograd_conv or stride != 1 or cin < 16 or cin % 2 != 0 or h * w < 4096:
+        return 0
+    if cin % 4 == 0 and cout >= 32 and h * w >= 24576:
+        return 2
     if cout % 64 == 0:
-        return True
-    return cout >= 96 and b * h * w <= 200000        # one N-tile per workgroup: only ahead on small grids
+        return 1
+    return 1 if (cout >= 96 and b * h * w <= 200000) else 0     # one N-tile per workgroup: only ahead on small grids
 
 
 # Frame pipeline of the decoder: level l of frame t+1 depends on level l+1 of its own frame and on
@@ -137,13 +141,17 @@ class _Conv3x3SameTF(torch.nn.Module):
             self._packed = (torch.from_numpy(wp).to(self.weight.device), cpad)
         return self._packed
 
-    def _packed_weights_winograd(self):
-        """(wu, CoutPad) for m4d_conv3x3_wino_bias_act: U = G g G^T, transformed once on the host."""
-        if getattr(self, "_packed_wino", None) is None or self._packed_wino[0].device != self.weight.device:
+    def _packed_weights_winograd(self, chunk=16):
+        """(wu, CoutPad) for m4d_conv3x3_wino_bias_act (chunk 16) / wino2 (chunk 8): U = G g G^T, transformed once on the host."""
+        cache = getattr(self, "_packed_wino", None)
+        if cache is None:
+            cache = self._packed_wino = {}
+        hit = cache.get(chunk)
+        if hit is None or hit[0].device != self.weight.device:
             hwio = self.weight.detach().permute(2, 3, 1, 0).cpu().numpy()
-            wu, cpad = nops.pack_conv_weights_winograd(hwio)
-            self._packed_wino = (torch.from_numpy(wu).to(self.weight.device), cpad)
-        return self._packed_wino
+            wu, cpad = nops.pack_conv_weights_winograd(hwio, chunk=chunk)
+            hit = cache[chunk] = (torch.from_numpy(wu).to(self.weight.device), cpad)
+        return hit
 
     def same_pads(self, h, w):
         """TF 'SAME' (before, after) pads for rows and columns at this stride."""
@@ -168,9 +176,11 @@ class _Conv3x3SameTF(torch.nn.Module):
         if (x_nhwc.is_cuda and self.stride in (1, 2) and mfma_conv_min_pixels > 0 and x_nhwc.shape[-1] >= mfma_conv_min_cin
                 and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= mfma_conv_min_pixels):
             b_, h_, w_, cin_ = x_nhwc.shape
-            if _use_winograd(b_, h_, w_, cin_, self.out_channels, self.stride):
-                wu, cpad = self._packed_weights_winograd()
-                return _timed("conv", self.tag, lambda: nops.conv3x3_wino_bias_act(
+            wino = _use_winograd(b_, h_, w_, cin_, self.out_channels, self.stride)
+            if wino:
+                wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8)
+                fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
+                return _timed("conv", self.tag, lambda: fn(
                     x_nhwc, wu, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope))
             wp, cpad = self._packed_weights()
             return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(

@@ -193,21 +193,21 @@ def conv3x3_bias_act(x, wp, bias, cout, cout_pad, slope=0.1, stride=1):
 _WINO_G = [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]]
 
 
-def pack_conv_weights_winograd(kernel_hwio):
+def pack_conv_weights_winograd(kernel_hwio, chunk=16):
     """Winograd F(2x2,3x3) filter transform U = G g G^T of a TF HWIO [3,3,Cin,Cout] kernel (in float64, rounded
-    once to float32), packed for m4d_conv3x3_wino_bias_act: [ceil(Cin/16)][16 positions][CoutPad][16 channels],
-    zero padded.  numpy in, numpy out."""
+    once to float32), packed for m4d_conv3x3_wino_bias_act (chunk = 16) / m4d_conv3x3_wino2_bias_act (chunk = 8):
+    [ceil(Cin/chunk)][16 positions][CoutPad][chunk channels], zero padded.  numpy in, numpy out."""
     import numpy as np
     k = np.asarray(kernel_hwio, dtype=np.float64)
     assert k.shape[:2] == (3, 3)
     cin, cout = k.shape[2], k.shape[3]
     G = np.array(_WINO_G, np.float64)
     U = np.einsum('ij,jkco,lk->ilco', G, k, G)                   # [4,4,Cin,Cout]
-    nch = -(-cin // 16)
+    nch = -(-cin // chunk)
     cpad = -(-cout // 32) * 32
-    full = np.zeros((16, nch * 16, cpad), np.float32)
+    full = np.zeros((16, nch * chunk, cpad), np.float32)
     full[:, :cin, :cout] = U.reshape(16, cin, cout).astype(np.float32)
-    w = full.reshape(16, nch, 16, cpad).transpose(1, 0, 3, 2)    # [chunk][pos][n][16]
+    w = full.reshape(16, nch, chunk, cpad).transpose(1, 0, 3, 2)    # [chunk][pos][n][channels]
     return np.ascontiguousarray(w), cpad
 
 
@@ -218,4 +218,14 @@ def conv3x3_wino_bias_act(x, wu, bias, cout, cout_pad, slope=0.1):
     out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
     check(lib.m4d_conv3x3_wino_bias_act(dptr(x, "x"), dptr(wu, "wu"), dptr(bias, "bias"), b, h, w, cin, int(cout),
                                         int(cout_pad), float(slope), dptr(out), stream_ptr()), "m4d_conv3x3_wino_bias_act")
+    return out
+
+
+def conv3x3_wino2_bias_act(x, wu8, bias, cout, cout_pad, slope=0.1):
+    """Winograd variant 2 (16x16 workgroup tile, 8-channel chunks; weights packed with chunk=8)."""
+    x = as_f32(x, "x")
+    b, h, w, cin = x.shape
+    out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    check(lib.m4d_conv3x3_wino2_bias_act(dptr(x, "x"), dptr(wu8, "wu8"), dptr(bias, "bias"), b, h, w, cin, int(cout),
+                                         int(cout_pad), float(slope), dptr(out), stream_ptr()), "m4d_conv3x3_wino2_bias_act")
     return out

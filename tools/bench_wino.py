@@ -14,12 +14,22 @@ for (h, w, cin, cout) in [(192, 640, 64, 128), (192, 640, 128, 128), (192, 640, 
     bias = torch.randn(cout, device=dev) * 0.1
     wp, cpad = nops.pack_conv_weights(k.numpy()); wpd = torch.from_numpy(wp).to(dev)
     wu, cpad2 = nops.pack_conv_weights_winograd(k.numpy()); wud = torch.from_numpy(wu).to(dev)
+    wu8, _ = nops.pack_conv_weights_winograd(k.numpy(), chunk=8); wu8d = torch.from_numpy(wu8).to(dev)
+    v2 = cin % 4 == 0
     ref = nops.conv3x3_bias_act(x, wpd, bias, cout, cpad, 0.1)
     got = nops.conv3x3_wino_bias_act(x, wud, bias, cout, cpad2, 0.1)
     torch.cuda.synchronize()
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     res = []
-    for fn in (lambda: nops.conv3x3_bias_act(x, wpd, bias, cout, cpad, 0.1), lambda: nops.conv3x3_wino_bias_act(x, wud, bias, cout, cpad2, 0.1)):
+    err2 = float("nan")
+    if v2:
+        got2 = nops.conv3x3_wino2_bias_act(x, wu8d, bias, cout, cpad2, 0.1)
+        torch.cuda.synchronize()
+        err2 = (got2 - ref).abs().max().item() / ref.abs().max().item()
+    fns = [lambda: nops.conv3x3_bias_act(x, wpd, bias, cout, cpad, 0.1), lambda: nops.conv3x3_wino_bias_act(x, wud, bias, cout, cpad2, 0.1)]
+    if v2:
+        fns.append(lambda: nops.conv3x3_wino2_bias_act(x, wu8d, bias, cout, cpad2, 0.1))
+    for fn in fns:
         for _ in range(3): fn()
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -28,4 +38,5 @@ for (h, w, cin, cout) in [(192, 640, 64, 128), (192, 640, 128, 128), (192, 640, 
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) * 1e3 / a.iters)
     fl = 2 * 9 * cin * cout * h * w * a.batch
-    print(f"{h}x{w} b={a.batch} {cin:3d}->{cout:3d}: max|diff|/max|ref| {err:.2e} | direct {res[0]:8.1f} us ({fl/res[0]/1e6:6.1f} TF/s) | winograd {res[1]:8.1f} us ({fl/res[1]/1e6:6.1f} eff. TF/s) | {res[0]/res[1]:.2f}x", flush=True)
+    print(f"{h}x{w} b={a.batch} {cin:3d}->{cout:3d}: max|diff|/max|ref| {err:.2e} | direct {res[0]:8.1f} us ({fl/res[0]/1e6:6.1f} TF/s) | winograd {res[1]:8.1f} us ({fl/res[1]/1e6:6.1f} eff. TF/s) | {res[0]/res[1]:.2f}x"
+          + (f" | v2 {res[2]:8.1f} us err {err2:.1e} {res[0]/res[2]:.2f}x" if v2 else ""), flush=True)
