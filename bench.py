@@ -15,8 +15,9 @@ timed region.  ``value`` = all frames processed by all ranks / max-over-ranks ti
 
 The JSON line also carries
   roofline     -- the dominant hand-written kernel of the step: the level-1 refiner
-                  128->128 convolution (fp32 MFMA implicit GEMM), algorithmic flops / HIP-event
-                  time on the launch stream, against the 157.3 TFLOP/s fp32-MFMA peak;
+                  128->128 convolution (Winograd F(2x2,3x3) on fp32 MFMA): the flops it executes on the
+                  matrix cores / HIP-event time on the launch stream, against the 157.3 TFLOP/s fp32-MFMA
+                  peak (+ the layer's direct-algorithm equivalent rate);
                   roofline_dscv / roofline_sncv: the level-1 cost-volume kernels, algorithmic
                   bytes / time against the 8 TB/s HBM3E peak;
   cpu_baseline -- the CPU oracle (a numpy restatement of the reference: TensorFlow is
@@ -211,8 +212,9 @@ def main():
                                "(BASELINE.json configs[1] when batch=1, configs[2] when batch=32)",
                    "global_batch": world * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",
-                   "conv_backend": "stride-1 3x3 convs: hand-written fp32-MFMA implicit GEMM with fused bias+leaky-relu "
-                                   "(libm4depth_hip.so); stride-2 / 3-channel encoder convs: MIOpen fp32",
+                   "conv_backend": "hand-written fp32-MFMA convolutions with fused bias+leaky-relu (libm4depth_hip.so): "
+                                   "Winograd F(2x2,3x3) for the wide stride-1 layers of levels 1-3, direct implicit GEMM "
+                                   "(stride 1 / 2, split-K on the coarse levels) elsewhere; 3-channel image convolution: MIOpen fp32",
                    "hot_path": "libm4depth_hip.so (HIP, gfx950)"},
         "AbsRel": round(metrics[0], 6), "launch": "eager" if args.eager else "hipGraph replay of the sequence forward; frames pipelined over the decoder "
                                                   "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)",
@@ -235,12 +237,23 @@ def main():
         h1, w1 = args.height >> 1, args.width >> 1
         for name, (n, sec) in summ.items():
             if name == "conv":
-                flops = 2.0 * 9 * 128 * 128 * h1 * w1 * args.batch
+                # The layer's algorithmic work is the direct convolution's 2*9*Cin*Cout flops per pixel.  The kernel that
+                # runs it is Winograd F(2x2,3x3) (2.25x fewer multiply-adds, m4d_wino.hip) unless M4D_WINOGRAD=0, so the
+                # roofline of the KERNEL is priced on the flops it executes on the matrix cores (2*4*Cin*Cout per pixel,
+                # rounded up to whole 2x2 tiles); the layer's direct-algorithm rate is reported next to it.
+                flops_direct = 2.0 * 9 * 128 * 128 * h1 * w1 * args.batch
+                wino = net.winograd_conv
+                flops = 2.0 * 16 * 128 * 128 * ((h1 + 1) // 2) * ((w1 + 1) // 2) * args.batch if wino else flops_direct
                 tf = flops / sec / 1e12
-                out["roofline"] = {"kernel": "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)",
+                out["roofline"] = {"kernel": ("conv3x3_wino2_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3) on fp32 MFMA, "
+                                              "bias+leaky-relu fused)") if wino else
+                                             "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)",
                                    "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                                   "traffic": traffic.get("conv_l1_128_128"), "algorithmic_flops_per_launch": flops,
+                                   "traffic": None if wino else traffic.get("conv_l1_128_128"),
+                                   "executed_mfma_flops_per_launch": flops,
+                                   "algorithmic_flops_per_launch": flops_direct,
+                                   "direct_algorithm_equivalent_tflops": round(flops_direct / sec / 1e12, 2),
                                    "algorithmic_bytes_per_launch": 4 * (2 * 128 * h1 * w1 * args.batch + 9 * 128 * 128),
                                    "avg_launch_us": round(sec * 1e6, 2), "launches": n}
                 continue
