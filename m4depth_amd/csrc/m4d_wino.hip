@@ -213,9 +213,10 @@ conv3x3_wino_kernel(const WinoArgs a) {
   // j = 0..3), so the column half, R[i][k] = (M A)[i][k], is done in registers; only the two R values per (tile, cout)
   // and wave meet in LDS, where Y[0][k] = R[0][k] + R[1][k] + R[2][k], Y[1][k] = R[1][k] - R[2][k] - R[3][k].
   // C/D map of the 32x32 MFMA: col (cout) = lane & 31, row (tile) = (reg & 3) + 8 * (reg >> 2) + 4 * kh.
-  constexpr int kMS = 33;                          // row stride (floats): 32 couts + 1 pad
-  float* Rb = lds;                                 // [4 rows i][2 k][32 tiles][kMS] = 33.8 KB
+  constexpr int kMS = 36;                          // row stride (floats): 32 couts + 4 pad (16-byte aligned rows)
+  float* Rb = lds;                                 // [4 rows i][2 k][32 tiles][kMS] = 36.9 KB
   float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+  const bool vec_ok = (a.Cout & 3) == 0;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -226,27 +227,42 @@ conv3x3_wino_kernel(const WinoArgs a) {
       Rb[((wave * 2 + 1) * kNT32 + trow) * kMS + m] = (m1 - m2) - m3;
     }
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {               // 32 tiles x 32 couts = 1024 (tile, cout) items, 4 per lane
-      const int item = it * 256 + t;
-      const int co_l = item & 31, tg = item >> 5;  // Winograd tile 0..31 of the workgroup
+    {                                              // 32 tiles x 8 cout quads = 256 items, one per lane, 16-byte loads / stores
+      const int cq = t & 7, tg = t >> 3;           // Winograd tile 0..31 of the workgroup
       const int ty2 = tg >> 3, tx2 = tg & 7;
-      const int co = n0 + nt * 32 + co_l;
-      float rv[4][2];
+      const int co = n0 + nt * 32 + 4 * cq;
+      float4 rv[4][2];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) rv[i][k] = Rb[((i * 2 + k) * kNT32 + tg) * kMS + co_l];
+        for (int k = 0; k < 2; ++k) rv[i][k] = *reinterpret_cast<const float4*>(Rb + ((i * 2 + k) * kNT32 + tg) * kMS + 4 * cq);
       if (co < a.Cout) {
-        const float bias = a.bias[co];
+        float bs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[e] = co + e < a.Cout ? a.bias[co + e] : 0.f;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const float y0 = (rv[0][k] + rv[1][k]) + rv[2][k];
-          const float y1 = (rv[1][k] - rv[2][k]) - rv[3][k];
+          const float* r0 = reinterpret_cast<const float*>(&rv[0][k]); const float* r1 = reinterpret_cast<const float*>(&rv[1][k]);
+          const float* r2 = reinterpret_cast<const float*>(&rv[2][k]); const float* r3 = reinterpret_cast<const float*>(&rv[3][k]);
+          float y0[4], y1[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v0 = ((r0[e] + r1[e]) + r2[e]) + bs[e];
+            float v1 = ((r1[e] - r2[e]) - r3[e]) + bs[e];
+            y0[e] = v0 > 0.f ? v0 : v0 * a.slope;
+            y1[e] = v1 > 0.f ? v1 : v1 * a.slope;
+          }
           const int ox = tile_x + 2 * tx2 + k, oy = tile_y + 2 * ty2;
           if (ox < a.w) {
-            if (oy < a.h) { float v = y0 + bias; oimg[((long long)oy * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
-            if (oy + 1 < a.h) { float v = y1 + bias; oimg[((long long)(oy + 1) * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+              if (oy + l < a.h) {
+                float* op = oimg + ((long long)(oy + l) * a.w + ox) * a.Cout + co;
+                const float* y = l ? y1 : y0;
+                if (vec_ok) *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+                else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) op[e] = y[e]; }
+              }
+            }
           }
         }
       }
@@ -374,6 +390,12 @@ conv3x3_wino2_kernel(const WinoArgs a) {
   const int n_frag = a.n_chunks * 4;
   auto load_b = [&](int q, int buf) { bq[buf] = *reinterpret_cast<const float4*>(wlane + (q >> 2) * w_chunk + (q & 3) * w_pos); };
 
+  unsigned long long* st = (a.stamps != nullptr && t == 0 && blockIdx.y == 0 && blockIdx.x < 512)
+                               ? a.stamps + (long long)blockIdx.x * (5 * 40 + 2) : nullptr;
+  if (st) st[0] = __builtin_readcyclecounter();
+  // (Tried: raw halo double buffered in LDS with the commit of chunk c+1 and the loads of chunk c+2 issued inside the
+  // MFMA phase of chunk c -- one phase less per chunk on paper, 5 % slower measured: hipcc places the commit's wait and
+  // the address arithmetic in front of the MFMAs instead of between them.)
   load_raw(0);
 #pragma unroll
   for (int q = 0; q < 6; ++q)
@@ -383,11 +405,15 @@ conv3x3_wino2_kernel(const WinoArgs a) {
     for (int cc = 0; cc < 2; ++cc) {               // two chunks per iteration: the ring index (4 * chunk + pi) % 8 is static
       const int chunk = chunk0 + cc;
       if (chunk < a.n_chunks) {
+        if (st && chunk < 40) st[2 + chunk * 5 + 0] = __builtin_readcyclecounter();
         commit_raw();
         if (chunk + 1 < a.n_chunks) load_raw(chunk + 1);
         __syncthreads();                           // raw visible; every wave is done with V
+        if (st && chunk < 40) st[2 + chunk * 5 + 1] = __builtin_readcyclecounter();
         transform();
+        if (st && chunk < 40) st[2 + chunk * 5 + 2] = __builtin_readcyclecounter();
         __syncthreads();
+        if (st && chunk < 40) st[2 + chunk * 5 + 3] = __builtin_readcyclecounter();
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
           const int ring = cc * 4 + pi;
@@ -404,15 +430,17 @@ conv3x3_wino2_kernel(const WinoArgs a) {
               acc[pi][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[ks], acc[pi][mt], 0, 0, 0);
           }
         }
+        if (st && chunk < 40) st[2 + chunk * 5 + 4] = __builtin_readcyclecounter();
       }
     }
   }
   __syncthreads();                                 // the epilogue buffer aliases raw / V
 
   // ---- output transform, as above; one pass per M-tile
-  constexpr int kMS = 33;
-  float* Rb = lds;                                 // [4 rows i][2 k][32 tiles][kMS] = 33.8 KB
+  constexpr int kMS = 36;                          // row stride (floats): 32 couts + 4 pad (16-byte aligned rows)
+  float* Rb = lds;                                 // [4 rows i][2 k][32 tiles][kMS] = 36.9 KB
   float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+  const bool vec_ok = (a.Cout & 3) == 0;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -423,34 +451,50 @@ conv3x3_wino2_kernel(const WinoArgs a) {
       Rb[((wave * 2 + 1) * 32 + trow) * kMS + m] = (m1 - m2) - m3;
     }
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int item = it * 256 + t;
-      const int co_l = item & 31, tl = item >> 5;  // tile inside this M-tile
+    {                                              // 32 tiles x 8 cout quads = 256 items, one per lane, 16-byte loads / stores
+      const int cq = t & 7, tl = t >> 3;           // tile inside this M-tile
       const int tg = mt * 32 + tl;                 // Winograd tile 0..63 of the workgroup (8 x 8)
       const int ty2 = tg >> 3, tx2 = tg & 7;
-      const int co = n0 + co_l;
-      float rv[4][2];
+      const int co = n0 + 4 * cq;
+      float4 rv[4][2];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) rv[i][k] = Rb[((i * 2 + k) * 32 + tl) * kMS + co_l];
+        for (int k = 0; k < 2; ++k) rv[i][k] = *reinterpret_cast<const float4*>(Rb + ((i * 2 + k) * 32 + tl) * kMS + 4 * cq);
       if (co < a.Cout) {
-        const float bias = a.bias[co];
+        float bs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[e] = co + e < a.Cout ? a.bias[co + e] : 0.f;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const float y0 = (rv[0][k] + rv[1][k]) + rv[2][k];
-          const float y1 = (rv[1][k] - rv[2][k]) - rv[3][k];
+          const float* r0 = reinterpret_cast<const float*>(&rv[0][k]); const float* r1 = reinterpret_cast<const float*>(&rv[1][k]);
+          const float* r2 = reinterpret_cast<const float*>(&rv[2][k]); const float* r3 = reinterpret_cast<const float*>(&rv[3][k]);
+          float y0[4], y1[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v0 = ((r0[e] + r1[e]) + r2[e]) + bs[e];
+            float v1 = ((r1[e] - r2[e]) - r3[e]) + bs[e];
+            y0[e] = v0 > 0.f ? v0 : v0 * a.slope;
+            y1[e] = v1 > 0.f ? v1 : v1 * a.slope;
+          }
           const int ox = tile_x + 2 * tx2 + k, oy = tile_y + 2 * ty2;
           if (ox < a.w) {
-            if (oy < a.h) { float v = y0 + bias; oimg[((long long)oy * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
-            if (oy + 1 < a.h) { float v = y1 + bias; oimg[((long long)(oy + 1) * a.w + ox) * a.Cout + co] = v > 0.f ? v : v * a.slope; }
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+              if (oy + l < a.h) {
+                float* op = oimg + ((long long)(oy + l) * a.w + ox) * a.Cout + co;
+                const float* y = l ? y1 : y0;
+                if (vec_ok) *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+                else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) op[e] = y[e]; }
+              }
+            }
           }
         }
       }
     }
     if (mt == 0) __syncthreads();
   }
+  if (st) st[1] = __builtin_readcyclecounter();
 }
 
 static unsigned long long* g_wino_stamps = nullptr;
@@ -487,8 +531,14 @@ extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, cons
   a.x = x; a.wu = wu8; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
   a.CoutPad = CoutPad; a.n_chunks = (Cin + kC2 - 1) / kC2; a.slope = slope;
   a.tiles_x = (w + kT2 - 1) / kT2; a.tiles_y = (h + kT2 - 1) / kT2;
-  a.ablate = 0; a.stamps = nullptr; a.prio_shift = -1;
+  a.ablate = 0; a.stamps = g_wino_stamps; a.prio_shift = -1;
   constexpr size_t lds = (size_t)(kHP2 * kRS2 + 16 * kNT64 * kRS2) * sizeof(float);     // 15.2 + 48 KB
+  static bool attr_set = false;                    // more than 64 KB of dynamic LDS needs the opt-in
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 32)), (unsigned)b);
   hipLaunchKernelGGL(conv3x3_wino2_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();

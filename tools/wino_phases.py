@@ -9,15 +9,18 @@ h, w, cin, cout = 192, 640, 128, 128
 x = torch.randn(1, h, w, cin, device=dev)
 k = torch.randn(3, 3, cin, cout) * (2.0 / (9 * cin)) ** 0.5
 bias = torch.zeros(cout, device=dev)
-wu, cpad = nops.pack_conv_weights_winograd(k.numpy()); wud = torch.from_numpy(wu).to(dev)
-for _ in range(3): nops.conv3x3_wino_bias_act(x, wud, bias, cout, cpad, 0.1)
+V2 = len(sys.argv) > 1 and sys.argv[1] == "2"
+chunk = 8 if V2 else 16
+conv = nops.conv3x3_wino2_bias_act if V2 else nops.conv3x3_wino_bias_act
+wu, cpad = nops.pack_conv_weights_winograd(k.numpy(), chunk=chunk); wud = torch.from_numpy(wu).to(dev)
+for _ in range(3): conv(x, wud, bias, cout, cpad, 0.1)
 buf = torch.zeros(512 * 202, dtype=torch.int64, device=dev)
 lib.m4d_wino_set_stamps(ctypes.c_void_p(buf.data_ptr()))
-nops.conv3x3_wino_bias_act(x, wud, bias, cout, cpad, 0.1)
+conv(x, wud, bias, cout, cpad, 0.1)
 torch.cuda.synchronize()
 lib.m4d_wino_set_stamps(None)
 s = buf.cpu().numpy().reshape(512, 202).astype(np.int64)
-n_ch = cin // 16
+n_ch = cin // chunk
 tot = s[:, 1] - s[:, 0]
 c = s[:, 2:2 + 5 * n_ch].reshape(512, n_ch, 5)
 commit = c[:, :, 1] - c[:, :, 0]          # commit + raw-load issue + first barrier
