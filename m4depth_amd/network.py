@@ -63,14 +63,21 @@ winograd_conv = _os.environ.get("M4D_WINOGRAD", "1") == "1"
 
 def _use_winograd(b, h, w, cin, cout, stride):
     """0 = direct convolution; 1 = Winograd kernel 1 (16x8 tile, 16-channel chunks, 2 N-tiles per workgroup);
-    2 = kernel 2 (16x16 tile, 8-channel chunks: half the weight traffic per flop -- ahead on the large maps)."""
-    if not winograd_conv or stride != 1 or cin < 16 or cin % 2 != 0 or h * w < 4096:
+    2 = kernel 2 (16x16 tile, 8-channel chunks: half the weight traffic per flop -- ahead on the large maps).
+    Winograd only pays when the launch fills the chip: the thresholds are workgroup counts (measured per layer of the
+    384x1280 pyramid, profiles/r01_step_launches_b1_wino.txt: level 3 and coarser stay on the direct kernel, which can
+    split N and K further)."""
+    if not winograd_conv or stride != 1 or cin < 16 or cin % 2 != 0:
         return 0
-    if cin % 4 == 0 and cout >= 32 and h * w >= 24576:
+    n32 = -(-cout // 32)
+    if cin % 4 == 0 and b * (-(-h // 16)) * (-(-w // 16)) * n32 >= 200:
         return 2
-    if cout % 64 == 0:
+    t8 = b * (-(-h // 8)) * (-(-w // 16))
+    if cout % 64 == 0 and t8 * (cout // 64) >= 400:
         return 1
-    return 1 if (cout >= 96 and b * h * w <= 200000) else 0     # one N-tile per workgroup: only ahead on small grids
+    if cout >= 96 and 400 <= t8 * n32 <= 3000:                 # one N-tile per workgroup: only ahead on small grids
+        return 1
+    return 0
 
 
 # Frame pipeline of the decoder: level l of frame t+1 depends on level l+1 of its own frame and on
