@@ -214,7 +214,8 @@ def main():
                    "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",
                    "conv_backend": "hand-written fp32-MFMA convolutions with fused bias+leaky-relu (libm4depth_hip.so): "
                                    "Winograd F(2x2,3x3) for the wide stride-1 layers of levels 1-3, direct implicit GEMM "
-                                   "(stride 1 / 2, split-K on the coarse levels) elsewhere; 3-channel image convolution: MIOpen fp32",
+                                   "(stride 1 / 2, split-K on the coarse levels) elsewhere; encoder head (3->16 convolution + DINL) as two fused "
+                                   "HIP kernels -- no MIOpen / framework kernel in the forward",
                    "hot_path": "libm4depth_hip.so (HIP, gfx950)"},
         "AbsRel": round(metrics[0], 6), "launch": "eager" if args.eager else "hipGraph replay of the sequence forward; frames pipelined over the decoder "
                                                   "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)",

@@ -299,6 +299,17 @@ int m4d_dinl_fwd_padded(const float* x, const float* scale, const float* bias, i
 int m4d_dinl_fwd(const float* x, const float* scale, const float* bias, int b, int h, int w, int C,
                  float slope, float* workspace, float* out, void* stream);
 
+/* Encoder level 0 (FeaturePyramid.call, m4depth_network.py:79-87 with DINL): the head of the network as two calls.
+ * m4d_enc_head_fwd: conv3x3(images [b,h,w,3], w_hwio [3,3,3,16]) + bias -> raw_out [b,h,w,16], and the DINL statistics of
+ *   raw_out into workspace (n = m4d_dinl_workspace_floats(b,16) floats): mean = the b*16 floats at n - 2*b*16, var the last b*16.
+ * m4d_conv3x3s2_dinl_bias_act: the stride-2 convolution on leaky_relu(DomainNormalization(raw), dn_slope), the
+ *   normalisation fused into its input staging; wp packed as for m4d_conv3x3s_bias_act_ws (CoutPad = 32). */
+int m4d_enc_head_fwd(const float* images, const float* w_hwio, const float* bias, int b, int h, int w, int C,
+                     float* workspace, float* raw_out, void* stream);
+int m4d_conv3x3s2_dinl_bias_act(const float* x_raw, const float* mean, const float* var, const float* dn_scale,
+                                const float* dn_bias, float dn_slope, const float* wp, const float* bias,
+                                int b, int h, int w, int Cout, int CoutPad, float slope, float* out, void* stream);
+
 /* The 7 metrics of metrics.py (AbsRel, SqRel, RMSE, RMSE_log, Delta1..3) of one batch in one
  * pass, including test_step's clipping gt in [0,max_d], est in [0.001,max_d]
  * (m4depth_network.py:465-467).  gt, est: n floats; out7: 7 floats (main.py:127-130 order);

@@ -33,6 +33,9 @@ struct ConvArgs {
   float slope;
   int ksplit, chunks_per_split;       // split-K (coarse pyramid levels): partial sums -> ws, reduced in order
   float* ws;
+  // DINL variant (encoder level 0): x is the RAW first convolution; DomainNormalization + leaky_relu(dn_slope) are applied
+  // while the halo is committed to LDS (m4depth_network.py:44-48,82-84)
+  const float* dn_mean; const float* dn_var; const float* dn_scale; const float* dn_bias; float dn_slope;
   int ablate;                         // profiling only (M4D_CONV_ABLATE): 1 = no re-staging after the first stage, 2 = no MFMAs, 4 = no stores
 };
 
@@ -50,7 +53,7 @@ constexpr int kKC = 16, kRS = 20;                   // chunk size, LDS row strid
 // CU fits and fills the barrier / staging bubbles of the other two: +8 % at batch 32 (9.84 -> 9.08 ms for the
 // level-1 128->128 layer), but at batch 1 the 960 workgroups of that layer then run as 768 + 192 (a 25 %-full
 // second round) and the launch gets slower -- so the host picks MINB = 3 only for grids of >= 4 full rounds.
-template <int NT, int TS, int STRIDE, bool DB, int MINB>
+template <int NT, int TS, int STRIDE, bool DB, int MINB, bool DINL = false>
 __global__ void __launch_bounds__(256, MINB)
 conv3x3_mfma_kernel(const ConvArgs a) {
   constexpr int kHWT = (kTW - 1) * STRIDE + 3, kHHT = (kTH - 1) * STRIDE + 3, kHP = kHWT * kHHT;   // input halo: 18x10 / 33x17
@@ -92,14 +95,40 @@ conv3x3_mfma_kernel(const ConvArgs a) {
       }
     }
   };
+  // DINL: this lane always holds the same channel pair (2 * (t & 7)) of some halo pixel; the 8 lanes of a pixel
+  // are adjacent, so the per-pixel l2 norm over the 16 channels is three xor-shuffles.
+  float dn_mu[2] = {0.f, 0.f}, dn_dv[2] = {1.f, 1.f}, dn_sc[2] = {1.f, 1.f}, dn_bs[2] = {0.f, 0.f};
+  if (DINL) {
+    const int c = 2 * (t & 7);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      dn_mu[e] = a.dn_mean[bi * 16 + c + e];
+      dn_dv[e] = 1.0f / (a.dn_var[bi * 16 + c + e] + 1e-12f);   // (x - mean) / (var + 1e-12), variance not std (:47), as a multiply
+      dn_sc[e] = a.dn_scale[c + e];
+      dn_bs[e] = a.dn_bias[c + e];
+    }
+  }
   auto commit_a = [&]() {
 #pragma unroll
     for (int u = 0; u < A_PER; ++u) {
       const int idx = u * 256 + t;
       const int hp = idx >> 3, kp = idx & 7;
+      float2 v = ra[u];
+      if (DINL) {
+        const float nx = (v.x - dn_mu[0]) * dn_dv[0], ny = (v.y - dn_mu[1]) * dn_dv[1];
+        float ss = nx * nx + ny * ny;
+        ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));                          // tf.math.l2_normalize
+        float ox = dn_sc[0] * (nx * inv) + dn_bs[0], oy = dn_sc[1] * (ny * inv) + dn_bs[1];
+        ox = ox > 0.f ? ox : ox * a.dn_slope; oy = oy > 0.f ? oy : oy * a.dn_slope;
+        const int hpc = hp < kHP ? hp : kHP - 1;
+        const int gy = tile_y * STRIDE - a.pad_y + hpc / kHWT, gx = tile_x * STRIDE - a.pad_x + hpc % kHWT;
+        const bool inside = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;                  // the padding is zeros of the NORMALISED map
+        v = make_float2(inside ? ox : 0.f, inside ? oy : 0.f);
+      }
       if (idx < A_F2) {                                // even channel -> slot kp, odd channel -> slot 8 + kp
-        lds_a[hp * kRS + kp] = ra[u].x;
-        lds_a[hp * kRS + 8 + kp] = ra[u].y;
+        lds_a[hp * kRS + kp] = v.x;
+        lds_a[hp * kRS + 8 + kp] = v.y;
       }
     }
   };
@@ -343,6 +372,37 @@ extern "C" int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const fl
                                   workspace_floats, stream);
 }
 
+// Encoder level 0, second convolution: stride-2 3x3 on the DomainNormalization of x_raw (16 channels), the
+// normalisation + leaky_relu(dn_slope) fused into the halo staging.
+extern "C" int m4d_conv3x3s2_dinl_bias_act(const float* x_raw, const float* mean, const float* var, const float* dn_scale,
+                                           const float* dn_bias, float dn_slope, const float* wp, const float* bias,
+                                           int b, int h, int w, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  M4D_CHECK_ARG(x_raw && mean && var && dn_scale && dn_bias && wp && bias && out && b > 0 && h > 0 && w > 0 && Cout > 0);
+  M4D_CHECK_ARG(CoutPad == 32 && Cout <= 32);                 // one N-tile: the reference's encoder level 0 has 16 filters
+  M4D_CHECK_ARG(((((uintptr_t)x_raw) & 7u) == 0) && ((((uintptr_t)wp) & 15u) == 0));
+  ConvArgs a;
+  a.x = x_raw; a.wp = wp; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = 16; a.Cout = Cout;
+  a.CoutPad = CoutPad; a.n_chunks = 1; a.ablate = 0;
+  a.oh = (h + 1) / 2; a.ow = (w + 1) / 2;
+  const int tph = (a.oh - 1) * 2 + 3 - h, tpw = (a.ow - 1) * 2 + 3 - w;
+  a.pad_y = (tph > 0 ? tph : 0) / 2; a.pad_x = (tpw > 0 ? tpw : 0) / 2;
+  a.tiles_x = (a.ow + kTW - 1) / kTW; a.tiles_y = (a.oh + kTH - 1) / kTH; a.slope = slope;
+  a.ksplit = 1; a.chunks_per_split = 1; a.ws = nullptr;
+  a.dn_mean = mean; a.dn_var = var; a.dn_scale = dn_scale; a.dn_bias = dn_bias; a.dn_slope = dn_slope;
+  constexpr int HP = ((kTW - 1) * 2 + 3) * ((kTH - 1) * 2 + 3);
+  constexpr size_t lds = (size_t)(HP * kRS + 9 * 32 * kRS) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<1, 9, 2, false, 2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), 1, (unsigned)b);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<1, 9, 2, false, 2, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+  return M4D_LAUNCH_RESULT();
+}
+
 extern "C" int m4d_conv3x3s_bias_act_ws(const float* x, const float* wp, const float* bias, int b, int h, int w,
                                         int Cin, int Cout, int CoutPad, int stride, float slope, float* out,
                                         float* workspace, long long workspace_floats, void* stream) {
@@ -352,6 +412,7 @@ extern "C" int m4d_conv3x3s_bias_act_ws(const float* x, const float* wp, const f
   ConvArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
   a.CoutPad = CoutPad; a.n_chunks = (Cin + kKC - 1) / kKC;
+  a.dn_mean = a.dn_var = a.dn_scale = a.dn_bias = nullptr; a.dn_slope = 1.0f;
   static int ablate = -1;
   if (ablate < 0) { const char* e = getenv("M4D_CONV_ABLATE"); ablate = e ? atoi(e) : 0; }
   a.ablate = ablate;

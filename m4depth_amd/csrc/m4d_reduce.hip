@@ -103,6 +103,68 @@ dinl_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, c
   }
 }
 
+// ---- encoder level 0, first convolution: 3 -> 16 channels, stride 1, + bias, + the DINL mean partial sums ------
+// K = 27 is far too small for the matrix cores and the layer writes the largest activation of the network
+// ([b,H,W,16]) once; a direct convolution with the 27 x 16 weights read through the scalar cache.  The
+// workgroup also leaves the per-channel sums of its outputs for the DINL mean (same partial layout as
+// dinl_partial_kernel pass 0), which saves one full read of that activation.
+template <int C>
+__global__ void __launch_bounds__(256)
+enc_head_conv_kernel(const float* __restrict__ img, const float* __restrict__ w27, const float* __restrict__ bias,
+                     int h, int w, float* __restrict__ out, float* __restrict__ partial) {
+  __shared__ float sh[4][C];
+  const int bi = blockIdx.y;
+  const int hw = h * w;
+  const float* ib = img + (long long)bi * hw * 3;
+  float* ob = out + (long long)bi * hw * C;
+  float csum[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) csum[c] = 0.f;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) {
+    const int y = p / w, x = p - y * w;
+    typedef float f2 __attribute__((ext_vector_type(2)));         // packed v_pk_mul_f32 / v_pk_add_f32: two channels per op
+    f2 acc2[C / 2];
+#pragma unroll
+    for (int c = 0; c < C / 2; ++c) acc2[c] = (f2){0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = x + kx - 1;
+        const bool in = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        const float* px = ib + ((long long)(in ? yy : y) * w + (in ? xx : x)) * 3;
+        const float v0 = in ? px[0] : 0.f, v1 = in ? px[1] : 0.f, v2 = in ? px[2] : 0.f;
+        const f2* wt = reinterpret_cast<const f2*>(w27 + (ky * 3 + kx) * 3 * C);   // HWIO: [tap][cin][cout], uniform -> scalar loads
+#pragma unroll
+        for (int c = 0; c < C / 2; ++c)
+          acc2[c] = ((acc2[c] + (f2){v0, v0} * wt[c]) + (f2){v1, v1} * wt[C / 2 + c]) + (f2){v2, v2} * wt[C + c];
+      }
+    }
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C / 2; ++c) { acc[2 * c] = acc2[c].x; acc[2 * c + 1] = acc2[c].y; }
+#pragma unroll
+    for (int c = 0; c < C; c += 4) {
+      float4 o = make_float4(acc[c] + bias[c], acc[c + 1] + bias[c + 1], acc[c + 2] + bias[c + 2], acc[c + 3] + bias[c + 3]);
+      *reinterpret_cast<float4*>(ob + (long long)p * C + c) = o;
+      csum[c] += o.x; csum[c + 1] += o.y; csum[c + 2] += o.z; csum[c + 3] += o.w;
+    }
+  }
+  // fixed-order reduction: butterfly inside the wave, then the 4 waves in index order
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float v = csum[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < C)
+    partial[((long long)bi * gridDim.x + blockIdx.x) * C + threadIdx.x] =
+        ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
 // ---- metrics.py in one pass ---------------------------------------------------------
 constexpr int kMetricSums = 9;
 constexpr int kMetricBlocks = 512;
@@ -206,6 +268,29 @@ extern "C" int m4d_dinl_fwd_padded(const float* x, const float* scale, const flo
   if (gx > 2048) gx = 2048;
   if (C == 16) hipLaunchKernelGGL(dinl_apply_kernel<16>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, w, slope, out, out_h, out_w, off_y, off_x);
   else hipLaunchKernelGGL(dinl_apply_kernel<32>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, w, slope, out, out_h, out_w, off_y, off_x);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_enc_head_fwd(const float* images, const float* w_hwio, const float* bias, int b, int h, int w, int C,
+                                float* workspace, float* raw_out, void* stream) {
+  M4D_CHECK_ARG(images && w_hwio && bias && workspace && raw_out && b > 0 && h > 0 && w > 0);
+  M4D_CHECK_ARG(C == 16);                            // encoder level 0 of the reference (m4depth_network.py:59)
+  M4D_CHECK_ARG(((((uintptr_t)raw_out | (uintptr_t)workspace)) & 15u) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int hw = h * w;
+  int nblk = (hw + 256 * 8 - 1) / (256 * 8);       // (4x more, smaller workgroups: same kernel time, slower finalize)
+  if (nblk > kDinlMaxBlocks) nblk = kDinlMaxBlocks;
+  if (nblk < 1) nblk = 1;
+  float* partial = workspace;
+  float* mean = workspace + (long long)b * kDinlMaxBlocks * C;
+  float* var = mean + (long long)b * C;
+  hipLaunchKernelGGL(enc_head_conv_kernel<16>, dim3(nblk, b), dim3(256), 0, s, images, w_hwio, bias, h, w, raw_out, partial);
+  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
+  const int ppi = 256 / (C / 4);
+  int nblk2 = (hw + ppi * 8 - 1) / (ppi * 8);
+  if (nblk2 > kDinlMaxBlocks) nblk2 = kDinlMaxBlocks;
+  hipLaunchKernelGGL(dinl_partial_kernel, dim3(nblk2, b), dim3(256), 0, s, (const float*)raw_out, (const float*)mean, hw, C, 1, partial);
+  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk2, C, hw, var);
   return M4D_LAUNCH_RESULT();
 }
 

@@ -80,6 +80,11 @@ def _use_winograd(b, h, w, cin, cout, stride):
     return 0
 
 
+# Encoder level 0 as two fused kernels (direct 3->16 convolution + bias + DINL statistics; DINL apply fused into the
+# stride-2 convolution's input staging) instead of MIOpen conv + bias pass + 3 DINL passes + conv: no MIOpen kernel is
+# left in the inference path.  0 = the unfused sequence.
+fused_encoder_head = _os.environ.get("M4D_FUSED_ENCODER_HEAD", "1") == "1"
+
 # Frame pipeline of the decoder: level l of frame t+1 depends on level l+1 of its own frame and on
 # level l of frame t only, so consecutive frames of a sequence run on two HIP streams as a
 # wavefront: the launch-latency-bound coarse levels of frame t+1 execute underneath the
@@ -131,6 +136,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(self.out_channels, device=device), requires_grad=False)
         self._packed = None
         self._packed_wino = None
+        self._hwio = None
 
     def load_hwio(self, kernel, bias, device):
         """Load a TF-layout [3,3,Cin,Cout] kernel."""
@@ -139,6 +145,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.bias = torch.nn.Parameter(_to_device_f32(bias, device).contiguous(), requires_grad=False)
         self._packed = None
         self._packed_wino = None
+        self._hwio = None
 
     def _packed_weights(self):
         """(wp, CoutPad) for m4d_conv3x3_bias_act, packed once from the OIHW parameter."""
@@ -299,6 +306,18 @@ class FeaturePyramid(torch.nn.Module):
         feature_maps = as_f32(images, "images")
         outputs = []
         for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):
+            if (self.use_dinl and i == 0 and fused_encoder_head and feature_maps.is_cuda and feature_maps.shape[-1] == 3
+                    and conv_s1.out_channels == 16 and conv_s2.out_channels <= 32 and conv_s1.weight is not None):
+                # level 0 in two fused calls: conv 3->16 + bias + DINL statistics; stride-2 conv normalising its input on the fly
+                if dn_layer.scale is None:
+                    dn_layer._build(16, feature_maps.device)
+                if getattr(conv_s1, "_hwio", None) is None or conv_s1._hwio.device != conv_s1.weight.device:
+                    conv_s1._hwio = conv_s1.weight.detach().permute(2, 3, 1, 0).contiguous()
+                wp2, cpad2 = conv_s2._packed_weights()
+                feature_maps = nops.encoder_head(feature_maps, conv_s1._hwio, conv_s1.bias, dn_layer.scale, dn_layer.bias,
+                                                 wp2, conv_s2.bias, conv_s2.out_channels, cpad2, 0.1)
+                outputs.append(feature_maps)
+                continue
             if self.use_dinl and i == 0:
                 tmp = dn_layer(conv_s1(feature_maps), slope=0.1)
             else:

@@ -229,3 +229,27 @@ def conv3x3_wino2_bias_act(x, wu8, bias, cout, cout_pad, slope=0.1):
     check(lib.m4d_conv3x3_wino2_bias_act(dptr(x, "x"), dptr(wu8, "wu8"), dptr(bias, "bias"), b, h, w, cin, int(cout),
                                          int(cout_pad), float(slope), dptr(out), stream_ptr()), "m4d_conv3x3_wino2_bias_act")
     return out
+
+
+def encoder_head(images, w_hwio, bias1, dn_scale, dn_bias, wp2, bias2, cout2, cout2_pad, slope=0.1):
+    """Encoder level 0 with DINL (m4depth_network.py:79-87) in two fused calls: conv3x3(3->16) + bias + DINL statistics,
+    then the stride-2 convolution reading the raw map and normalising it on the fly.  Returns [b, h/2, w/2, cout2]."""
+    images = as_f32(images, "images")
+    b, h, w, c3 = images.shape
+    if c3 != 3:
+        raise ValueError(f"encoder_head expects RGB images, got {c3} channels")
+    C = bias1.numel()
+    ws = _workspace("dinl", 4 * int(lib.m4d_dinl_workspace_floats(b, C)), images.device)
+    raw = torch.empty((b, h, w, C), dtype=torch.float32, device=images.device)
+    check(lib.m4d_enc_head_fwd(dptr(images, "images"), dptr(w_hwio, "w_hwio"), dptr(bias1, "bias"), b, h, w, C, dptr(ws),
+                               dptr(raw), stream_ptr()), "m4d_enc_head_fwd")
+    total = int(lib.m4d_dinl_workspace_floats(b, C))     # [partials | mean b*C | var b*C]
+    mean = ws[total - 2 * b * C: total - b * C]
+    var = ws[total - b * C: total]
+    oh, ow = -(-h // 2), -(-w // 2)
+    out = torch.empty((b, oh, ow, cout2), dtype=torch.float32, device=images.device)
+    check(lib.m4d_conv3x3s2_dinl_bias_act(dptr(raw), dptr(mean), dptr(var), dptr(dn_scale.reshape(-1), "dn_scale"),
+                                          dptr(dn_bias.reshape(-1), "dn_bias"), float(slope), dptr(wp2, "wp"), dptr(bias2, "bias"),
+                                          b, h, w, int(cout2), int(cout2_pad), float(slope), dptr(out), stream_ptr()),
+          "m4d_conv3x3s2_dinl_bias_act")
+    return out
