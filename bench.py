@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--eager", action="store_true", help="do not replay the step from a hipGraph")
+    p.add_argument("--in-flight", type=int, default=1,
+                   help="independent sequence batches in flight (each on its own stream and model state); 1 = the quoted number")
     p.add_argument("--launch", default="graph", choices=["tasks", "graph"],
                    help="tasks: one hipGraph per (frame, level) task on one stream per frame; graph: one hipGraph per step")
     return p.parse_args()
@@ -166,15 +168,38 @@ def main():
     for _ in range(max(args.warmup, 1)):                 # eager warm-up: MIOpen solver search, state allocation
         model.test_step(data)
     runner = None
+    replicas = [model]
     if not args.eager:
         runner = net.TaskGraphSequence(model, data) if args.launch == "tasks" and args.seq_len > 1 else net.GraphedSequence(model, data)
         step = lambda: model.graphed_test_step(data, runner)
+        if args.in_flight > 1:
+            # Sequence batches are independent (every one starts with new_traj): keep several in flight, each with its own
+            # recurrent state, graph and stream, so that the latency-bound coarse levels at the head of one overlap with the
+            # chip-filling level-1 convolutions at the tail of the previous one.  Weights are shared read-only.
+            runners, streams = [runner], [torch.cuda.Stream() for _ in range(args.in_flight)]
+            for _ in range(args.in_flight - 1):
+                mr = M.M4Depth(nbre_levels=args.levels, dscv_range=args.dscv_range, sncv_range=args.sncv_range)
+                mr.load_numpy_weights(weights, dev)
+                mr.compile(metrics=M.default_metrics())
+                mr.test_step(data)
+                replicas.append(mr)
+                runners.append(net.GraphedSequence(mr, data))
+            counter = [0]
+
+            def step():
+                i = counter[0] % args.in_flight
+                counter[0] += 1
+                streams[i].wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(streams[i]):
+                    replicas[i].graphed_test_step(data, runners[i])
         for _ in range(args.warmup):
             step()
     else:
         step = lambda: model.test_step(data)
-    for m in model.compiled_metrics:
-        m.reset_state()
+    torch.cuda.synchronize()
+    for mr in replicas:
+        for m in mr.compiled_metrics:
+            m.reset_state()
     D.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -184,6 +209,11 @@ def main():
     D.barrier(dev)
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, dev)
+    for mr in replicas[1:]:                                                   # fold the replicas' Keras-Mean accumulators together
+        for m, m2 in zip(model.compiled_metrics, mr.compiled_metrics):
+            if m2.total is not None:
+                m.total = m2.total if m.total is None else m.total + m2.total
+                m.count += m2.count
     gathered = D.all_gather_metric_states(model.compiled_metrics, dev)       # the one collective (RCCL)
     metrics = D.reduce_metric_states(gathered).tolist()
 
@@ -217,7 +247,8 @@ def main():
                                    "(stride 1 / 2, split-K on the coarse levels) elsewhere; encoder head (3->16 convolution + DINL) as two fused "
                                    "HIP kernels -- no MIOpen / framework kernel in the forward",
                    "hot_path": "libm4depth_hip.so (HIP, gfx950)"},
-        "AbsRel": round(metrics[0], 6), "launch": "eager" if args.eager else "hipGraph replay of the sequence forward; frames pipelined over the decoder "
+        "AbsRel": round(metrics[0], 6), "sequence_batches_in_flight": args.in_flight,
+        "launch": "eager" if args.eager else "hipGraph replay of the sequence forward; frames pipelined over the decoder "
                                                   "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)",
     }
     if timer.events:

@@ -654,6 +654,21 @@ class M4Depth(torch.nn.Module):
             convs = list(lvl.disp_refiner.prep_conv_layers) + list(lvl.disp_refiner.est_d_conv_layers)
             for i, conv in enumerate(convs):
                 conv.load_hwio(weights[f"lvl.{lvl.lvl_depth}.conv.{i}.kernel"], weights[f"lvl.{lvl.lvl_depth}.conv.{i}.bias"], device)
+        return self.prepack()
+
+    def prepack(self):
+        """Build every packed weight layout a layer can be dispatched to (direct, Winograd 16 / 8-channel chunks) NOW:
+        which one is used depends on the batch and map size, packing is host work (a device-to-host copy), and that must
+        never happen lazily inside a hipGraph capture."""
+        for conv in self.modules():
+            if isinstance(conv, _Conv3x3SameTF) and conv.weight is not None and conv.weight.is_cuda:
+                cin = conv.weight.shape[1]
+                if cin >= mfma_conv_min_cin or cin == 3:
+                    conv._packed_weights()
+                if conv.stride == 1 and cin >= 16 and cin % 2 == 0:
+                    conv._packed_weights_winograd(16)
+                    if cin % 4 == 0:
+                        conv._packed_weights_winograd(8)
         return self
 
     def load_tf_checkpoint(self, prefix_or_dir, device):
