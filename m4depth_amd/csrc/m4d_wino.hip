@@ -414,16 +414,25 @@ conv3x3_wino2_kernel(const WinoArgs a) {
         if (st && chunk < 40) st[2 + chunk * 5 + 2] = __builtin_readcyclecounter();
         __syncthreads();
         if (st && chunk < 40) st[2 + chunk * 5 + 3] = __builtin_readcyclecounter();
+        // A fragments are read one position ahead of the MFMAs that use them (the LDS round trip otherwise sits in front
+        // of every 8-MFMA group), and the weight prefetch is unconditional (index clamped): no branch inside the loop.
+        float4 af[2][2];
+        af[0][0] = *reinterpret_cast<const float4*>(vlane);
+        af[0][1] = *reinterpret_cast<const float4*>(vlane + 32 * kRS2);
 #pragma unroll
         for (int pi = 0; pi < 4; ++pi) {
           const int ring = cc * 4 + pi;
           const int q = chunk * 4 + pi;
-          if (q + 6 < n_frag) load_b(q + 6, (ring + 6) % 8);
+          load_b(min(q + 6, n_frag - 1), (ring + 6) % 8);
+          if (pi + 1 < 4) {
+            af[(pi + 1) & 1][0] = *reinterpret_cast<const float4*>(vlane + ((pi + 1) * kNT64) * kRS2);
+            af[(pi + 1) & 1][1] = *reinterpret_cast<const float4*>(vlane + ((pi + 1) * kNT64 + 32) * kRS2);
+          }
           const float4 b0 = bq[ring];
           const float bv[4] = {b0.x, b0.y, b0.z, b0.w};
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
-            const float4 a0 = *reinterpret_cast<const float4*>(vlane + (pi * kNT64 + mt * 32) * kRS2);
+            const float4 a0 = af[pi & 1][mt];
             const float av[4] = {a0.x, a0.y, a0.z, a0.w};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
