@@ -153,6 +153,14 @@ int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, const float* bi
  * after the MFMA loop.  NULL switches it off. */
 void m4d_wino_set_stamps(unsigned long long* device_buffer);
 
+/* The tail of a level in one kernel: the last two DispRefiner convolutions (32 -> 16 + leaky_relu(0.1), 16 -> 5;
+ * m4depth_network.py:109-135) and m4d_level_post (:247-260).  x32 [b,h,w,32]; w6p [9][16][32] = kernel[ky][kx][k][n] as
+ * [tap][n][k]; w7p [9][16][16] likewise with rows n >= 5 zero; outputs as m4d_level_post. */
+int m4d_refiner_tail(const float* x32, const float* w6p, const float* b6, const float* w7p, const float* b7,
+                     const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
+                     int b, int h, int w, float scale, float* parallax, float* depth, float* other,
+                     float* depth_state, void* stream);
+
 /* ---- gradients of the cost volumes (train_step, m4depth_network.py:371-399) ------ */
 
 /* Backward of m4d_dscv_fwd: what tf.GradientTape derives from depth_operations.py:224-281.

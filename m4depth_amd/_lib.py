@@ -67,6 +67,8 @@ _SIGNATURES = {
     "m4d_enc_head_fwd": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
     "m4d_conv3x3s2_dinl_bias_act": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_f, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                     _c_f, _c_fp, _c_fp],
+    "m4d_refiner_tail": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
+                         _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "m4d_depth_metrics": [_c_fp, _c_fp, ctypes.c_longlong, _c_f, _c_fp, _c_fp, _c_fp],
     "m4d_level_pre": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int,
                       _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp],

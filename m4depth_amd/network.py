@@ -85,6 +85,9 @@ def _use_winograd(b, h, w, cin, cout, stride):
 # left in the inference path.  0 = the unfused sequence.
 fused_encoder_head = _os.environ.get("M4D_FUSED_ENCODER_HEAD", "1") == "1"
 
+# The last two refiner convolutions (32->16, 16->5) and the level tail in ONE kernel (csrc/m4d_tail.hip).  0 = three launches.
+fused_refiner_tail = _os.environ.get("M4D_FUSED_TAIL", "1") == "1"
+
 # Frame pipeline of the decoder: level l of frame t+1 depends on level l+1 of its own frame and on
 # level l of frame t only, so consecutive frames of a sequence run on two HIP streams as a
 # wavefront: the launch-latency-bound coarse levels of frame t+1 execute underneath the
@@ -393,6 +396,17 @@ class DepthEstimatorLevel(torch.nn.Module):
         self.depth_prev_t = None
         self._spare_f = None
 
+    def _tail_weights(self, convs):
+        """Packed weights of the fused level tail (conv 32->16, conv 16->5), built once per device."""
+        tw = getattr(self, "_tail_w", None)
+        if tw is None or tw[0].device != convs[5].weight.device:
+            k6 = convs[5].weight.detach().permute(2, 3, 1, 0).cpu().numpy()
+            k7 = convs[6].weight.detach().permute(2, 3, 1, 0).cpu().numpy()
+            w6, w7 = nops.pack_refiner_tail_weights(k6, k7)
+            dev = convs[5].weight.device
+            tw = self._tail_w = (torch.from_numpy(w6).to(dev), torch.from_numpy(w7).to(dev))
+        return tw
+
     def _vector_processing(self, f_map, out=None):
         if self.ablation.normalize_features:                                          # :179-182
             return nops.normalize_cuts(f_map, self.nbre_cuts, out=out)
@@ -465,9 +479,20 @@ class DepthEstimatorLevel(torch.nn.Module):
         self.last_f_input = f_input
         self.last_cv_inputs = (curr_f, prev_f, para_prev_t, para_prev_l, rot_t, tr, cf, cc)   # for tools/bench_kernels.py
         # "depth_estimator" (:244-260)
-        prev_out = self.disp_refiner(f_input)
-        para_curr_l, depth, other = nops.level_post(prev_out[0], rot_t, tr, {"f": cf, "c": cc}, scale,
-                                                    depth_state=self.depth_prev_t if not self.is_training else None)
+        convs = list(self.disp_refiner.prep_conv_layers) + list(self.disp_refiner.est_d_conv_layers)
+        if (fused_refiner_tail and dev.type == "cuda" and len(convs) == 7 and convs[5].weight is not None
+                and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16)):
+            x = f_input
+            for conv in convs[:5]:
+                x = conv(x, slope=0.1)
+            w6p, w7p = self._tail_weights(convs)
+            para_curr_l, depth, other = _timed("tail", self.lvl_depth, lambda: nops.refiner_tail(
+                x, w6p, convs[5].bias, w7p, convs[6].bias, rot_t, tr, {"f": cf, "c": cc}, scale,
+                depth_state=self.depth_prev_t if not self.is_training else None))
+        else:
+            prev_out = self.disp_refiner(f_input)
+            para_curr_l, depth, other = nops.level_post(prev_out[0], rot_t, tr, {"f": cf, "c": cc}, scale,
+                                                        depth_state=self.depth_prev_t if not self.is_training else None)
         if not self.is_training:
             self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
         return {"other": other, "depth": depth, "parallax": para_curr_l}
@@ -669,6 +694,12 @@ class M4Depth(torch.nn.Module):
                     conv._packed_weights_winograd(16)
                     if cin % 4 == 0:
                         conv._packed_weights_winograd(8)
+        for lvl in self.d_estimator.levels:
+            convs = list(lvl.disp_refiner.prep_conv_layers) + list(lvl.disp_refiner.est_d_conv_layers)
+            if len(convs) == 7 and convs[5].weight is not None and convs[5].weight.is_cuda \
+                    and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16):
+                lvl._tail_w = None
+                lvl._tail_weights(convs)
         return self
 
     def load_tf_checkpoint(self, prefix_or_dir, device):

@@ -253,3 +253,36 @@ def encoder_head(images, w_hwio, bias1, dn_scale, dn_bias, wp2, bias2, cout2, co
                                           b, h, w, int(cout2), int(cout2_pad), float(slope), dptr(out), stream_ptr()),
           "m4d_conv3x3s2_dinl_bias_act")
     return out
+
+
+def pack_refiner_tail_weights(k6_hwio, k7_hwio):
+    """Weights of the fused level tail (m4d_refiner_tail): conv6 [3,3,32,16] -> [9][16][32], conv7 [3,3,16,5] -> [9][16][16]
+    (output rows 5..15 zero).  numpy in, numpy out."""
+    import numpy as np
+    k6 = np.asarray(k6_hwio, np.float32)
+    k7 = np.asarray(k7_hwio, np.float32)
+    assert k6.shape == (3, 3, 32, 16) and k7.shape == (3, 3, 16, 5), (k6.shape, k7.shape)
+    w6 = np.ascontiguousarray(k6.reshape(9, 32, 16).transpose(0, 2, 1))
+    w7 = np.zeros((9, 16, 16), np.float32)
+    w7[:, :5, :] = k7.reshape(9, 16, 5).transpose(0, 2, 1)
+    return w6, w7
+
+
+def refiner_tail(x32, w6p, b6, w7p, b7, rot, trans, camera, scale, depth_state=None):
+    """conv(32->16)+lrelu, conv(16->5) and the level tail (level_post) in one launch: returns (parallax, depth, other)."""
+    x = as_f32(x32, "x32")
+    b, h, w, c = x.shape
+    if c != 32:
+        raise ValueError(f"refiner_tail expects the 32-channel refiner activation, got {c} channels")
+    rot = as_f32(rot, "rot")
+    tr = as_f32(trans, "trans").reshape(b, 3)
+    f = as_f32(camera["f"], "camera['f']").reshape(b, 2)
+    cc = as_f32(camera["c"], "camera['c']").reshape(b, 2)
+    para = torch.empty((b, h, w, 1), dtype=torch.float32, device=x.device)
+    depth = torch.empty_like(para)
+    other = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
+    check(lib.m4d_refiner_tail(dptr(x, "x32"), dptr(w6p, "w6p"), dptr(b6, "b6"), dptr(w7p, "w7p"), dptr(b7, "b7"),
+                               dptr(rot, "rot"), rot.shape[1], dptr(tr), dptr(f), dptr(cc), b, h, w, float(scale),
+                               dptr(para), dptr(depth), dptr(other), dptr(depth_state, "depth_state"), stream_ptr()),
+          "m4d_refiner_tail")
+    return para, depth, other
