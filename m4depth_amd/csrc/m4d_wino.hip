@@ -32,7 +32,6 @@ struct WinoArgs {
   int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
   float slope;
   unsigned long long* stamps;   // profiling only (m4d_wino_set_stamps): per workgroup, per chunk, 5 cycle counters of wave 0
-  int prio_shift;
   int ablate;      // profiling only (M4D_WINO_ABLATE): 1 = weights loaded once, 2 = no MFMAs, 4 = no input transform, 8 = no epilogue
 };
 
@@ -70,8 +69,8 @@ conv3x3_wino_kernel(const WinoArgs a) {
       ng = L % n_groups;
     }
   }
-  // experiment knob (M4D_WINO_PRIO): raise the wave priority of every second workgroup (by a chosen bit of its id)
-  if (a.prio_shift >= 0 && ((blockIdx.x >> a.prio_shift) & 1)) __builtin_amdgcn_s_setprio(2);
+  // (tried: s_setprio on every second workgroup, and a start-up delay to put the two workgroups of a CU in anti-phase --
+  // neither changes the kernel time)
   const int tile_y = (tile / a.tiles_x) * kTH, tile_x = (tile % a.tiles_x) * kTW;
   const int n0 = ng * BN;
   const int bi = blockIdx.y;
@@ -522,9 +521,7 @@ extern "C" int m4d_conv3x3_wino_bias_act(const float* x, const float* wu, const 
   if (ablate < 0) { const char* e = getenv("M4D_WINO_ABLATE"); ablate = e ? atoi(e) : 0; }
   a.ablate = ablate;
   a.stamps = g_wino_stamps;
-  static int prio_shift = -2;
-  if (prio_shift == -2) { const char* e = getenv("M4D_WINO_PRIO"); prio_shift = e ? atoi(e) : -1; }
-  a.prio_shift = prio_shift;
+
   hipStream_t s = (hipStream_t)stream;
   if ((CoutPad / 32) % 2 == 0) launch_wino<2>(a, s);
   else launch_wino<1>(a, s);
@@ -540,7 +537,7 @@ extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, cons
   a.x = x; a.wu = wu8; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
   a.CoutPad = CoutPad; a.n_chunks = (Cin + kC2 - 1) / kC2; a.slope = slope;
   a.tiles_x = (w + kT2 - 1) / kT2; a.tiles_y = (h + kT2 - 1) / kT2;
-  a.ablate = 0; a.stamps = g_wino_stamps; a.prio_shift = -1;
+  a.ablate = 0; a.stamps = g_wino_stamps;
   constexpr size_t lds = (size_t)(kHP2 * kRS2 + 16 * kNT64 * kRS2) * sizeof(float);     // 15.2 + 48 KB
   static bool attr_set = false;                    // more than 64 KB of dynamic LDS needs the opt-in
   if (!attr_set) {
