@@ -350,3 +350,105 @@ def test_mfma_conv3x3_bias_act(M, dev, b, h, w, cin, cout, slope, stride):
     assert err < 1e-5 * max(1.0, np.abs(ref).max()), err
     again = nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, slope, stride=stride)
     assert torch.equal(got, again)
+
+
+# ------------------------------------------------------------------ Winograd convolutions, fused tail, encoder head
+@pytest.mark.parametrize("b,h,w,cin,cout,slope", [
+    (2, 24, 40, 64, 128, 0.1),        # whole tiles
+    (1, 37, 53, 122, 96, 0.1),        # ragged tiles, K padding (122 = 7 chunks + 10), one N-tile per workgroup
+    (1, 17, 23, 32, 48, 1.0),         # N padding (48 -> 64), no activation
+    (2, 16, 16, 16, 32, 0.1),         # a single chunk
+    (1, 33, 70, 96, 64, 0.1),
+])
+def test_winograd_conv_kernel1(M, dev, b, h, w, cin, cout, slope):
+    """Winograd F(2x2,3x3) convolution (16x8 tile, 16-channel chunks) vs the oracle's direct conv2d_same.  Tolerance 1e-5 of
+    the output scale, the same as for the direct MFMA kernel (measured difference ~2e-6); deterministic."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(cin * 11 + cout)
+    x = rng.standard_normal([b, h, w, cin]).astype(F)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = (0.1 * rng.standard_normal([cout])).astype(F)
+    wu, cpad = nops.pack_conv_weights_winograd(k, chunk=16)
+    xd, wd, bd = to_dev(x, dev), to_dev(wu, dev), to_dev(bias, dev)
+    got = nops.conv3x3_wino_bias_act(xd, wd, bd, cout, cpad, slope)
+    ref = O.conv2d_same(x, k, bias, 1)
+    ref = np.where(ref > 0, ref, ref * F(slope)).astype(F)
+    err = np.max(np.abs(npy(got) - ref))
+    assert err < 1e-5 * max(1.0, np.abs(ref).max()), err
+    assert torch.equal(got, nops.conv3x3_wino_bias_act(xd, wd, bd, cout, cpad, slope))
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,slope", [
+    (2, 32, 48, 64, 128, 0.1),
+    (1, 37, 53, 124, 96, 0.1),        # ragged tiles, K padding (124 = 15 chunks + 4)
+    (1, 19, 21, 32, 40, 1.0),         # N padding, no activation
+    (2, 16, 16, 8, 32, 0.1),          # a single chunk
+    (1, 50, 90, 96, 64, 0.1),
+])
+def test_winograd_conv_kernel2(M, dev, b, h, w, cin, cout, slope):
+    """Winograd kernel 2 (16x16 tile, 8-channel chunks, two M-tiles per wave) vs the oracle; same tolerance."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(cin * 13 + cout)
+    x = rng.standard_normal([b, h, w, cin]).astype(F)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = (0.1 * rng.standard_normal([cout])).astype(F)
+    wu, cpad = nops.pack_conv_weights_winograd(k, chunk=8)
+    xd, wd, bd = to_dev(x, dev), to_dev(wu, dev), to_dev(bias, dev)
+    got = nops.conv3x3_wino2_bias_act(xd, wd, bd, cout, cpad, slope)
+    ref = O.conv2d_same(x, k, bias, 1)
+    ref = np.where(ref > 0, ref, ref * F(slope)).astype(F)
+    err = np.max(np.abs(npy(got) - ref))
+    assert err < 1e-5 * max(1.0, np.abs(ref).max()), err
+    assert torch.equal(got, nops.conv3x3_wino2_bias_act(xd, wd, bd, cout, cpad, slope))
+
+
+@pytest.mark.parametrize("b,h,w,quat", [(2, 24, 40, True), (1, 37, 53, False), (1, 6, 20, True)])
+def test_fused_refiner_tail(M, dev, b, h, w, quat):
+    """conv(32->16)+lrelu, conv(16->5) and the level tail in one kernel vs the oracle's two convolutions + the oracle's
+    exp/clip/parallax2depth: refiner output within 1e-5, parallax 2e-6 relative (expf), depth through its conditioning."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(h * w)
+    x = np.maximum(rng.standard_normal([b, h, w, 32]), -0.3).astype(F)
+    k6 = (rng.standard_normal([3, 3, 32, 16]) * np.sqrt(2.0 / (9 * 32))).astype(F)
+    k7 = (rng.standard_normal([3, 3, 16, 5]) * np.sqrt(1.0 / (9 * 16))).astype(F)
+    b6 = (0.1 * rng.standard_normal([16])).astype(F)
+    b7 = (0.1 * rng.standard_normal([5])).astype(F)
+    rot, trans = motion_np(rng, b, quat=quat)
+    cam = camera_np(b, h, w)
+    scale = F(0.5)
+    mid = O.conv2d_same(x, k6, b6, 1)
+    mid = np.where(mid > 0, mid, mid * F(0.1)).astype(F)
+    out5 = O.conv2d_same(mid, k7, b7, 1)
+    para_ref = (np.exp(np.clip(out5[..., :1], F(-7), F(7))) / scale).astype(F)
+    w6, w7 = nops.pack_refiner_tail_weights(k6, k7)
+    state = torch.zeros((b, h, w, 1), device=dev)
+    para, depth, other = nops.refiner_tail(to_dev(x, dev), to_dev(w6, dev), to_dev(b6, dev), to_dev(w7, dev), to_dev(b7, dev),
+                                           to_dev(rot, dev), to_dev(trans, dev), to_dev(cam, dev), float(scale), depth_state=state)
+    assert np.max(np.abs(npy(other) - out5[..., 1:])) < 1e-5 * max(1.0, np.abs(out5).max())
+    assert rel_err(npy(para), para_ref).max() < 3e-5                      # exp of a value known to 1e-5
+    depth_from_gpu_para = O.parallax2depth(npy(para), rot, trans, cam)    # the converter itself is bit-exact elsewhere
+    assert_bits_equal(npy(depth), depth_from_gpu_para, "depth = parallax2depth(parallax)")
+    assert torch.equal(state, depth)
+
+
+def test_fused_encoder_head(M, dev):
+    """Direct 3->16 convolution + bias + DINL statistics, and the stride-2 convolution with the DINL apply fused into its
+    staging, vs the oracle's conv -> domain_normalization -> leaky_relu -> conv(stride 2) -> leaky_relu."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(77)
+    b, h, w = 2, 36, 52
+    img = rng.random([b, h, w, 3]).astype(F)
+    k1 = (rng.standard_normal([3, 3, 3, 16]) * np.sqrt(2.0 / 27)).astype(F)
+    b1 = (0.1 * rng.standard_normal([16])).astype(F)
+    k2 = (rng.standard_normal([3, 3, 16, 16]) * np.sqrt(2.0 / 144)).astype(F)
+    b2 = (0.1 * rng.standard_normal([16])).astype(F)
+    sc = (1.0 + 0.1 * rng.standard_normal([16])).astype(F)
+    bs = (0.1 * rng.standard_normal([16])).astype(F)
+    t = O.conv2d_same(img, k1, b1, 1)
+    t = O.leaky_relu(O.domain_normalization(t, sc, bs), 0.1)
+    ref = O.leaky_relu(O.conv2d_same(t, k2, b2, 2), 0.1)
+    wp2, cpad2 = nops.pack_conv_weights(k2)
+    got = nops.encoder_head(to_dev(img, dev), to_dev(k1.reshape(27, 16).copy(), dev), to_dev(b1, dev), to_dev(sc, dev),
+                            to_dev(bs, dev), to_dev(wp2, dev), to_dev(b2, dev), 16, cpad2, 0.1)
+    err = np.max(np.abs(npy(got) - ref))
+    assert err < 2e-5 * max(1.0, np.abs(ref).max()), err
