@@ -11,12 +11,16 @@ tree (children by attribute name, list elements by index) with, per variable, th
 Variables are therefore looked up by walking ATTRIBUTE PATHS of the reference model
 (``encoder/conv_layers_s1/0/kernel`` ...), not by guessing key strings.
 
-UNPINNED: the build environment has neither TensorFlow nor any checkpoint (the reference's weights are a
-separate download), so this restates the formats from TensorFlow's sources -- core/lib/io/format.cc,
-block.cc (table), core/util/tensor_bundle (entries, string tensors), core/protobuf/tensor_bundle.proto and
-trackable_object_graph.proto -- and is tested against a writer that follows the same description
-(tests/test_tf_checkpoint.py).  Block compression is rejected loudly (the bundle writer stores index blocks
-uncompressed); crc32c fields are not verified.
+Pinning: TensorFlow cannot run here, so the formats are restated from TensorFlow's sources --
+core/lib/io/format.cc, block.cc (table), core/util/tensor_bundle (entries, string tensors),
+core/protobuf/tensor_bundle.proto and trackable_object_graph.proto.  The table / bundle-entry / tensor-data
+layers ARE pinned against files written by TensorFlow itself: the reference ships the bundles of its legacy
+model (.legacy/trained_weights/M4Depth-d6), whose index files and the head of one data file are committed
+under tests/golden/tf_legacy/; every block trailer and every tensor carries a masked crc32c written by
+TensorFlow, and the reader verifies them (tests/test_tf_checkpoint.py).  Those bundles are name-based
+(tf.train.Saver), so the object-graph walk (``lookup``) remains UNPINNED: it is tested against a writer that
+follows the same description (tests/tf_bundle_writer.py).  Block compression is rejected loudly (the bundle
+writer stores index blocks uncompressed).
 """
 from __future__ import annotations
 
@@ -74,15 +78,53 @@ def parse_proto(buf):
     return out
 
 
+def _make_crc_table():
+    table = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+        table.append(c)
+    return table
+
+
+_CRC_TABLE = _make_crc_table()
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli), the checksum of TensorFlow's core/lib/hash/crc32c.h."""
+    crc ^= 0xFFFFFFFF
+    table = _CRC_TABLE
+    for b in data:
+        crc = table[(crc ^ b) & 0xFF] ^ (crc >> 8)
+    return crc ^ 0xFFFFFFFF
+
+
+def masked_crc32c(data):
+    """crc32c::Mask: what the table trailers and BundleEntryProto.crc32c store."""
+    c = crc32c(data)
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+class ChecksumError(ValueError):
+    pass
+
+
 def _signed(v):
     return v - (1 << 64) if v >= (1 << 63) else v
 
 
 # ------------------------------------------------------------------------------ the index table
-def _read_block(data, offset, size):
-    ctype = data[offset + size]                      # 1-byte compression type, then a 4-byte crc
+def _read_block(data, offset, size, verify=True):
+    if offset + size + 5 > len(data):
+        raise ValueError("table block (%d, %d) runs past the end of the file" % (offset, size))
+    ctype = data[offset + size]                      # 1-byte compression type, then the masked crc32c of block + type
     if ctype != 0:
         raise NotImplementedError("compressed table block (type %d): tensor-bundle indexes are written uncompressed" % ctype)
+    if verify:
+        want = struct.unpack_from("<I", data, offset + size + 1)[0]
+        if masked_crc32c(data[offset:offset + size + 1]) != want:
+            raise ChecksumError("table block at offset %d: crc32c mismatch (corrupt index file)" % offset)
     return data[offset:offset + size]
 
 
@@ -101,8 +143,9 @@ def _block_entries(block):
         pos += vlen
 
 
-def read_table(path):
-    """All (key, value) pairs of a LevelDB-format table file, in key order."""
+def read_table(path, verify=True):
+    """All (key, value) pairs of a LevelDB-format table file, in key order; ``verify`` checks every block's
+    crc32c trailer."""
     with open(path, "rb") as fh:
         data = fh.read()
     if len(data) < 48:
@@ -116,26 +159,30 @@ def read_table(path):
     idx_off, pos = _varint(footer, pos)
     idx_size, pos = _varint(footer, pos)
     out = []
-    for _, handle in _block_entries(_read_block(data, idx_off, idx_size)):
+    for _, handle in _block_entries(_read_block(data, idx_off, idx_size, verify)):
         off, p = _varint(handle, 0)
         size, p = _varint(handle, p)
-        out.extend(_block_entries(_read_block(data, off, size)))
+        out.extend(_block_entries(_read_block(data, off, size, verify)))
     return out
 
 
 # ------------------------------------------------------------------------------ the bundle
 class CheckpointReader:
     """``reader = CheckpointReader(prefix)``; ``reader.keys()``, ``reader.tensor(key)``,
-    ``reader.lookup("encoder/conv_layers_s1/0/kernel")`` (attribute path from the checkpoint root)."""
+    ``reader.lookup("encoder/conv_layers_s1/0/kernel")`` (attribute path from the checkpoint root).
+    ``verify`` (default on) checks the crc32c TensorFlow stored for every index block and every tensor read;
+    ``data_path`` overrides the ``<prefix>.data-SSSSS-of-NNNNN`` naming (a format string taking shard, shards)."""
 
-    def __init__(self, prefix):
+    def __init__(self, prefix, verify=True, data_path=None):
         self.prefix = prefix
+        self.verify = verify
+        self.data_path = data_path
         index = prefix + ".index"
         if not os.path.isfile(index):
             raise FileNotFoundError(f"no checkpoint index at {index}")
         self.entries = {}
         self.num_shards = 1
-        for key, value in read_table(index):
+        for key, value in read_table(index, verify):
             if key == b"":
                 hdr = parse_proto(value)             # BundleHeaderProto: num_shards = 1, endianness = 2, version = 3
                 self.num_shards = hdr.get(1, [1])[0]
@@ -150,19 +197,23 @@ class CheckpointReader:
             if 7 in e:
                 raise NotImplementedError(f"sliced (partitioned) variable {key!r}")
             self.entries[key.decode()] = dict(dtype=e.get(1, [0])[0], shape=shape, shard=e.get(3, [0])[0],
-                                              offset=e.get(4, [0])[0], size=e.get(5, [0])[0])
+                                              offset=e.get(4, [0])[0], size=e.get(5, [0])[0],
+                                              crc32c=e.get(6, [None])[0])
         self._graph = None
 
     def keys(self):
         return sorted(self.entries)
 
     def _bytes(self, e):
-        path = "%s.data-%05d-of-%05d" % (self.prefix, e["shard"], self.num_shards)
+        path = (self.data_path or (self.prefix + ".data-%05d-of-%05d")) % (e["shard"], self.num_shards)
         with open(path, "rb") as fh:
             fh.seek(e["offset"])
             raw = fh.read(e["size"])
         if len(raw) != e["size"]:
             raise ValueError(f"{path}: truncated (wanted {e['size']} bytes at {e['offset']})")
+        if self.verify and e["crc32c"] is not None and e["dtype"] != DT_STRING:
+            if masked_crc32c(raw) != e["crc32c"]:          # string tensors checksum lengths + bytes differently
+                raise ChecksumError(f"{path}: crc32c mismatch for the tensor at offset {e['offset']} (corrupt data file)")
         return raw
 
     def tensor(self, key):

@@ -431,9 +431,21 @@ def test_fused_refiner_tail(M, dev, b, h, w, quat):
     assert torch.equal(state, depth)
 
 
-def test_fused_encoder_head(M, dev):
+def _trained_legacy_encoder_weights():
+    """The trained first two encoder levels of the reference's legacy model, read from the TensorFlow-written bundle
+    head in tests/golden/tf_legacy (same layer shapes as FeaturePyramid, m4depth_network.py:59-74)."""
+    import os
+    from m4depth_amd import tf_checkpoint as TC
+    d = os.path.join(os.path.dirname(__file__), "golden", "tf_legacy")
+    r = TC.CheckpointReader(os.path.join(d, "features"), data_path=os.path.join(d, "features.data-%05d-of-%05d"))
+    return {(l, c, p): r.tensor(f"feature_pyramid/layer_{l}/conv2d_{c}/{p}") for l in (1, 2) for c in (1, 2) for p in ("kernel", "bias")}
+
+
+@pytest.mark.parametrize("weights", ["random", "trained"])
+def test_fused_encoder_head(M, dev, weights):
     """Direct 3->16 convolution + bias + DINL statistics, and the stride-2 convolution with the DINL apply fused into its
-    staging, vs the oracle's conv -> domain_normalization -> leaky_relu -> conv(stride 2) -> leaky_relu."""
+    staging, vs the oracle's conv -> domain_normalization -> leaky_relu -> conv(stride 2) -> leaky_relu; with random
+    weights and with the trained weights of the reference's legacy encoder."""
     from m4depth_amd import network_ops as nops
     rng = np.random.default_rng(77)
     b, h, w = 2, 36, 52
@@ -442,6 +454,9 @@ def test_fused_encoder_head(M, dev):
     b1 = (0.1 * rng.standard_normal([16])).astype(F)
     k2 = (rng.standard_normal([3, 3, 16, 16]) * np.sqrt(2.0 / 144)).astype(F)
     b2 = (0.1 * rng.standard_normal([16])).astype(F)
+    if weights == "trained":
+        tw = _trained_legacy_encoder_weights()
+        k1, b1, k2, b2 = tw[1, 1, "kernel"], tw[1, 1, "bias"], tw[1, 2, "kernel"], tw[1, 2, "bias"]
     sc = (1.0 + 0.1 * rng.standard_normal([16])).astype(F)
     bs = (0.1 * rng.standard_normal([16])).astype(F)
     t = O.conv2d_same(img, k1, b1, 1)
@@ -452,3 +467,20 @@ def test_fused_encoder_head(M, dev):
                             to_dev(bs, dev), to_dev(wp2, dev), to_dev(b2, dev), 16, cpad2, 0.1)
     err = np.max(np.abs(npy(got) - ref))
     assert err < 2e-5 * max(1.0, np.abs(ref).max()), err
+
+
+def test_encoder_level_2_with_trained_weights(M, dev):
+    """16->32 stride 1 and 32->32 stride 2 (TF SAME) through the MFMA convolution with the trained weights of the
+    reference's legacy encoder (tests/golden/tf_legacy) vs the oracle."""
+    from m4depth_amd import network_ops as nops
+    tw = _trained_legacy_encoder_weights()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal([2, 45, 70, 16]).astype(F)
+    ref = O.leaky_relu(O.conv2d_same(x, tw[2, 1, "kernel"], tw[2, 1, "bias"], 1), 0.1)
+    ref = O.leaky_relu(O.conv2d_same(ref, tw[2, 2, "kernel"], tw[2, 2, "bias"], 2), 0.1)
+    t = to_dev(x, dev)
+    for c, stride in ((1, 1), (2, 2)):
+        wp, cpad = nops.pack_conv_weights(tw[2, c, "kernel"])
+        t = nops.conv3x3_bias_act(t, to_dev(wp, dev), to_dev(tw[2, c, "bias"], dev), tw[2, c, "kernel"].shape[3], cpad, 0.1, stride)
+    err = np.max(np.abs(npy(t) - ref))
+    assert t.shape == (2, 23, 35, 32) and err < 1e-5 * max(1.0, np.abs(ref).max()), err
