@@ -505,6 +505,263 @@ conv3x3_wino2_kernel(const WinoArgs a) {
   if (st) st[1] = __builtin_readcyclecounter();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variant 3 = variant 2's arithmetic (bit-identical results) with the waves of a workgroup SPECIALISED: the PMC counters
+// of variant 2 show the matrix cores busy 48 % of the time -- every wave alternates "transform the next chunk" and
+// "32 MFMAs", with two workgroup barriers per chunk, and the two resident workgroups do not stay in anti-phase.  Here a
+// workgroup is 8 waves: waves 0-3 only issue MFMAs (4 positions x 2 M-tiles x 1 N-tile each, as before), waves 4-7 only
+// stage and transform, one chunk ahead, into the other half of a double-buffered V (and a double-buffered raw halo, so
+// that the raw commit of chunk c+2 and the transform of chunk c+1 share ONE barrier per chunk with the MFMAs of chunk c).
+// One workgroup per CU (129 KB of LDS), i.e. one MFMA wave + one producer wave per SIMD.
+constexpr int kRawF = kHP2 * kRS2;               // floats per raw buffer   (15.2 KB)
+constexpr int kVF = 16 * kNT64 * kRS2;           // floats per V buffer     (48 KB)
+
+__global__ void __launch_bounds__(512)
+conv3x3_wino3_kernel(const WinoArgs a) {
+  constexpr int A_F4 = kHP2 * 2;                 // float4 loads per halo chunk (648)
+  extern __shared__ __align__(16) float lds[];
+  float* raw = lds;                              // [2][kHP2][kRS2]
+  float* V = lds + 2 * kRawF;                    // [2][16][64][kRS2]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n_tiles = a.tiles_x * a.tiles_y, n_groups = a.CoutPad / 32;
+  int tile, ng;
+  {
+    const int L = blockIdx.x;
+    if ((n_tiles & 7) == 0) {
+      const int xcd = L & 7, idx = L >> 3;
+      tile = xcd * (n_tiles >> 3) + idx / n_groups;
+      ng = idx % n_groups;
+    } else {
+      tile = L / n_groups;
+      ng = L % n_groups;
+    }
+  }
+  const int tile_y = (tile / a.tiles_x) * kT2, tile_x = (tile % a.tiles_x) * kT2;
+  const int n0 = ng * 32;
+  const int bi = blockIdx.y;
+  const int n = a.n_chunks;
+  f32x16 acc[4][2];
+  const int m = lane & 31, kh = lane >> 5;
+  // phase stamps (m4d_wino_set_stamps): lane 0 of consumer wave 0 and of producer wave 4, first 512 workgroups
+  unsigned long long* st = (a.stamps != nullptr && (t == 0 || t == 256) && blockIdx.y == 0 && blockIdx.x < 512)
+                               ? a.stamps + (long long)blockIdx.x * (5 * 40 + 2) : nullptr;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ producers
+    const int pt = t - 256;
+    __builtin_amdgcn_s_setprio(3);                 // fp32 MFMAs run on the VALU datapath: let the short producer bursts through
+    const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
+    // Raw staging: producer wave j (0..3) owns the chunks k = j (mod 4): it loads the whole 18x18x8 halo of such a chunk
+    // (11 float4 per lane) right after committing the previous one, i.e. FOUR phases before the data is needed -- the
+    // phase stamps show ~1.5 us from issue to data under load, more than one 2 k-cycle MFMA phase -- and since these are
+    // the wave's only loads, the compiler's wait-for-everything before the commit is exact.  The four sub-chunks of a
+    // 128-byte line are requested by the four waves within one phase (vector-L1 hits for three of them).
+    constexpr int A_PW = (A_F4 + 63) / 64;         // 11 float4 per lane
+    const int pw = wave - 4;
+    int pix_off[A_PW];                             // (clamped pixel) * Cin, per load slot
+    unsigned pix_valid = 0;
+#pragma unroll
+    for (int u = 0; u < A_PW; ++u) {
+      const int idx = u * 64 + lane;
+      const int hp = min(idx >> 1, kHP2 - 1);
+      const int gy = tile_y - 1 + hp / kH2, gx = tile_x - 1 + hp % kH2;
+      const bool ok = idx < A_F4 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      pix_valid |= ok ? (1u << u) : 0u;
+      pix_off[u] = (min(max(gy, 0), a.h - 1) * a.w + min(max(gx, 0), a.w - 1)) * a.Cin;
+    }
+    const int k4 = (lane & 1) * 4;
+    float4 ra[A_PW];
+    bool ra_ch_ok = true;                          // the 4 channels of this lane exist in the loaded chunk
+    auto load_raw = [&](int chunk) {               // unconditional loads (clamped), validity applied at the commit
+      const int c0 = chunk * kC2;
+      ra_ch_ok = c0 + k4 < a.Cin;
+      const float* base = ximg + min(c0 + k4, a.Cin - 4);
+#pragma unroll
+      for (int u = 0; u < A_PW; ++u) ra[u] = *reinterpret_cast<const float4*>(base + pix_off[u]);
+    };
+    auto commit_raw = [&](float* rb) {
+#pragma unroll
+      for (int u = 0; u < A_PW; ++u) {
+        const int idx = u * 64 + lane;
+        const bool ok = ((pix_valid >> u) & 1u) && ra_ch_ok;
+        const float4 v = ok ? ra[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < A_F4) *reinterpret_cast<float4*>(rb + (idx >> 1) * kRS2 + k4) = v;
+      }
+    };
+    const int tt = pt >> 2, cp = pt & 3;           // item = (Winograd tile, channel pair)
+    const int tty = tt >> 3, ttx = tt & 7;
+    auto transform = [&](const float* rb, float* vb) {
+      float2 c[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* rp = rb + ((2 * tty + i) * kH2 + 2 * ttx) * kRS2 + 2 * cp;
+        const float2 d0 = *reinterpret_cast<const float2*>(rp), d1 = *reinterpret_cast<const float2*>(rp + kRS2);
+        const float2 d2 = *reinterpret_cast<const float2*>(rp + 2 * kRS2), d3 = *reinterpret_cast<const float2*>(rp + 3 * kRS2);
+        c[i][0] = make_float2(d0.x - d2.x, d0.y - d2.y);
+        c[i][1] = make_float2(d1.x + d2.x, d1.y + d2.y);
+        c[i][2] = make_float2(d2.x - d1.x, d2.y - d1.y);
+        c[i][3] = make_float2(d1.x - d3.x, d1.y - d3.y);
+      }
+      float* vp = vb + tt * kRS2 + 2 * cp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<float2*>(vp + (0 + j) * kNT64 * kRS2) = make_float2(c[0][j].x - c[2][j].x, c[0][j].y - c[2][j].y);
+        *reinterpret_cast<float2*>(vp + (4 + j) * kNT64 * kRS2) = make_float2(c[1][j].x + c[2][j].x, c[1][j].y + c[2][j].y);
+        *reinterpret_cast<float2*>(vp + (8 + j) * kNT64 * kRS2) = make_float2(c[2][j].x - c[1][j].x, c[2][j].y - c[1][j].y);
+        *reinterpret_cast<float2*>(vp + (12 + j) * kNT64 * kRS2) = make_float2(c[1][j].x - c[3][j].x, c[1][j].y - c[3][j].y);
+      }
+    };
+    const int last = n - 1;                        // chunk indices are clamped: surplus loads are never committed
+    load_raw(min(pw, last));
+    if (pw == 0) { commit_raw(raw); load_raw(min(4, last)); }
+    __syncthreads();                               // raw(0) visible to every producer
+    transform(raw, V);
+    if (pw == 1) { if (1 < n) commit_raw(raw + kRawF); load_raw(min(5, last)); }
+    __syncthreads();                               // V(0) ready, raw(1) visible
+    // phase c (the consumers run the MFMAs of chunk c): wave (c+2)%4 commits raw(c+2) and reloads its registers with
+    // raw(c+6); everyone transforms raw(c+1) into the other half of V.
+    for (int c = 0; c < n; ++c) {
+      const int cur = c & 1;
+      if (st && c < 40) st[2 + c * 5 + 4] = __builtin_readcyclecounter();
+      if (((c + 2) & 3) == pw) {
+        if (c + 2 < n) commit_raw(raw + cur * kRawF);              // raw(c) was transformed during phase c-1
+        load_raw(min(c + 6, last));
+      }
+      if (st && c < 40) st[2 + c * 5 + 2] = __builtin_readcyclecounter();
+      if (c + 1 < n) transform(raw + (cur ^ 1) * kRawF, V + (cur ^ 1) * kVF);
+      if (st && c < 40) st[2 + c * 5 + 3] = __builtin_readcyclecounter();
+      __syncthreads();
+    }
+  } else {
+    // ------------------------------------------------------------------------------------------------ consumers
+#pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pi][mt][r] = 0.f;
+    // weights: wu[chunk][pos][CoutPad][8]; this lane reads channels 4kh..4kh+3 of cout n0 + m
+    const float* wlane = a.wu + ((long long)(4 * wave) * a.CoutPad + n0 + m) * kC2 + kh * 4;
+    const long long w_pos = (long long)a.CoutPad * kC2;
+    const long long w_chunk = 16 * w_pos;
+    const float* vlane0 = V + ((4 * wave) * kNT64 + m) * kRS2 + kh * 4;
+    float4 bq[8];
+    const int n_frag = n * 4;
+    auto load_b = [&](int q, int buf) { bq[buf] = *reinterpret_cast<const float4*>(wlane + (q >> 2) * w_chunk + (q & 3) * w_pos); };
+#pragma unroll
+    for (int q = 0; q < 6; ++q) load_b(min(q, n_frag - 1), q);
+    __syncthreads();
+    __syncthreads();
+    if (st) st[0] = __builtin_readcyclecounter();
+    for (int chunk0 = 0; chunk0 < n; chunk0 += 2) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {             // two chunks per iteration: ring index and V half are static
+        const int chunk = chunk0 + cc;
+        if (chunk < n) {
+          const float* vlane = vlane0 + cc * kVF;
+          if (st && chunk < 40) st[2 + chunk * 5 + 0] = __builtin_readcyclecounter();
+          float4 af[2][2];
+          af[0][0] = *reinterpret_cast<const float4*>(vlane);
+          af[0][1] = *reinterpret_cast<const float4*>(vlane + 32 * kRS2);
+#pragma unroll
+          for (int pi = 0; pi < 4; ++pi) {
+            const int ring = cc * 4 + pi;
+            const int q = chunk * 4 + pi;
+            load_b(min(q + 6, n_frag - 1), (ring + 6) % 8);
+            if (pi + 1 < 4) {
+              af[(pi + 1) & 1][0] = *reinterpret_cast<const float4*>(vlane + ((pi + 1) * kNT64) * kRS2);
+              af[(pi + 1) & 1][1] = *reinterpret_cast<const float4*>(vlane + ((pi + 1) * kNT64 + 32) * kRS2);
+            }
+            // One MFMA wave per SIMD: nothing else hides a stall, so the order is pinned -- the weight fragment for 6
+            // groups ahead and the A fragments of the next position are ISSUED here, then the 8 MFMAs of this position
+            // (hipcc otherwise sinks the loads to the end of the chunk and waits for them at the top of the next).
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 b0 = bq[ring];
+            const float bv[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) {
+                const float4 a0 = af[pi & 1][mt];
+                const float av[4] = {a0.x, a0.y, a0.z, a0.w};
+                acc[pi][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[ks], acc[pi][mt], 0, 0, 0);
+                // A second MFMA waiting at the issue stage for the matrix pipe blocks the SIMD's VALU port for the
+                // producer wave as well; idling here (~48 of the 64 pipe cycles) leaves the port to the producer.
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (st && chunk < 40) st[2 + chunk * 5 + 1] = __builtin_readcyclecounter();
+          __syncthreads();
+        }
+      }
+    }
+  }
+  // every wave is past the barrier that ends the last phase: raw / V are free, the epilogue buffer aliases them
+
+  // ---- output transform: the consumers hand A^T (M A) rows over through LDS, all 8 waves finish (one item each)
+  if (st && t == 0) st[1] = __builtin_readcyclecounter();
+  constexpr int kMS = 36;                          // row stride (floats): 32 couts + 4 pad (16-byte aligned rows)
+  constexpr int kRbMT = 4 * 2 * 32 * kMS;          // floats per M-tile: [4 rows i][2 k][32 tiles][kMS] = 36.9 KB
+  float* Rb = lds;
+  if (wave < 4) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0][mt][r], m1 = acc[1][mt][r], m2 = acc[2][mt][r], m3 = acc[3][mt][r];
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        Rb[mt * kRbMT + ((wave * 2 + 0) * 32 + trow) * kMS + m] = (m0 + m1) + m2;
+        Rb[mt * kRbMT + ((wave * 2 + 1) * 32 + trow) * kMS + m] = (m1 - m2) - m3;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+    const bool vec_ok = (a.Cout & 3) == 0;
+    const int mt = t >> 8, cq = t & 7, tl = (t >> 3) & 31;
+    const int tg = mt * 32 + tl;                   // Winograd tile 0..63 of the workgroup (8 x 8)
+    const int ty2 = tg >> 3, tx2 = tg & 7;
+    const int co = n0 + 4 * cq;
+    float4 rv[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) rv[i][k] = *reinterpret_cast<const float4*>(Rb + mt * kRbMT + ((i * 2 + k) * 32 + tl) * kMS + 4 * cq);
+    if (co < a.Cout) {
+      float bs[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bs[e] = co + e < a.Cout ? a.bias[co + e] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float* r0 = reinterpret_cast<const float*>(&rv[0][k]); const float* r1 = reinterpret_cast<const float*>(&rv[1][k]);
+        const float* r2 = reinterpret_cast<const float*>(&rv[2][k]); const float* r3 = reinterpret_cast<const float*>(&rv[3][k]);
+        float y0[4], y1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v0 = ((r0[e] + r1[e]) + r2[e]) + bs[e];
+          float v1 = ((r1[e] - r2[e]) - r3[e]) + bs[e];
+          y0[e] = v0 > 0.f ? v0 : v0 * a.slope;
+          y1[e] = v1 > 0.f ? v1 : v1 * a.slope;
+        }
+        const int ox = tile_x + 2 * tx2 + k, oy = tile_y + 2 * ty2;
+        if (ox < a.w) {
+#pragma unroll
+          for (int l = 0; l < 2; ++l) {
+            if (oy + l < a.h) {
+              float* op = oimg + ((long long)(oy + l) * a.w + ox) * a.Cout + co;
+              const float* y = l ? y1 : y0;
+              if (vec_ok) *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+              else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) op[e] = y[e]; }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 static unsigned long long* g_wino_stamps = nullptr;
 extern "C" void m4d_wino_set_stamps(unsigned long long* device_buffer) { g_wino_stamps = device_buffer; }
 
@@ -546,6 +803,19 @@ extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, cons
     attr_set = true;
   }
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 32)), (unsigned)b);
+  static int variant = -1;                         // M4D_WINO_VARIANT=3: the wave-specialised experiment (same results, bit for bit, slower)
+  if (variant < 0) { const char* e = getenv("M4D_WINO_VARIANT"); variant = e ? atoi(e) : 2; }
+  if (variant == 3) {
+    constexpr size_t lds3 = (size_t)(2 * kRawF + 2 * kVF) * sizeof(float);              // 30.4 + 96 KB
+    static bool attr3_set = false;
+    if (!attr3_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      attr3_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wino3_kernel, grid, dim3(512), lds3, (hipStream_t)stream, a);
+    return M4D_LAUNCH_RESULT();
+  }
   hipLaunchKernelGGL(conv3x3_wino2_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

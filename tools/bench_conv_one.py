@@ -8,17 +8,24 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1); ap.add_argument("--cin", type=int, default=128)
 ap.add_argument("--cout", type=int, default=128); ap.add_argument("--h", type=int, default=192)
 ap.add_argument("--w", type=int, default=640); ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--winograd", type=int, default=0, help="0 = direct MFMA kernel, 1 / 2 = Winograd kernel 1 / 2")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 x = torch.randn(a.batch, a.h, a.w, a.cin, device=dev)
 k = torch.randn(3, 3, a.cin, a.cout) * (2.0 / (9 * a.cin)) ** 0.5
 bias = torch.randn(a.cout, device=dev) * 0.1
-wp, cpad = nops.pack_conv_weights(k.numpy()); wpd = torch.from_numpy(wp).to(dev)
-for _ in range(3): nops.conv3x3_bias_act(x, wpd, bias, a.cout, cpad, 0.1)
+if a.winograd:
+    wp, cpad = nops.pack_conv_weights_winograd(k.numpy(), chunk=8 if a.winograd == 2 else 16)
+    fn = nops.conv3x3_wino2_bias_act if a.winograd == 2 else nops.conv3x3_wino_bias_act
+else:
+    wp, cpad = nops.pack_conv_weights(k.numpy())
+    fn = nops.conv3x3_bias_act
+wpd = torch.from_numpy(wp).to(dev)
+for _ in range(3): fn(x, wpd, bias, a.cout, cpad, 0.1)
 torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(a.iters): nops.conv3x3_bias_act(x, wpd, bias, a.cout, cpad, 0.1)
+for _ in range(a.iters): fn(x, wpd, bias, a.cout, cpad, 0.1)
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / a.iters
 fl = 2 * 9 * a.cin * a.cout * a.h * a.w * a.batch

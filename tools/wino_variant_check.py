@@ -1,0 +1,34 @@
+"""Winograd kernel 2 (M4D_WINO_VARIANT=2) vs the wave-specialised kernel 3 (default): run once per variant with
+--save, then --compare: the outputs must be bit-identical (same arithmetic, same order)."""
+import argparse, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from m4depth_amd import network_ops as nops
+ap = argparse.ArgumentParser()
+ap.add_argument("--save"); ap.add_argument("--compare", nargs=2)
+a = ap.parse_args()
+if a.compare:
+    x, y = torch.load(a.compare[0]), torch.load(a.compare[1])
+    for k in x:
+        same = torch.equal(x[k].view(torch.int32), y[k].view(torch.int32))
+        print(k, "bit-identical" if same else f"DIFFERENT max {(x[k] - y[k]).abs().max().item():.3e}")
+    sys.exit(0)
+dev = torch.device("cuda:0")
+out = {}
+g = torch.Generator().manual_seed(3)
+for (b, h, w, cin, cout) in [(1, 192, 640, 128, 128), (2, 96, 320, 124, 96), (1, 37, 53, 8, 40), (1, 50, 70, 20, 128), (3, 16, 16, 4, 32)]:
+    x = torch.randn(b, h, w, cin, generator=g).to(dev)
+    k = torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    wu8, cpad = nops.pack_conv_weights_winograd(k.numpy(), chunk=8)
+    wud = torch.from_numpy(wu8).to(dev)
+    y = nops.conv3x3_wino2_bias_act(x, wud, bias, cout, cpad, 0.1)
+    for _ in range(3): nops.conv3x3_wino2_bias_act(x, wud, bias, cout, cpad, 0.1)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): nops.conv3x3_wino2_bias_act(x, wud, bias, cout, cpad, 0.1)
+    e1.record(); torch.cuda.synchronize()
+    print(f"b={b} {h}x{w} {cin}->{cout}: {e0.elapsed_time(e1) * 100:.1f} us", flush=True)
+    out[f"{b}x{h}x{w}x{cin}->{cout}"] = y.cpu()
+torch.save(out, a.save)
