@@ -292,6 +292,8 @@ constexpr int kHP2 = kH2 * kH2;                  // 324 halo pixels
 constexpr int kC2 = 8;                           // channels per chunk
 constexpr int kRS2 = 12;                         // LDS row stride (floats): 8 + 4 pad (48 B: conflict-free 16-byte reads)
 constexpr int kNT64 = 64;                        // Winograd tiles per workgroup (8 x 8) = two MFMA M-tiles
+constexpr int kWSkew = 64;                       // floats of padding after each position block of the packed weights: the
+                                                 // 16 position blocks of a chunk then start on different L2 channels
 
 __global__ void __launch_bounds__(256, 2)
 conv3x3_wino2_kernel(const WinoArgs a) {
@@ -380,9 +382,9 @@ conv3x3_wino2_kernel(const WinoArgs a) {
 
   const int m = lane & 31, kh = lane >> 5;
   // weights: wu[chunk][pos][CoutPad][8]; this lane reads channels 4kh..4kh+3 of cout n0 + m
-  const float* wlane = a.wu + ((long long)(4 * wave) * a.CoutPad + n0 + m) * kC2 + kh * 4;
-  const long long w_pos = (long long)a.CoutPad * kC2;
+  const long long w_pos = (long long)a.CoutPad * kC2 + kWSkew;
   const long long w_chunk = 16 * w_pos;
+  const float* wlane = a.wu + (4 * wave) * w_pos + (n0 + m) * kC2 + kh * 4;
   const float* vlane = V + ((4 * wave) * kNT64 + m) * kRS2 + kh * 4;
 
   float4 bq[8];
@@ -506,25 +508,38 @@ conv3x3_wino2_kernel(const WinoArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Variant 3 = variant 2's arithmetic (bit-identical results) with the waves of a workgroup SPECIALISED: the PMC counters
-// of variant 2 show the matrix cores busy 48 % of the time -- every wave alternates "transform the next chunk" and
-// "32 MFMAs", with two workgroup barriers per chunk, and the two resident workgroups do not stay in anti-phase.  Here a
-// workgroup is 8 waves: waves 0-3 only issue MFMAs (4 positions x 2 M-tiles x 1 N-tile each, as before), waves 4-7 only
-// stage and transform, one chunk ahead, into the other half of a double-buffered V (and a double-buffered raw halo, so
-// that the raw commit of chunk c+2 and the transform of chunk c+1 share ONE barrier per chunk with the MFMAs of chunk c).
-// One workgroup per CU (129 KB of LDS), i.e. one MFMA wave + one producer wave per SIMD.
+// (Tried, measured, removed -- git history has it: "variant 3", the same arithmetic with the waves of a 512-thread
+// workgroup SPECIALISED, 4 waves issuing only MFMAs and 4 waves only staging + transforming one chunk ahead into a
+// double-buffered V.  Bit-identical, 15 % slower.  The phase stamps show why: while a wave streams fp32 MFMAs, a second
+// wave on the same SIMD gets one or two VALU instructions issued per MFMA (64 cycles) -- fp32 MFMA runs at the VALU
+// fp32 rate and evidently on the same issue port -- so the ~100-instruction producer stretched to the length of the MFMA
+// phase and the barrier made the phases add up instead of overlapping; wave priorities and padding the MFMA stream
+// with s_nop changed nothing.  Loads issued four phases ahead made no difference either: it is issue, not latency.)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Variant 4 = variant 2's arithmetic (bit-identical results), restructured around what the stamps and counters say
+// limits variant 2 (matrix cores busy 48 %): not the amount of VALU work but the phases in which NO wave of a SIMD has
+// an MFMA to issue -- two barriers per chunk with the LDS-read -> transform -> LDS-write chain between them.  Here
+//   * V is double buffered and the transform of chunk c+1 is issued by every wave BETWEEN ITS OWN MFMA groups of chunk
+//     c (pinned with sched_barrier): one barrier per chunk, and the transform's LDS latencies sit under MFMAs;
+//   * a workgroup is 8 waves = 4 position rows x TWO N-tiles (64 couts): the transformed tile is used twice, each
+//     wave transforms half an item (8 of the 16 positions), and both waves of a SIMD are always in the same phase;
+//   * raw halo double buffered as well: commit of chunk c+2 and loads of chunk c+3 ride in the same phase.
+// One workgroup per CU (126 KB of LDS in the K loop, 147 KB for the epilogue staging).  Needs CoutPad % 64 == 0.
 constexpr int kRawF = kHP2 * kRS2;               // floats per raw buffer   (15.2 KB)
 constexpr int kVF = 16 * kNT64 * kRS2;           // floats per V buffer     (48 KB)
 
 __global__ void __launch_bounds__(512)
-conv3x3_wino3_kernel(const WinoArgs a) {
+conv3x3_wino4_kernel(const WinoArgs a) {
   constexpr int A_F4 = kHP2 * 2;                 // float4 loads per halo chunk (648)
   extern __shared__ __align__(16) float lds[];
   float* raw = lds;                              // [2][kHP2][kRS2]
   float* V = lds + 2 * kRawF;                    // [2][16][64][kRS2]
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int n_tiles = a.tiles_x * a.tiles_y, n_groups = a.CoutPad / 32;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);           // scalar: everything derived from it stays off the VALU
+  const int pr = wave & 3, nt = wave >> 2;       // position row, N-tile of this wave
+  const int n_tiles = a.tiles_x * a.tiles_y, n_groups = a.CoutPad / 64;
   int tile, ng;
   {
     const int L = blockIdx.x;
@@ -538,197 +553,227 @@ conv3x3_wino3_kernel(const WinoArgs a) {
     }
   }
   const int tile_y = (tile / a.tiles_x) * kT2, tile_x = (tile % a.tiles_x) * kT2;
-  const int n0 = ng * 32;
+  const int n0 = ng * 64 + nt * 32;
   const int bi = blockIdx.y;
-  const int n = a.n_chunks;
-  f32x16 acc[4][2];
-  const int m = lane & 31, kh = lane >> 5;
-  // phase stamps (m4d_wino_set_stamps): lane 0 of consumer wave 0 and of producer wave 4, first 512 workgroups
-  unsigned long long* st = (a.stamps != nullptr && (t == 0 || t == 256) && blockIdx.y == 0 && blockIdx.x < 512)
-                               ? a.stamps + (long long)blockIdx.x * (5 * 40 + 2) : nullptr;
+  const int n = a.n_chunks, last = n - 1;
+  const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
 
-  if (wave >= 4) {
-    // ------------------------------------------------------------------------------------------------ producers
-    const int pt = t - 256;
-    __builtin_amdgcn_s_setprio(3);                 // fp32 MFMAs run on the VALU datapath: let the short producer bursts through
-    const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
-    // Raw staging: producer wave j (0..3) owns the chunks k = j (mod 4): it loads the whole 18x18x8 halo of such a chunk
-    // (11 float4 per lane) right after committing the previous one, i.e. FOUR phases before the data is needed -- the
-    // phase stamps show ~1.5 us from issue to data under load, more than one 2 k-cycle MFMA phase -- and since these are
-    // the wave's only loads, the compiler's wait-for-everything before the commit is exact.  The four sub-chunks of a
-    // 128-byte line are requested by the four waves within one phase (vector-L1 hits for three of them).
-    constexpr int A_PW = (A_F4 + 63) / 64;         // 11 float4 per lane
-    const int pw = wave - 4;
-    int pix_off[A_PW];                             // (clamped pixel) * Cin, per load slot
-    unsigned pix_valid = 0;
-#pragma unroll
-    for (int u = 0; u < A_PW; ++u) {
-      const int idx = u * 64 + lane;
+  // ---- raw staging: 648 float4 per chunk over 512 threads (slot 1 only for t < 136); pixel part hoisted
+  const int k4 = (t & 1) * 4;
+  int pix_off0, pix_off1;
+  bool pix_ok0, pix_ok1;
+  {
+    auto pixel = [&](int idx, int& off, bool& ok) {
       const int hp = min(idx >> 1, kHP2 - 1);
       const int gy = tile_y - 1 + hp / kH2, gx = tile_x - 1 + hp % kH2;
-      const bool ok = idx < A_F4 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-      pix_valid |= ok ? (1u << u) : 0u;
-      pix_off[u] = (min(max(gy, 0), a.h - 1) * a.w + min(max(gx, 0), a.w - 1)) * a.Cin;
-    }
-    const int k4 = (lane & 1) * 4;
-    float4 ra[A_PW];
-    bool ra_ch_ok = true;                          // the 4 channels of this lane exist in the loaded chunk
-    auto load_raw = [&](int chunk) {               // unconditional loads (clamped), validity applied at the commit
-      const int c0 = chunk * kC2;
-      ra_ch_ok = c0 + k4 < a.Cin;
+      ok = idx < A_F4 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      off = (min(max(gy, 0), a.h - 1) * a.w + min(max(gx, 0), a.w - 1)) * a.Cin;
+    };
+    pixel(t, pix_off0, pix_ok0);
+    pixel(512 + t, pix_off1, pix_ok1);
+  }
+  const int raw_dst0 = (t >> 1) * kRS2 + k4;                           // slot 0: hp = t >> 1
+  const int raw_dst1 = min((512 + t) >> 1, kHP2 - 1) * kRS2 + k4;      // slot 1: hp = 256 + (t >> 1)
+  const bool slot1 = t < A_F4 - 512;
+  // VALU instructions are not free next to fp32 MFMAs (same issue port): the common case -- the whole halo inside the
+  // image, a full 8-channel chunk -- is a uniform base + a hoisted 32-bit lane offset, and a plain store at the commit
+  const bool interior = tile_y >= 1 && tile_x >= 1 && tile_y + kT2 + 1 <= a.h && tile_x + kT2 + 1 <= a.w;
+  const unsigned voff0 = (unsigned)(pix_off0 + k4) * 4u, voff1 = (unsigned)(pix_off1 + k4) * 4u;     // bytes
+  float4 ra0, ra1;
+  auto load_raw = [&](int chunk) {               // unconditional (clamped) loads, validity applied at the commit
+    const int c0 = chunk * kC2;
+    if (c0 + kC2 <= a.Cin) {
+      const char* base = reinterpret_cast<const char*>(ximg) + (size_t)c0 * 4;
+      ra0 = *reinterpret_cast<const float4*>(base + voff0);
+      ra1 = *reinterpret_cast<const float4*>(base + voff1);
+    } else {
       const float* base = ximg + min(c0 + k4, a.Cin - 4);
+      ra0 = *reinterpret_cast<const float4*>(base + pix_off0);
+      ra1 = *reinterpret_cast<const float4*>(base + pix_off1);
+    }
+  };
+  auto commit_raw = [&](float* rb, int chunk) {  // chunk = the one the registers hold (no state carried from the load)
+    const int c0 = chunk * kC2;
+    if (interior && c0 + kC2 <= a.Cin) {
+      *reinterpret_cast<float4*>(rb + raw_dst0) = ra0;
+      if (slot1) *reinterpret_cast<float4*>(rb + raw_dst1) = ra1;
+    } else {
+      const bool ch_ok = c0 + k4 < a.Cin;
+      const bool ok0 = pix_ok0 && ch_ok, ok1 = pix_ok1 && ch_ok;
+      *reinterpret_cast<float4*>(rb + raw_dst0) = make_float4(ok0 ? ra0.x : 0.f, ok0 ? ra0.y : 0.f, ok0 ? ra0.z : 0.f, ok0 ? ra0.w : 0.f);
+      if (slot1)
+        *reinterpret_cast<float4*>(rb + raw_dst1) = make_float4(ok1 ? ra1.x : 0.f, ok1 ? ra1.y : 0.f, ok1 ? ra1.z : 0.f, ok1 ? ra1.w : 0.f);
+    }
+  };
+
+  // ---- input transform: item = (Winograd tile, channel pair) on t & 255; waves 0-3 (hf = 0) produce positions 0-7
+  // (rows 0, 1 of B^T (d B)) from input rows 0-2, waves 4-7 positions 8-15 (rows 2, 3) from input rows 1-3
+  const int ti = t & 255;
+  const int tt = ti >> 2, cp = ti & 3;
+  const int tty = tt >> 3, ttx = tt & 7;
+  const int hf = nt;                             // scalar
+  const int raw_src = ((2 * tty + hf) * kH2 + 2 * ttx) * kRS2 + 2 * cp;
+  const int v_dst = tt * kRS2 + 2 * cp + hf * 8 * kNT64 * kRS2;
+  float2 d[3][4];
+  auto read_raw = [&](const float* rb) {
 #pragma unroll
-      for (int u = 0; u < A_PW; ++u) ra[u] = *reinterpret_cast<const float4*>(base + pix_off[u]);
-    };
-    auto commit_raw = [&](float* rb) {
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int u = 0; u < A_PW; ++u) {
-        const int idx = u * 64 + lane;
-        const bool ok = ((pix_valid >> u) & 1u) && ra_ch_ok;
-        const float4 v = ok ? ra[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < A_F4) *reinterpret_cast<float4*>(rb + (idx >> 1) * kRS2 + k4) = v;
-      }
-    };
-    const int tt = pt >> 2, cp = pt & 3;           // item = (Winograd tile, channel pair)
-    const int tty = tt >> 3, ttx = tt & 7;
-    auto transform = [&](const float* rb, float* vb) {
-      float2 c[4][4];
+      for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const float2*>(rb + raw_src + (i * kH2 + j) * kRS2);
+  };
+  auto sub2 = [](float2 x, float2 y) { return make_float2(x.x - y.x, x.y - y.y); };
+  auto add2 = [](float2 x, float2 y) { return make_float2(x.x + y.x, x.y + y.y); };
+  auto transform_write = [&](float* vb) {        // c = d B per input row, then two rows of B^T c
+    float2 c[3][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* rp = rb + ((2 * tty + i) * kH2 + 2 * ttx) * kRS2 + 2 * cp;
-        const float2 d0 = *reinterpret_cast<const float2*>(rp), d1 = *reinterpret_cast<const float2*>(rp + kRS2);
-        const float2 d2 = *reinterpret_cast<const float2*>(rp + 2 * kRS2), d3 = *reinterpret_cast<const float2*>(rp + 3 * kRS2);
-        c[i][0] = make_float2(d0.x - d2.x, d0.y - d2.y);
-        c[i][1] = make_float2(d1.x + d2.x, d1.y + d2.y);
-        c[i][2] = make_float2(d2.x - d1.x, d2.y - d1.y);
-        c[i][3] = make_float2(d1.x - d3.x, d1.y - d3.y);
-      }
-      float* vp = vb + tt * kRS2 + 2 * cp;
+    for (int i = 0; i < 3; ++i) {
+      c[i][0] = sub2(d[i][0], d[i][2]);
+      c[i][1] = add2(d[i][1], d[i][2]);
+      c[i][2] = sub2(d[i][2], d[i][1]);
+      c[i][3] = sub2(d[i][1], d[i][3]);
+    }
+    float* vp = vb + v_dst;
+    if (hf == 0) {                               // c[0..2] = rows 0, 1, 2
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<float2*>(vp + (0 + j) * kNT64 * kRS2) = make_float2(c[0][j].x - c[2][j].x, c[0][j].y - c[2][j].y);
-        *reinterpret_cast<float2*>(vp + (4 + j) * kNT64 * kRS2) = make_float2(c[1][j].x + c[2][j].x, c[1][j].y + c[2][j].y);
-        *reinterpret_cast<float2*>(vp + (8 + j) * kNT64 * kRS2) = make_float2(c[2][j].x - c[1][j].x, c[2][j].y - c[1][j].y);
-        *reinterpret_cast<float2*>(vp + (12 + j) * kNT64 * kRS2) = make_float2(c[1][j].x - c[3][j].x, c[1][j].y - c[3][j].y);
+        *reinterpret_cast<float2*>(vp + (0 + j) * kNT64 * kRS2) = sub2(c[0][j], c[2][j]);
+        *reinterpret_cast<float2*>(vp + (4 + j) * kNT64 * kRS2) = add2(c[1][j], c[2][j]);
       }
-    };
-    const int last = n - 1;                        // chunk indices are clamped: surplus loads are never committed
-    load_raw(min(pw, last));
-    if (pw == 0) { commit_raw(raw); load_raw(min(4, last)); }
-    __syncthreads();                               // raw(0) visible to every producer
-    transform(raw, V);
-    if (pw == 1) { if (1 < n) commit_raw(raw + kRawF); load_raw(min(5, last)); }
-    __syncthreads();                               // V(0) ready, raw(1) visible
-    // phase c (the consumers run the MFMAs of chunk c): wave (c+2)%4 commits raw(c+2) and reloads its registers with
-    // raw(c+6); everyone transforms raw(c+1) into the other half of V.
-    for (int c = 0; c < n; ++c) {
-      const int cur = c & 1;
-      if (st && c < 40) st[2 + c * 5 + 4] = __builtin_readcyclecounter();
-      if (((c + 2) & 3) == pw) {
-        if (c + 2 < n) commit_raw(raw + cur * kRawF);              // raw(c) was transformed during phase c-1
-        load_raw(min(c + 6, last));
+    } else {                                     // c[0..2] = rows 1, 2, 3
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<float2*>(vp + (0 + j) * kNT64 * kRS2) = sub2(c[1][j], c[0][j]);     // positions 8 + j:  c2 - c1
+        *reinterpret_cast<float2*>(vp + (4 + j) * kNT64 * kRS2) = sub2(c[0][j], c[2][j]);     // positions 12 + j: c1 - c3
       }
-      if (st && c < 40) st[2 + c * 5 + 2] = __builtin_readcyclecounter();
-      if (c + 1 < n) transform(raw + (cur ^ 1) * kRawF, V + (cur ^ 1) * kVF);
-      if (st && c < 40) st[2 + c * 5 + 3] = __builtin_readcyclecounter();
-      __syncthreads();
     }
-  } else {
-    // ------------------------------------------------------------------------------------------------ consumers
+  };
+
+  f32x16 acc[4][2];
 #pragma unroll
-    for (int pi = 0; pi < 4; ++pi)
+  for (int pi = 0; pi < 4; ++pi)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pi][mt][r] = 0.f;
-    // weights: wu[chunk][pos][CoutPad][8]; this lane reads channels 4kh..4kh+3 of cout n0 + m
-    const float* wlane = a.wu + ((long long)(4 * wave) * a.CoutPad + n0 + m) * kC2 + kh * 4;
-    const long long w_pos = (long long)a.CoutPad * kC2;
-    const long long w_chunk = 16 * w_pos;
-    const float* vlane0 = V + ((4 * wave) * kNT64 + m) * kRS2 + kh * 4;
-    float4 bq[8];
-    const int n_frag = n * 4;
-    auto load_b = [&](int q, int buf) { bq[buf] = *reinterpret_cast<const float4*>(wlane + (q >> 2) * w_chunk + (q & 3) * w_pos); };
+      for (int r = 0; r < 16; ++r) acc[pi][mt][r] = 0.f;
+
+  const int m = lane & 31, kh = lane >> 5;
+  // weights: wu[chunk][pos][CoutPad][8]; this lane reads channels 4kh..4kh+3 of cout n0 + m
+  const long long w_pos = (long long)a.CoutPad * kC2 + kWSkew;
+  const long long w_chunk = 16 * w_pos;
+  const char* wbase = reinterpret_cast<const char*>(a.wu + (4 * pr) * w_pos + (long long)n0 * kC2);    // uniform
+  const unsigned wlane_off = (unsigned)((m * kC2 + kh * 4) * 4);                                        // bytes, per lane
+  const float* vlane0 = V + ((4 * pr) * kNT64 + m) * kRS2 + kh * 4;
+  float4 bq[8];
+  const int n_frag = n * 4;
+  auto load_b = [&](int q, int buf) {
+    bq[buf] = *reinterpret_cast<const float4*>(wbase + ((q >> 2) * w_chunk + (q & 3) * w_pos) * 4 + wlane_off);
+  };
+
+  // phase stamps (m4d_wino_set_stamps): thread 0 of the first 512 workgroups
+  unsigned long long* st = (a.stamps != nullptr && t == 0 && blockIdx.y == 0 && blockIdx.x < 512)
+                               ? a.stamps + (long long)blockIdx.x * (5 * 40 + 2) : nullptr;
+  if (st) st[0] = __builtin_readcyclecounter();
+  // ---- prologue: raw(0) -> V(0), raw(1) committed, raw(2) in registers
+  load_raw(0);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) load_b(min(q, n_frag - 1), q);
-    __syncthreads();
-    __syncthreads();
-    if (st) st[0] = __builtin_readcyclecounter();
-    for (int chunk0 = 0; chunk0 < n; chunk0 += 2) {
+  for (int q = 0; q < 6; ++q) load_b(min(q, n_frag - 1), q);
+  commit_raw(raw, 0);
+  load_raw(min(1, last));
+  __syncthreads();
+  read_raw(raw);
+  transform_write(V);
+  commit_raw(raw + kRawF, min(1, last));
+  load_raw(min(2, last));
+  __syncthreads();
+
+  for (int chunk0 = 0; chunk0 < n; chunk0 += 2) {
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {             // two chunks per iteration: ring index and V half are static
-        const int chunk = chunk0 + cc;
-        if (chunk < n) {
-          const float* vlane = vlane0 + cc * kVF;
-          if (st && chunk < 40) st[2 + chunk * 5 + 0] = __builtin_readcyclecounter();
-          float4 af[2][2];
-          af[0][0] = *reinterpret_cast<const float4*>(vlane);
-          af[0][1] = *reinterpret_cast<const float4*>(vlane + 32 * kRS2);
+    for (int cc = 0; cc < 2; ++cc) {               // two chunks per iteration: ring index and buffer parity are static
+      const int chunk = chunk0 + cc;
+      if (chunk < n) {
+        const float* vlane = vlane0 + cc * kVF;
+        const float* raw_next = raw + (cc ^ 1) * kRawF;    // raw(chunk + 1), committed during the previous phase
+        float* raw_free = raw + cc * kRawF;                // raw(chunk) was transformed during the previous phase
+        float* v_next = V + (cc ^ 1) * kVF;
+        if (st && chunk < 40) st[2 + chunk * 5 + 0] = __builtin_readcyclecounter();
+        float4 af[2][2];
+        af[0][0] = *reinterpret_cast<const float4*>(vlane);
+        af[0][1] = *reinterpret_cast<const float4*>(vlane + 32 * kRS2);
 #pragma unroll
-          for (int pi = 0; pi < 4; ++pi) {
-            const int ring = cc * 4 + pi;
-            const int q = chunk * 4 + pi;
-            load_b(min(q + 6, n_frag - 1), (ring + 6) % 8);
-            if (pi + 1 < 4) {
-              af[(pi + 1) & 1][0] = *reinterpret_cast<const float4*>(vlane + ((pi + 1) * kNT64) * kRS2);
-              af[(pi + 1) & 1][1] = *reinterpret_cast<const float4*>(vlane + ((pi + 1) * kNT64 + 32) * kRS2);
-            }
-            // One MFMA wave per SIMD: nothing else hides a stall, so the order is pinned -- the weight fragment for 6
-            // groups ahead and the A fragments of the next position are ISSUED here, then the 8 MFMAs of this position
-            // (hipcc otherwise sinks the loads to the end of the chunk and waits for them at the top of the next).
-            __builtin_amdgcn_sched_barrier(0);
-            const float4 b0 = bq[ring];
-            const float bv[4] = {b0.x, b0.y, b0.z, b0.w};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-              for (int mt = 0; mt < 2; ++mt) {
-                const float4 a0 = af[pi & 1][mt];
-                const float av[4] = {a0.x, a0.y, a0.z, a0.w};
-                acc[pi][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[ks], acc[pi][mt], 0, 0, 0);
-                // A second MFMA waiting at the issue stage for the matrix pipe blocks the SIMD's VALU port for the
-                // producer wave as well; idling here (~48 of the 64 pipe cycles) leaves the port to the producer.
-              }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int pi = 0; pi < 4; ++pi) {
+          const int ring = cc * 4 + pi;
+          const int q = chunk * 4 + pi;
+          load_b(min(q + 6, n_frag - 1), (ring + 6) % 8);
+          if (pi + 1 < 4) {
+            af[(pi + 1) & 1][0] = *reinterpret_cast<const float4*>(vlane + ((pi + 1) * kNT64) * kRS2);
+            af[(pi + 1) & 1][1] = *reinterpret_cast<const float4*>(vlane + ((pi + 1) * kNT64 + 32) * kRS2);
           }
-          if (st && chunk < 40) st[2 + chunk * 5 + 1] = __builtin_readcyclecounter();
-          __syncthreads();
+          // the side work of this phase, one piece in front of each MFMA group (surplus work past the last chunk is
+          // harmless: it lands in buffers nobody reads any more).  (Tried: different slots for the two waves of a SIMD,
+          // which otherwise run this stream in lockstep -- slower.)
+          if (pi == 0) read_raw(raw_next);
+          if (pi == 2) {
+            if (st && chunk < 40) st[2 + chunk * 5 + 1] = __builtin_readcyclecounter();
+            transform_write(v_next);
+            if (st && chunk < 40) st[2 + chunk * 5 + 2] = __builtin_readcyclecounter();
+          }
+          if (pi == 3) {
+            if (st && chunk < 40) st[2 + chunk * 5 + 3] = __builtin_readcyclecounter();
+            commit_raw(raw_free, min(chunk + 2, last));
+            load_raw(min(chunk + 3, last));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const float4 b0 = bq[ring];
+          const float bv[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const float4 a0 = af[pi & 1][mt];
+              const float av[4] = {a0.x, a0.y, a0.z, a0.w};
+              acc[pi][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[ks], acc[pi][mt], 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (st && chunk < 40) st[2 + chunk * 5 + 4] = __builtin_readcyclecounter();
+        __syncthreads();
       }
     }
   }
+  if (st) st[1] = __builtin_readcyclecounter();
   // every wave is past the barrier that ends the last phase: raw / V are free, the epilogue buffer aliases them
 
-  // ---- output transform: the consumers hand A^T (M A) rows over through LDS, all 8 waves finish (one item each)
-  if (st && t == 0) st[1] = __builtin_readcyclecounter();
+  // ---- output transform: rows of A^T (M A) through LDS per (N-tile, M-tile), then one 2x2-output item x 4 couts per thread
   constexpr int kMS = 36;                          // row stride (floats): 32 couts + 4 pad (16-byte aligned rows)
-  constexpr int kRbMT = 4 * 2 * 32 * kMS;          // floats per M-tile: [4 rows i][2 k][32 tiles][kMS] = 36.9 KB
+  constexpr int kRbMT = 4 * 2 * 32 * kMS;          // floats per (N-tile, M-tile): [4 rows i][2 k][32 tiles][kMS] = 36.9 KB
   float* Rb = lds;
-  if (wave < 4) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < 2; ++mt) {
+    float* rb = Rb + (nt * 2 + mt) * kRbMT;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[0][mt][r], m1 = acc[1][mt][r], m2 = acc[2][mt][r], m3 = acc[3][mt][r];
-        const int trow = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        Rb[mt * kRbMT + ((wave * 2 + 0) * 32 + trow) * kMS + m] = (m0 + m1) + m2;
-        Rb[mt * kRbMT + ((wave * 2 + 1) * 32 + trow) * kMS + m] = (m1 - m2) - m3;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][mt][r], m1 = acc[1][mt][r], m2 = acc[2][mt][r], m3 = acc[3][mt][r];
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      rb[((pr * 2 + 0) * 32 + trow) * kMS + m] = (m0 + m1) + m2;
+      rb[((pr * 2 + 1) * 32 + trow) * kMS + m] = (m1 - m2) - m3;
     }
   }
   __syncthreads();
-  {
-    float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
-    const bool vec_ok = (a.Cout & 3) == 0;
-    const int mt = t >> 8, cq = t & 7, tl = (t >> 3) & 31;
+  float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+  const bool vec_ok = (a.Cout & 3) == 0;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = it * 512 + t;                 // (N-tile, M-tile, tile in M-tile, cout quad)
+    const int cq = item & 7, tl = (item >> 3) & 31, mt = (item >> 8) & 1, ont = item >> 9;
+    const float* rb = Rb + (ont * 2 + mt) * kRbMT;
     const int tg = mt * 32 + tl;                   // Winograd tile 0..63 of the workgroup (8 x 8)
     const int ty2 = tg >> 3, tx2 = tg & 7;
-    const int co = n0 + 4 * cq;
+    const int co = ng * 64 + ont * 32 + 4 * cq;
     float4 rv[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) rv[i][k] = *reinterpret_cast<const float4*>(Rb + mt * kRbMT + ((i * 2 + k) * 32 + tl) * kMS + 4 * cq);
+      for (int k = 0; k < 2; ++k) rv[i][k] = *reinterpret_cast<const float4*>(rb + ((i * 2 + k) * 32 + tl) * kMS + 4 * cq);
     if (co < a.Cout) {
       float bs[4];
 #pragma unroll
@@ -760,6 +805,7 @@ conv3x3_wino3_kernel(const WinoArgs a) {
       }
     }
   }
+  if (st) st[2 + 5 * 40 - 1] = __builtin_readcyclecounter();      // end of the epilogue (slot of chunk 39, never a real chunk here)
 }
 
 static unsigned long long* g_wino_stamps = nullptr;
@@ -803,17 +849,24 @@ extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, cons
     attr_set = true;
   }
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 32)), (unsigned)b);
-  static int variant = -1;                         // M4D_WINO_VARIANT=3: the wave-specialised experiment (same results, bit for bit, slower)
-  if (variant < 0) { const char* e = getenv("M4D_WINO_VARIANT"); variant = e ? atoi(e) : 2; }
-  if (variant == 3) {
-    constexpr size_t lds3 = (size_t)(2 * kRawF + 2 * kVF) * sizeof(float);              // 30.4 + 96 KB
-    static bool attr3_set = false;
-    if (!attr3_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  // Kernel 4 (512 threads, 64 couts, one workgroup per CU) where its grid still fills the chip and the K loop is long
+  // enough to pay for its prologue (tools/bench_wino_variants.py: 3-13 % faster from 240 workgroups up, slower at 120 and
+  // for 2-chunk layers); otherwise kernel 2 (twice as many, smaller workgroups).  Same results bit for bit.
+  // M4D_WINO_VARIANT=2 forces kernel 2, M4D_WINO4_MIN_WG moves the threshold.
+  static int variant = -1, min_wg4 = -1;
+  if (variant < 0) { const char* e = getenv("M4D_WINO_VARIANT"); variant = e ? atoi(e) : 4; }
+  if (min_wg4 < 0) { const char* e = getenv("M4D_WINO4_MIN_WG"); min_wg4 = e ? atoi(e) : 200; }
+  if (variant == 4 && CoutPad % 64 == 0 && Cin >= 32 && (long long)a.tiles_x * a.tiles_y * (CoutPad / 64) * b >= min_wg4) {
+    constexpr size_t lds4 = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);              // epilogue staging 147 KB (K loop: 126 KB)
+    static_assert(lds4 >= (size_t)(2 * kRawF + 2 * kVF) * sizeof(float), "epilogue staging must cover the K-loop buffers");
+    static bool attr4_set = false;
+    if (!attr4_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
-      attr3_set = true;
+      attr4_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_wino3_kernel, grid, dim3(512), lds3, (hipStream_t)stream, a);
+    const dim3 grid4((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
+    hipLaunchKernelGGL(conv3x3_wino4_kernel, grid4, dim3(512), lds4, (hipStream_t)stream, a);
     return M4D_LAUNCH_RESULT();
   }
   hipLaunchKernelGGL(conv3x3_wino2_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -193,10 +193,15 @@ def conv3x3_bias_act(x, wp, bias, cout, cout_pad, slope=0.1, stride=1):
 _WINO_G = [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]]
 
 
+_WINO_SKEW = 64
+
+
 def pack_conv_weights_winograd(kernel_hwio, chunk=16):
     """Winograd F(2x2,3x3) filter transform U = G g G^T of a TF HWIO [3,3,Cin,Cout] kernel (in float64, rounded
     once to float32), packed for m4d_conv3x3_wino_bias_act (chunk = 16) / m4d_conv3x3_wino2_bias_act (chunk = 8):
-    [ceil(Cin/chunk)][16 positions][CoutPad][chunk channels], zero padded.  numpy in, numpy out."""
+    [ceil(Cin/chunk)][16 positions][CoutPad][chunk channels], zero padded; for chunk = 8 every position block is
+    followed by 64 floats of padding (kWSkew in m4d_wino.hip: the 16 position blocks of a chunk, 4 KB apart at
+    CoutPad = 128, otherwise all start on the same L2 channel).  numpy in, numpy out."""
     import numpy as np
     k = np.asarray(kernel_hwio, dtype=np.float64)
     assert k.shape[:2] == (3, 3)
@@ -207,8 +212,12 @@ def pack_conv_weights_winograd(kernel_hwio, chunk=16):
     cpad = -(-cout // 32) * 32
     full = np.zeros((16, nch * chunk, cpad), np.float32)
     full[:, :cin, :cout] = U.reshape(16, cin, cout).astype(np.float32)
-    w = full.reshape(16, nch, chunk, cpad).transpose(1, 0, 3, 2)    # [chunk][pos][n][channels]
-    return np.ascontiguousarray(w), cpad
+    w = np.ascontiguousarray(full.reshape(16, nch, chunk, cpad).transpose(1, 0, 3, 2))    # [chunk][pos][n][channels]
+    if chunk == 8:
+        skewed = np.zeros((nch, 16, cpad * chunk + _WINO_SKEW), np.float32)
+        skewed[:, :, :cpad * chunk] = w.reshape(nch, 16, cpad * chunk)
+        return skewed, cpad
+    return w, cpad
 
 
 def conv3x3_wino_bias_act(x, wu, bias, cout, cout_pad, slope=0.1):

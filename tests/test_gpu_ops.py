@@ -384,9 +384,12 @@ def test_winograd_conv_kernel1(M, dev, b, h, w, cin, cout, slope):
     (1, 19, 21, 32, 40, 1.0),         # N padding, no activation
     (2, 16, 16, 8, 32, 0.1),          # a single chunk
     (1, 50, 90, 96, 64, 0.1),
+    (2, 100, 130, 36, 120, 0.1),      # >= 200 workgroups of 64 couts, Cin >= 32: kernel 4 (ragged tiles, half-empty last
+    (1, 192, 320, 64, 64, 1.0),       # chunk, Cout < CoutPad); an interior-only fast path + the border tiles
 ])
 def test_winograd_conv_kernel2(M, dev, b, h, w, cin, cout, slope):
-    """Winograd kernel 2 (16x16 tile, 8-channel chunks, two M-tiles per wave) vs the oracle; same tolerance."""
+    """Winograd kernel 2 (16x16 tile, 8-channel chunks, two M-tiles per wave) and kernel 4 (the same arithmetic on 512-thread
+    workgroups, chosen by m4d_conv3x3_wino2_bias_act when the grid is large enough) vs the oracle; same tolerance."""
     from m4depth_amd import network_ops as nops
     rng = np.random.default_rng(cin * 13 + cout)
     x = rng.standard_normal([b, h, w, cin]).astype(F)
@@ -484,3 +487,20 @@ def test_encoder_level_2_with_trained_weights(M, dev):
         t = nops.conv3x3_bias_act(t, to_dev(wp, dev), to_dev(tw[2, c, "bias"], dev), tw[2, c, "kernel"].shape[3], cpad, 0.1, stride)
     err = np.max(np.abs(npy(t) - ref))
     assert t.shape == (2, 23, 35, 32) and err < 1e-5 * max(1.0, np.abs(ref).max()), err
+
+
+def test_winograd_kernel_4_is_bitwise_kernel_2(dev, tmp_path):
+    """m4d_conv3x3_wino2_bias_act picks kernel 2 or kernel 4 by grid size; both must give the same bits (same products,
+    same order).  The choice is read once per process (M4D_WINO_VARIANT), hence two subprocesses."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "wino_variant_check.py")
+    outs = []
+    for variant in ("2", "4"):
+        env = dict(os.environ, M4D_WINO_VARIANT=variant, M4D_WINO4_MIN_WG="0")
+        out = str(tmp_path / f"v{variant}.pt")
+        subprocess.run([sys.executable, tool, "--save", out], check=True, env=env, timeout=600, capture_output=True)
+        outs.append(out)
+    res = subprocess.run([sys.executable, tool, "--compare", *outs], check=True, timeout=600, capture_output=True, text=True).stdout
+    lines = [l for l in res.strip().splitlines() if l]
+    assert len(lines) >= 5 and all(l.endswith("bit-identical") for l in lines), res

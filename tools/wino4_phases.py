@@ -1,5 +1,4 @@
-"""Per-phase cycle stamps of the wave-specialised Winograd kernel (variant 3): consumer MFMA time, producer commit /
-transform time and barrier waits per chunk."""
+"""Per-phase cycle stamps of Winograd kernel 4 (m4d_wino_set_stamps): where a chunk's time goes for wave 0."""
 import os, sys, ctypes, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,11 +20,14 @@ s = buf.cpu().numpy().reshape(512, 202).astype(np.int64)
 n_ch = cin // 8
 c = s[:, 2:2 + 5 * n_ch].reshape(512, n_ch, 5)
 f = lambda a: f"median {np.median(a):8.0f}  mean {a.mean():8.0f}  p90 {np.percentile(a, 90):8.0f}"
-print("K loop total (consumer)                     ", f(s[:, 1] - s[:, 0]))
-print("consumer: MFMA phase (start -> before barrier)", f(c[:, :, 1] - c[:, :, 0]))
-print("consumer: barrier wait + loop (end -> next start)", f(c[:, 1:, 0] - c[:, :-1, 1]))
-print("producer: commit + load issue              ", f(c[:, :-3, 2] - c[:, :-3, 4]))
-print("producer: transform                        ", f(c[:, :-1, 3] - c[:, :-1, 2]))
-print("producer: barrier wait (end -> next start)  ", f(c[:, 1:, 4] - c[:, :-1, 3]))
-print("phase period (consumer start to start)      ", f(c[:, 1:, 0] - c[:, :-1, 0]))
+print("workgroup total                              ", f(s[:, 201] - s[:, 0]))
+print("prologue (start -> first chunk)              ", f(c[:, 0, 0] - s[:, 0]))
+print("K loop                                       ", f(s[:, 1] - c[:, 0, 0]))
+print("epilogue                                     ", f(s[:, 201] - s[:, 1]))
+print("per chunk: A reads + raw reads + groups 0, 1  ", f(c[:, :, 1] - c[:, :, 0]))
+print("per chunk: transform + V writes               ", f(c[:, :, 2] - c[:, :, 1]))
+print("per chunk: group 2                            ", f(c[:, :, 3] - c[:, :, 2]))
+print("per chunk: commit + loads + group 3           ", f(c[:, :, 4] - c[:, :, 3]))
+print("per chunk: barrier (end -> next start)        ", f(c[:, 1:, 0] - c[:, :-1, 4]))
+print("phase period                                  ", f(c[:, 1:, 0] - c[:, :-1, 0]))
 print("one workgroup, chunks 4..8:\n", (c[7, 4:9, :] - c[7, 4, 0]))

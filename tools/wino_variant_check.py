@@ -1,5 +1,6 @@
-"""Winograd kernel 2 (M4D_WINO_VARIANT=2) vs the wave-specialised kernel 3 (default): run once per variant with
---save, then --compare: the outputs must be bit-identical (same arithmetic, same order)."""
+"""Winograd kernel 2 (M4D_WINO_VARIANT=2) vs kernel 4 (default where the grid is large enough; M4D_WINO4_MIN_WG=0 forces
+it wherever it applies): run once per variant with --save, then --compare: the outputs must be bit-identical (same
+arithmetic, same order).  Used by tests/test_gpu_ops.py::test_winograd_kernel_4_is_bitwise_kernel_2."""
 import argparse, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,7 +17,8 @@ if a.compare:
 dev = torch.device("cuda:0")
 out = {}
 g = torch.Generator().manual_seed(3)
-for (b, h, w, cin, cout) in [(1, 192, 640, 128, 128), (2, 96, 320, 124, 96), (1, 37, 53, 8, 40), (1, 50, 70, 20, 128), (3, 16, 16, 4, 32)]:
+for (b, h, w, cin, cout) in [(1, 192, 640, 128, 128), (2, 96, 320, 124, 64), (1, 37, 53, 36, 40), (1, 50, 70, 44, 128), (3, 16, 16, 32, 64),
+                             (1, 100, 130, 64, 120)]:
     x = torch.randn(b, h, w, cin, generator=g).to(dev)
     k = torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5
     bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
