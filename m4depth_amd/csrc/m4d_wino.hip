@@ -529,6 +529,7 @@ conv3x3_wino2_kernel(const WinoArgs a) {
 constexpr int kRawF = kHP2 * kRS2;               // floats per raw buffer   (15.2 KB)
 constexpr int kVF = 16 * kNT64 * kRS2;           // floats per V buffer     (48 KB)
 
+template <bool STAMPS>
 __global__ void __launch_bounds__(512)
 conv3x3_wino4_kernel(const WinoArgs a) {
   constexpr int A_F4 = kHP2 * 2;                 // float4 loads per halo chunk (648)
@@ -580,29 +581,21 @@ conv3x3_wino4_kernel(const WinoArgs a) {
   const bool interior = tile_y >= 1 && tile_x >= 1 && tile_y + kT2 + 1 <= a.h && tile_x + kT2 + 1 <= a.w;
   const unsigned voff0 = (unsigned)(pix_off0 + k4) * 4u, voff1 = (unsigned)(pix_off1 + k4) * 4u;     // bytes
   float4 ra0, ra1;
-  auto load_raw = [&](int chunk) {               // unconditional (clamped) loads, validity applied at the commit
-    const int c0 = chunk * kC2;
-    if (c0 + kC2 <= a.Cin) {
-      const char* base = reinterpret_cast<const char*>(ximg) + (size_t)c0 * 4;
-      ra0 = *reinterpret_cast<const float4*>(base + voff0);
-      ra1 = *reinterpret_cast<const float4*>(base + voff1);
-    } else {
-      const float* base = ximg + min(c0 + k4, a.Cin - 4);
-      ra0 = *reinterpret_cast<const float4*>(base + pix_off0);
-      ra1 = *reinterpret_cast<const float4*>(base + pix_off1);
-    }
+  auto load_raw = [&](int chunk) {               // Cin % 8 == 0 (launcher): every chunk is full; loads unconditional (clamped pixel)
+    const char* base = reinterpret_cast<const char*>(ximg) + (size_t)chunk * (kC2 * 4);
+    ra0 = *reinterpret_cast<const float4*>(base + voff0);
+    ra1 = *reinterpret_cast<const float4*>(base + voff1);
   };
-  auto commit_raw = [&](float* rb, int chunk) {  // chunk = the one the registers hold (no state carried from the load)
-    const int c0 = chunk * kC2;
-    if (interior && c0 + kC2 <= a.Cin) {
+  auto commit_raw = [&](float* rb) {
+    if (interior) {
       *reinterpret_cast<float4*>(rb + raw_dst0) = ra0;
       if (slot1) *reinterpret_cast<float4*>(rb + raw_dst1) = ra1;
     } else {
-      const bool ch_ok = c0 + k4 < a.Cin;
-      const bool ok0 = pix_ok0 && ch_ok, ok1 = pix_ok1 && ch_ok;
-      *reinterpret_cast<float4*>(rb + raw_dst0) = make_float4(ok0 ? ra0.x : 0.f, ok0 ? ra0.y : 0.f, ok0 ? ra0.z : 0.f, ok0 ? ra0.w : 0.f);
+      *reinterpret_cast<float4*>(rb + raw_dst0) =
+          make_float4(pix_ok0 ? ra0.x : 0.f, pix_ok0 ? ra0.y : 0.f, pix_ok0 ? ra0.z : 0.f, pix_ok0 ? ra0.w : 0.f);
       if (slot1)
-        *reinterpret_cast<float4*>(rb + raw_dst1) = make_float4(ok1 ? ra1.x : 0.f, ok1 ? ra1.y : 0.f, ok1 ? ra1.z : 0.f, ok1 ? ra1.w : 0.f);
+        *reinterpret_cast<float4*>(rb + raw_dst1) =
+            make_float4(pix_ok1 ? ra1.x : 0.f, pix_ok1 ? ra1.y : 0.f, pix_ok1 ? ra1.z : 0.f, pix_ok1 ? ra1.w : 0.f);
     }
   };
 
@@ -670,19 +663,19 @@ conv3x3_wino4_kernel(const WinoArgs a) {
   };
 
   // phase stamps (m4d_wino_set_stamps): thread 0 of the first 512 workgroups
-  unsigned long long* st = (a.stamps != nullptr && t == 0 && blockIdx.y == 0 && blockIdx.x < 512)
+  unsigned long long* st = (STAMPS && a.stamps != nullptr && t == 0 && blockIdx.y == 0 && blockIdx.x < 512)
                                ? a.stamps + (long long)blockIdx.x * (5 * 40 + 2) : nullptr;
-  if (st) st[0] = __builtin_readcyclecounter();
+  if (STAMPS && st) st[0] = __builtin_readcyclecounter();
   // ---- prologue: raw(0) -> V(0), raw(1) committed, raw(2) in registers
   load_raw(0);
 #pragma unroll
   for (int q = 0; q < 6; ++q) load_b(min(q, n_frag - 1), q);
-  commit_raw(raw, 0);
+  commit_raw(raw);
   load_raw(min(1, last));
   __syncthreads();
   read_raw(raw);
   transform_write(V);
-  commit_raw(raw + kRawF, min(1, last));
+  commit_raw(raw + kRawF);
   load_raw(min(2, last));
   __syncthreads();
 
@@ -695,7 +688,7 @@ conv3x3_wino4_kernel(const WinoArgs a) {
         const float* raw_next = raw + (cc ^ 1) * kRawF;    // raw(chunk + 1), committed during the previous phase
         float* raw_free = raw + cc * kRawF;                // raw(chunk) was transformed during the previous phase
         float* v_next = V + (cc ^ 1) * kVF;
-        if (st && chunk < 40) st[2 + chunk * 5 + 0] = __builtin_readcyclecounter();
+        if (STAMPS && st && chunk < 40) st[2 + chunk * 5 + 0] = __builtin_readcyclecounter();
         float4 af[2][2];
         af[0][0] = *reinterpret_cast<const float4*>(vlane);
         af[0][1] = *reinterpret_cast<const float4*>(vlane + 32 * kRS2);
@@ -713,13 +706,13 @@ conv3x3_wino4_kernel(const WinoArgs a) {
           // which otherwise run this stream in lockstep -- slower.)
           if (pi == 0) read_raw(raw_next);
           if (pi == 2) {
-            if (st && chunk < 40) st[2 + chunk * 5 + 1] = __builtin_readcyclecounter();
+            if (STAMPS && st && chunk < 40) st[2 + chunk * 5 + 1] = __builtin_readcyclecounter();
             transform_write(v_next);
-            if (st && chunk < 40) st[2 + chunk * 5 + 2] = __builtin_readcyclecounter();
+            if (STAMPS && st && chunk < 40) st[2 + chunk * 5 + 2] = __builtin_readcyclecounter();
           }
           if (pi == 3) {
-            if (st && chunk < 40) st[2 + chunk * 5 + 3] = __builtin_readcyclecounter();
-            commit_raw(raw_free, min(chunk + 2, last));
+            if (STAMPS && st && chunk < 40) st[2 + chunk * 5 + 3] = __builtin_readcyclecounter();
+            commit_raw(raw_free);
             load_raw(min(chunk + 3, last));
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -735,12 +728,12 @@ conv3x3_wino4_kernel(const WinoArgs a) {
             }
           __builtin_amdgcn_sched_barrier(0);
         }
-        if (st && chunk < 40) st[2 + chunk * 5 + 4] = __builtin_readcyclecounter();
+        if (STAMPS && st && chunk < 40) st[2 + chunk * 5 + 4] = __builtin_readcyclecounter();
         __syncthreads();
       }
     }
   }
-  if (st) st[1] = __builtin_readcyclecounter();
+  if (STAMPS && st) st[1] = __builtin_readcyclecounter();
   // every wave is past the barrier that ends the last phase: raw / V are free, the epilogue buffer aliases them
 
   // ---- output transform: rows of A^T (M A) through LDS per (N-tile, M-tile), then one 2x2-output item x 4 couts per thread
@@ -805,7 +798,7 @@ conv3x3_wino4_kernel(const WinoArgs a) {
       }
     }
   }
-  if (st) st[2 + 5 * 40 - 1] = __builtin_readcyclecounter();      // end of the epilogue (slot of chunk 39, never a real chunk here)
+  if (STAMPS && st) st[2 + 5 * 40 - 1] = __builtin_readcyclecounter();      // end of the epilogue (slot of chunk 39, never a real chunk here)
 }
 
 static unsigned long long* g_wino_stamps = nullptr;
@@ -856,17 +849,20 @@ extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, cons
   static int variant = -1, min_wg4 = -1;
   if (variant < 0) { const char* e = getenv("M4D_WINO_VARIANT"); variant = e ? atoi(e) : 4; }
   if (min_wg4 < 0) { const char* e = getenv("M4D_WINO4_MIN_WG"); min_wg4 = e ? atoi(e) : 200; }
-  if (variant == 4 && CoutPad % 64 == 0 && Cin >= 32 && (long long)a.tiles_x * a.tiles_y * (CoutPad / 64) * b >= min_wg4) {
+  if (variant == 4 && CoutPad % 64 == 0 && Cin >= 32 && Cin % 8 == 0 && (long long)a.tiles_x * a.tiles_y * (CoutPad / 64) * b >= min_wg4) {
     constexpr size_t lds4 = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);              // epilogue staging 147 KB (K loop: 126 KB)
     static_assert(lds4 >= (size_t)(2 * kRawF + 2 * kVF) * sizeof(float), "epilogue staging must cover the K-loop buffers");
     static bool attr4_set = false;
     if (!attr4_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
       attr4_set = true;
     }
     const dim3 grid4((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
-    hipLaunchKernelGGL(conv3x3_wino4_kernel, grid4, dim3(512), lds4, (hipStream_t)stream, a);
+    if (a.stamps) hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, grid4, dim3(512), lds4, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, grid4, dim3(512), lds4, (hipStream_t)stream, a);
     return M4D_LAUNCH_RESULT();
   }
   hipLaunchKernelGGL(conv3x3_wino2_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -384,8 +384,8 @@ def test_winograd_conv_kernel1(M, dev, b, h, w, cin, cout, slope):
     (1, 19, 21, 32, 40, 1.0),         # N padding, no activation
     (2, 16, 16, 8, 32, 0.1),          # a single chunk
     (1, 50, 90, 96, 64, 0.1),
-    (2, 100, 130, 36, 120, 0.1),      # >= 200 workgroups of 64 couts, Cin >= 32: kernel 4 (ragged tiles, half-empty last
-    (1, 192, 320, 64, 64, 1.0),       # chunk, Cout < CoutPad); an interior-only fast path + the border tiles
+    (2, 100, 130, 40, 120, 0.1),      # >= 200 workgroups of 64 couts, Cin >= 32, Cin % 8 == 0: kernel 4 (ragged tiles,
+    (1, 192, 320, 64, 64, 1.0),       # Cout < CoutPad); interior fast path + border tiles
 ])
 def test_winograd_conv_kernel2(M, dev, b, h, w, cin, cout, slope):
     """Winograd kernel 2 (16x16 tile, 8-channel chunks, two M-tiles per wave) and kernel 4 (the same arithmetic on 512-thread
