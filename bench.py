@@ -278,12 +278,12 @@ def main():
                 flops_exec = 2.0 * 16 * 128 * 128 * ((h1 + 1) // 2) * ((w1 + 1) // 2) * args.batch if wino else flops_direct
                 tf = flops_direct / sec / 1e12                 # the contract's definition: ALGORITHMIC flops / time
                 tf_exec = flops_exec / sec / 1e12
-                out["roofline"] = {"kernel": ("conv3x3_wino2_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3) on fp32 MFMA, "
+                out["roofline"] = {"kernel": ("conv3x3_wino4_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3) on fp32 MFMA, "
                                               "bias+leaky-relu fused)") if wino else
                                              "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)",
                                    "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                                   "traffic": None if wino else traffic.get("conv_l1_128_128"),
+                                   "traffic": traffic.get("wino_l1_128_128" if wino else "conv_l1_128_128"),
                                    "algorithmic_flops_per_launch": flops_direct,
                                    "note": ("achieved / frac use the layer's algorithmic (direct-convolution) flops, 2*9*Cin*Cout per "
                                             "pixel; the Winograd kernel executes 2.25x fewer on the matrix cores, so frac can exceed 1 -- "

@@ -1,17 +1,17 @@
-"""rocprofv3 durations of the roofline kernel (level-1 128->128 refiner layer = conv3x3_wino2_kernel on a 480-tile x
-4-group grid) from a kernel trace of `bench.py --steps 10 --warmup 3`, to set beside the HIP-event average bench.py
-prints.  conv3x3_wino2_kernel serves every wide layer of levels 1-2, so the --stats average of the NAME mixes them;
-this keeps the launches with the level-1 Cout = 128 grid (1920 workgroups: the 64->128 and the 128->128 layer), separates
+"""rocprofv3 durations of the roofline kernel (level-1 128->128 refiner layer = conv3x3_wino4_kernel on a 480-tile x
+2-group grid of 512-thread workgroups) from a kernel trace of `bench.py --steps 10 --warmup 3`, to set beside the HIP-event average bench.py
+prints.  conv3x3_wino4_kernel serves several wide layers of levels 1-2, so the --stats average of the NAME mixes them;
+this keeps the launches with the level-1 Cout = 128 grid (960 workgroups: the 64->128 and the 128->128 layer), separates
 the two layers by duration and isolates the last 15 launches of the 128->128 layer = bench.py's eager kernel-timing pass
 (5 steps x 3 full frames, one stream).
 
-    python tools/conv_roofline_check.py <kernel_trace.csv> [workgroups=1920] [split_us=165]"""
+    python tools/conv_roofline_check.py <kernel_trace.csv> [workgroups=960] [split_us=150]"""
 import csv
 import sys
 
-NAME = "conv3x3_wino2_kernel"
-wgs = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
-split = float(sys.argv[3]) if len(sys.argv) > 3 else 165.0
+NAME = "conv3x3_wino4_kernel"
+wgs = int(sys.argv[2]) if len(sys.argv) > 2 else 960
+split = float(sys.argv[3]) if len(sys.argv) > 3 else 150.0
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if NAME in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 
