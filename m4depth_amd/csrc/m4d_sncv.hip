@@ -310,6 +310,56 @@ sncv_generic_kernel(const SncvArgs a, long long total) {
   }
 }
 
+// Small maps (the three coarsest levels: a few hundred to a few thousand pixels, C >= 96): the halo-tile kernel above
+// runs a handful of workgroups that each spend most of their time staging a halo several times the size of their
+// tile (19-28 us for 120-1920 pixels).  Here: one lane per OUTPUT element, channel runs read as float4 straight from
+// global memory (the whole map is L2 / vector-L1 resident), consecutive lanes = consecutive output channels of a pixel
+// (coalesced stores).  Same arithmetic, same order: products rounded individually, summed in channel order, / NC,
+// leaky_relu.
+template <int NC>
+__global__ void __launch_bounds__(256)
+sncv_small_kernel(const SncvArgs a, int total_px) {
+  const int mo = 2 * a.r + 1;
+  const int och = mo * mo * a.k;
+  const long long total = (long long)total_px * och;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % och);
+    const int gp = (int)(idx / och);
+    const int kk = ch % a.k;
+    const int dsp = ch / a.k;
+    const int y = dsp / mo, x = dsp - y * mo;
+    const int gx = gp % a.w;
+    const int gyb = gp / a.w;                      // bi * h + gy
+    const int gy = gyb % a.h;
+    const int sy = gy + (y - a.r) * a.d, sx = gx + (x - a.r) * a.d;
+    const bool in = sy >= 0 && sy < a.h && sx >= 0 && sx < a.w;
+    const float* p1 = a.c1 + (long long)gp * a.C + kk * NC;
+    const float* p2 = a.c2 + ((long long)(gyb - gy + (in ? sy : gy)) * a.w + (in ? sx : gx)) * a.C + kk * NC;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; c += 4) {
+      const float4 u = *reinterpret_cast<const float4*>(p1 + c);
+      float4 v = *reinterpret_cast<const float4*>(p2 + c);
+      if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);                     // zero padding (:293)
+      if (c == 0) acc = u.x * v.x; else acc = acc + u.x * v.x;
+      acc = acc + u.y * v.y;
+      acc = acc + u.z * v.z;
+      acc = acc + u.w * v.w;
+    }
+    const float mean = acc / (float)NC;
+    a.out[(long long)gp * a.out_stride + ch] = mean > 0.f ? mean : mean * 0.1f;
+  }
+}
+
+template <int NC>
+void launch_small(const SncvArgs& a, int b, hipStream_t s) {
+  const int total_px = b * a.h * a.w;
+  const long long total = (long long)total_px * (2 * a.r + 1) * (2 * a.r + 1) * a.k;
+  long long g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  hipLaunchKernelGGL((sncv_small_kernel<NC>), dim3((int)g), dim3(256), 0, s, a, total_px);
+}
+
 template <int NC, int MO>
 void launch_lds_mo(const SncvArgs& a, int b, size_t lds, hipStream_t s) {
   const int tiles = a.tiles_x * ((a.h + a.th - 1) / a.th);
@@ -347,6 +397,19 @@ extern "C" int m4d_sncv_fwd(const float* c1, const float* c2, int b, int h, int 
   const bool nc_ok = a.nc == 4 || a.nc == 8 || a.nc == 16 || a.nc == 24 || a.nc == 32;
   static int variant = -1;                  // M4D_SNCV_VARIANT=0 disables the specialised kernels (debugging)
   if (variant < 0) { const char* e = getenv("M4D_SNCV_VARIANT"); variant = e ? atoi(e) : 1; }
+  static int small_px = -1;                 // M4D_SNCV_SMALL_PX: maps up to this many pixels (batch included) take the small-map kernel
+  if (small_px < 0) { const char* e = getenv("M4D_SNCV_SMALL_PX"); small_px = e ? atoi(e) : 6000; }
+  if (variant == 1 && aligned && nc_ok && (long long)b * h * w <= small_px) {
+    a.th = a.tw = a.tiles_x = 0;
+    switch (a.nc) {
+      case 4: launch_small<4>(a, b, s); break;
+      case 8: launch_small<8>(a, b, s); break;
+      case 16: launch_small<16>(a, b, s); break;
+      case 24: launch_small<24>(a, b, s); break;
+      default: launch_small<32>(a, b, s); break;
+    }
+    return M4D_LAUNCH_RESULT();
+  }
   if (variant == 1 && aligned && c1 == c2 && search_range == 3 && dilation_rate == 1) {
     bool done = false;
     if (a.nc == 16 && nbre_cuts == 1) done = launch_sncv7<16, 1, 32, 8>(c1, b, h, w, out, out_stride, s);
