@@ -305,3 +305,45 @@ def test_frame_pipeline_is_bitwise_neutral(dev):
                     assert torch.equal(ref, out), "captured pipeline differs"
     finally:
         net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels, net.level_pipeline_streams = old
+
+
+@pytest.mark.parametrize("H,Wd,rd,rs,name", [(384, 1280, 4, 3, "configs[1]"), (768, 2560, 6, 6, "configs[4]")])
+def test_fullsize_configs_properties(dev, H, Wd, rd, rs, name):
+    """BASELINE.json's full-size geometries, 6 levels, batch 1 (no oracle run at these sizes: size-independent
+    properties).  768x2560 with 13 DSCV hypotheses and 13x13 SNCV displacements is the large-window configuration: the
+    runtime-window kernels, LDS tile shrinking and the 470-channel / 1462-channel refiner inputs at full scale."""
+    L, T, b = 6, 3, 1
+    W = S.init_weights(L, seed=21, dscv_range=rd, sncv_range=rs)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=77)
+    model = _build(dev, L, rd, rs, W)
+    ds, dc = to_dev(samples, dev), to_dev(cam, dev)
+    # frame 0 alone = new_traj: the reset branch (Appendix B invariant 9)
+    first = model([ds[:1], dc])["depth"]
+    assert first.shape == (b, H, Wd, 1) and torch.all(first == 1000.0)
+    for l, lvl in enumerate(model.d_estimator.levels):
+        assert torch.all(lvl.depth_prev_t == 1000.0)
+        fs = lvl.prev_f_maps
+        k = 2 ** ((l + 1) // 2)
+        n2 = (fs.reshape(*fs.shape[:3], k, -1) ** 2).sum(-1)
+        assert torch.allclose(n2, torch.ones_like(n2), atol=1e-5)           # the state holds the NORMALISED features
+    model.reset_state()
+    out = model([ds, dc])["depth"].clone()
+    assert out.shape == (b, H, Wd, 1) and torch.isfinite(out).all()
+    for l in range(L):
+        k = 2 ** ((l + 1) // 2)
+        fin = model.d_estimator.levels[l].last_f_input
+        assert fin.shape == (b, H >> (l + 1), Wd >> (l + 1), (2 * rd + 1) * k + (2 * rs + 1) ** 2 * k + 6)
+        assert torch.isfinite(fin).all()
+        est = model.last_estimates[-1][l]
+        cam_l = {"f": dc["f"] / float(2 ** (l + 1)), "c": dc["c"] / float(2 ** (l + 1))}
+        import m4depth_amd as M
+        # depth and parallax of a level are tied by parallax2depth with the level's intrinsics, bit for bit
+        assert torch.equal(est["depth"], M.parallax2depth(est["parallax"], ds[-1]["rot"], ds[-1]["trans"], cam_l))
+        lo, hi = np.exp(-7.0) / 2.0 ** (l + 1 - 3), np.exp(7.0) / 2.0 ** (l + 1 - 3)
+        assert est["parallax"].min() >= lo * (1 - 1e-5) and est["parallax"].max() <= hi * (1 + 1e-5)     # exp(clip(., -7, 7)) / 2^(l-3)
+    # the output is the nearest x2 upsample of the finest level
+    fine = model.last_estimates[-1][0]["depth"]
+    assert torch.equal(out[:, ::2, ::2], fine) and torch.equal(out[:, 1::2, 1::2], fine)
+    # deterministic: a second run from the same state gives the same bits
+    model.reset_state()
+    assert torch.equal(model([ds, dc])["depth"], out)
