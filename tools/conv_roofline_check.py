@@ -5,13 +5,13 @@ this keeps the launches with the level-1 Cout = 128 grid (960 workgroups: the 64
 the two layers by duration and isolates the last 15 launches of the 128->128 layer = bench.py's eager kernel-timing pass
 (5 steps x 3 full frames, one stream).
 
-    python tools/conv_roofline_check.py <kernel_trace.csv> [workgroups=960] [split_us=150]"""
+    python tools/conv_roofline_check.py <kernel_trace.csv> [workgroups=960] [split_us=165]"""
 import csv
 import sys
 
 NAME = "conv3x3_wino4_kernel"
 wgs = int(sys.argv[2]) if len(sys.argv) > 2 else 960
-split = float(sys.argv[3]) if len(sys.argv) > 3 else 150.0
+split = float(sys.argv[3]) if len(sys.argv) > 3 else 165.0
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if NAME in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 
