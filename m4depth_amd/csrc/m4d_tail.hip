@@ -32,7 +32,7 @@ constexpr int kTW = 16, kTH = 8;
 constexpr int kXW = kTW + 4, kXH = kTH + 4, kXP = kXW * kXH;     // input halo 20 x 12 = 240
 constexpr int kMW = kTW + 2, kMH = kTH + 2, kMP = kMW * kMH;     // conv6 positions 18 x 10 = 180
 constexpr int kXS = 36, kMS = 20;                                // LDS row strides (floats): 32 + 4, 16 + 4
-constexpr int kW6 = 9 * 16 * kXS, kW7 = 9 * 16 * kMS;
+constexpr int kW6 = 9 * 16 * kXS, kW7 = 9 * 8 * kMS;               // w7: only 8 of the 16 packed cout rows are kept (5 used)
 
 __global__ void __launch_bounds__(256, 2)
 refiner_tail_kernel(const TailArgs a) {
@@ -40,7 +40,7 @@ refiner_tail_kernel(const TailArgs a) {
   float* xin = lds;                       // [kXP][kXS]   34.6 KB   (later: out5 [128][8])
   float* mid = xin + kXP * kXS;           // [kMP][kMS]   14.4 KB
   float* w6 = mid + kMP * kMS;            // [9][16][kXS] 20.7 KB
-  float* w7 = w6 + kW6;                   // [9][16][kMS] 11.5 KB
+  float* w7 = w6 + kW6;                   // [9][8][kMS]   5.8 KB  (75.5 KB in all: two workgroups per CU)
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int bi = blockIdx.y;
@@ -70,10 +70,12 @@ refiner_tail_kernel(const TailArgs a) {
       *reinterpret_cast<float4*>(w6 + (idx >> 3) * kXS + (idx & 7) * 4) = *reinterpret_cast<const float4*>(a.w6 + idx * 4);
   }
 #pragma unroll
-  for (int u = 0; u < (9 * 16 * 4 + 255) / 256; ++u) {               // w7: 576 float4
+  for (int u = 0; u < (9 * 8 * 4 + 255) / 256; ++u) {                // w7: rows 0..7 of every tap, 288 float4
     const int idx = u * 256 + t;
-    if (idx < 9 * 16 * 4)
-      *reinterpret_cast<float4*>(w7 + (idx >> 2) * kMS + (idx & 3) * 4) = *reinterpret_cast<const float4*>(a.w7 + idx * 4);
+    if (idx < 9 * 8 * 4) {
+      const int tap = idx >> 5, row = (idx >> 2) & 7, q = idx & 3;
+      *reinterpret_cast<float4*>(w7 + (tap * 8 + row) * kMS + q * 4) = *reinterpret_cast<const float4*>(a.w7 + ((tap * 16 + row) * 4 + q) * 4);
+    }
   }
   __syncthreads();
 
@@ -121,12 +123,12 @@ refiner_tail_kernel(const TailArgs a) {
     for (int mt = 0; mt < 2; ++mt) {
       const int row = wave * 2 + mt;
       const float* ap = mid + (row * kMW + li) * kMS + kq * 4;
-      const float* bp = w7 + li * kMS + kq * 4;
+      const float* bp = w7 + (li & 7) * kMS + kq * 4;                  // output columns 8..15 are never stored: they alias 0..7
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const float4 a0 = *reinterpret_cast<const float4*>(ap + ((tap / 3) * kMW + (tap % 3)) * kMS);
-        const float4 b0 = *reinterpret_cast<const float4*>(bp + tap * 16 * kMS);
+        const float4 b0 = *reinterpret_cast<const float4*>(bp + tap * 8 * kMS);
         const float av[4] = {a0.x, a0.y, a0.z, a0.w};
         const float bv[4] = {b0.x, b0.y, b0.z, b0.w};
 #pragma unroll
@@ -174,7 +176,7 @@ extern "C" int m4d_refiner_tail(const float* x32, const float* w6p, const float*
   a.parallax = parallax; a.depth = depth; a.other = other; a.depth_state = depth_state;
   a.tiles_x = (w + kTW - 1) / kTW;
   const int tiles = a.tiles_x * ((h + kTH - 1) / kTH);
-  constexpr size_t lds = (size_t)(kXP * kXS + kMP * kMS + kW6 + kW7) * sizeof(float);          // 81.2 KB
+  constexpr size_t lds = (size_t)(kXP * kXS + kMP * kMS + kW6 + kW7) * sizeof(float);          // 75.5 KB
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&refiner_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
