@@ -80,6 +80,11 @@ def _use_winograd(b, h, w, cin, cout, stride):
     return 0
 
 
+# Refiner input padded to a multiple of 8 channels (levels 2-6: 58k + 6 = 122, 238, 470): the padding channels are
+# zero in a persistent buffer and meet zero weights, so every sum is unchanged bit for bit, and the first refiner layer
+# of level 2 becomes eligible for the 8-channel-chunk Winograd kernels (122 -> 128).  0 = exact-width input.
+pad_refiner_input = _os.environ.get("M4D_PAD_REFINER_INPUT", "1") == "1"
+
 # Encoder level 0 as two fused kernels (direct 3->16 convolution + bias + DINL statistics; DINL apply fused into the
 # stride-2 convolution's input staging) instead of MIOpen conv + bias pass + 3 DINL passes + conv: no MIOpen kernel is
 # left in the inference path.  0 = the unfused sequence.
@@ -139,6 +144,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(self.out_channels, device=device), requires_grad=False)
         self._packed = None
         self._packed_wino = None
+        self._packed_padded = None
         self._hwio = None
 
     def load_hwio(self, kernel, bias, device):
@@ -148,26 +154,42 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.bias = torch.nn.Parameter(_to_device_f32(bias, device).contiguous(), requires_grad=False)
         self._packed = None
         self._packed_wino = None
+        self._packed_padded = None
         self._hwio = None
 
-    def _packed_weights(self):
+    def _hwio_numpy(self, cin_pad=None):
+        """The TF-layout kernel on the host; ``cin_pad`` > Cin appends zero input channels (for a zero-padded input)."""
+        hwio = self.weight.detach().permute(2, 3, 1, 0).cpu().numpy()
+        if cin_pad is not None and cin_pad > hwio.shape[2]:
+            hwio = np.concatenate([hwio, np.zeros(hwio.shape[:2] + (cin_pad - hwio.shape[2], hwio.shape[3]), hwio.dtype)], axis=2)
+        return hwio
+
+    def _packed_weights(self, cin_pad=None):
         """(wp, CoutPad) for m4d_conv3x3_bias_act, packed once from the OIHW parameter."""
+        if cin_pad is not None and cin_pad != self.weight.shape[1]:
+            cache = getattr(self, "_packed_padded", None)
+            if cache is None:
+                cache = self._packed_padded = {}
+            hit = cache.get(cin_pad)
+            if hit is None or hit[0].device != self.weight.device:
+                wp, cpad = nops.pack_conv_weights(self._hwio_numpy(cin_pad))
+                hit = cache[cin_pad] = (torch.from_numpy(wp).to(self.weight.device), cpad)
+            return hit
         if self._packed is None or self._packed[0].device != self.weight.device:
-            hwio = self.weight.detach().permute(2, 3, 1, 0).cpu().numpy()
-            wp, cpad = nops.pack_conv_weights(hwio)
+            wp, cpad = nops.pack_conv_weights(self._hwio_numpy())
             self._packed = (torch.from_numpy(wp).to(self.weight.device), cpad)
         return self._packed
 
-    def _packed_weights_winograd(self, chunk=16):
+    def _packed_weights_winograd(self, chunk=16, cin_pad=None):
         """(wu, CoutPad) for m4d_conv3x3_wino_bias_act (chunk 16) / wino2 (chunk 8): U = G g G^T, transformed once on the host."""
         cache = getattr(self, "_packed_wino", None)
         if cache is None:
             cache = self._packed_wino = {}
-        hit = cache.get(chunk)
+        key = chunk if cin_pad is None or cin_pad == self.weight.shape[1] else (chunk, cin_pad)
+        hit = cache.get(key)
         if hit is None or hit[0].device != self.weight.device:
-            hwio = self.weight.detach().permute(2, 3, 1, 0).cpu().numpy()
-            wu, cpad = nops.pack_conv_weights_winograd(hwio, chunk=chunk)
-            hit = cache[chunk] = (torch.from_numpy(wu).to(self.weight.device), cpad)
+            wu, cpad = nops.pack_conv_weights_winograd(self._hwio_numpy(cin_pad), chunk=chunk)
+            hit = cache[key] = (torch.from_numpy(wu).to(self.weight.device), cpad)
         return hit
 
     def same_pads(self, h, w):
@@ -195,11 +217,11 @@ class _Conv3x3SameTF(torch.nn.Module):
             b_, h_, w_, cin_ = x_nhwc.shape
             wino = _use_winograd(b_, h_, w_, cin_, self.out_channels, self.stride)
             if wino:
-                wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8)
+                wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8, cin_)     # cin_ > Cin: zero-padded input
                 fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
                 return _timed("conv", self.tag, lambda: fn(
                     x_nhwc, wu, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope))
-            wp, cpad = self._packed_weights()
+            wp, cpad = self._packed_weights(cin_)
             return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
                 x_nhwc, wp, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope, stride=self.stride))
         x = x_nhwc.permute(0, 3, 1, 2)                   # channels-last NCHW view, no copy
@@ -448,7 +470,14 @@ class DepthEstimatorLevel(torch.nn.Module):
         r = self.dscv_range
         ncp = 2 * r + 1
         F_in = self.f_in
-        f_input = torch.empty((b, h, w, F_in), dtype=torch.float32, device=dev)
+        F_st = F_in                                   # channel stride of the refiner input buffer
+        if (pad_refiner_input and dev.type == "cuda" and not self.is_training and F_in % 8 != 0
+                and mfma_conv_min_pixels > 0 and F_in >= mfma_conv_min_cin and b * h * w >= mfma_conv_min_pixels):   # the first layer takes the hand-written path
+            F_st = (F_in + 7) // 8 * 8
+            f_buf = nops.zeroed_workspace(("f_input", self.lvl_depth), (b, h, w, F_st), dev)
+        else:
+            f_buf = torch.empty((b, h, w, F_in), dtype=torch.float32, device=dev)
+        f_input = f_buf
         log_off = ncp * k
         other_off = log_off + 1 if self.ablation.level_memory else -1
         sncv_off = log_off + 1 + (4 if self.ablation.level_memory else 0)
@@ -465,18 +494,18 @@ class DepthEstimatorLevel(torch.nn.Module):
             raise ValueError('Rotation must be expressed as a small angle (x,y,z) or a quaternion (w,x,y,z)')
         fin_ptr = f_input.data_ptr()
         time_recurr = self.ablation.time_recurr
-        log_ptr = ctypes.c_void_p(fin_ptr + 4 * (F_in - 1)) if time_recurr else None
+        log_ptr = ctypes.c_void_p(fin_ptr + 4 * (F_in - 1)) if time_recurr else None      # channel F_in - 1 of a stride-F_st row
         # DSCV (:220-221) -> f_input[..., 0:9k]; time-recurrence feature (:238) -> f_input[..., -1]
         prev_f = as_f32(prev_f_maps, "prev_f_maps")
         check(_timed("dscv", self.lvl_depth, lambda: lib.m4d_dscv_fwd(
             dptr(curr_f), dptr(prev_f), dptr(para_prev_t), dptr(para_prev_l), dptr(rot_t), rot_t.shape[1],
             dptr(tr), dptr(cf), dptr(cc), b, h, w, c, r, k, _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr),
-            F_in, None, log_ptr, F_in, scale, None, stream_ptr())), "m4d_dscv_fwd")
+            F_st, None, log_ptr, F_st, scale, None, stream_ptr())), "m4d_dscv_fwd")
         if self.ablation.SNCV:                                                         # :231-233
             check(_timed("sncv", self.lvl_depth, lambda: lib.m4d_sncv_fwd(
                 dptr(curr_f), dptr(curr_f), b, h, w, c, self.sncv_range, 1, k,
-                ctypes.c_void_p(fin_ptr + 4 * sncv_off), F_in, stream_ptr())), "m4d_sncv_fwd")
-        self.last_f_input = f_input
+                ctypes.c_void_p(fin_ptr + 4 * sncv_off), F_st, stream_ptr())), "m4d_sncv_fwd")
+        self.last_f_input = f_input if F_st == F_in else f_input[..., :F_in]      # the reference-width view (inspection / tests)
         self.last_cv_inputs = (curr_f, prev_f, para_prev_t, para_prev_l, rot_t, tr, cf, cc)   # for tools/bench_kernels.py
         # "depth_estimator" (:244-260)
         convs = list(self.disp_refiner.prep_conv_layers) + list(self.disp_refiner.est_d_conv_layers)
@@ -696,6 +725,12 @@ class M4Depth(torch.nn.Module):
                         conv._packed_weights_winograd(8)
         for lvl in self.d_estimator.levels:
             convs = list(lvl.disp_refiner.prep_conv_layers) + list(lvl.disp_refiner.est_d_conv_layers)
+            c0 = convs[0] if convs else None
+            if pad_refiner_input and c0 is not None and c0.weight is not None and c0.weight.is_cuda and c0.weight.shape[1] % 8 != 0:
+                cin_pad = (c0.weight.shape[1] + 7) // 8 * 8           # the zero-padded refiner input (DepthEstimatorLevel.forward)
+                c0._packed_weights(cin_pad)
+                c0._packed_weights_winograd(16, cin_pad)
+                c0._packed_weights_winograd(8, cin_pad)
             if len(convs) == 7 and convs[5].weight is not None and convs[5].weight.is_cuda \
                     and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16):
                 lvl._tail_w = None

@@ -117,6 +117,21 @@ def _workspace(key, nbytes, device):
     return ws
 
 
+_zero_ws_cache = {}
+
+
+def zeroed_workspace(key, shape, device):
+    """A persistent float32 buffer of ``shape`` per (purpose, shape, device, stream), zero-filled ONCE when it is created:
+    for buffers whose padding elements are never written (the channel-padded refiner input).  Created outside any
+    hipGraph capture by the eager warm-up pass; replays only reuse it."""
+    k = (key, tuple(shape), device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    buf = _zero_ws_cache.get(k)
+    if buf is None:
+        buf = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
+        _zero_ws_cache[k] = buf
+    return buf
+
+
 def dinl_act(x, scale, bias, slope=1.0, out=None, offset=(0, 0)):
     """DomainNormalization (m4depth_network.py:44-48) fused with leaky_relu(slope)
     (slope = 1.0: normalisation alone).  x [b,h,w,C], C in (16, 32).  ``out`` may be a larger
