@@ -46,15 +46,15 @@ sncv_lds_kernel(const SncvArgs a) {
   const float* c2b = a.c2 + (long long)bi * a.h * a.w * C;
 
   // ---- stage the halo tile: coalesced float4 rows, zero outside the image (:293)
-  for (int idx = threadIdx.x; idx < hh_t * hw_t * c4n; idx += blockDim.x) {
+  for (int idx = threadIdx.x; idx < hh_t * hw_t * c4n; idx += blockDim.x) {      // unconditional (clamped) loads, see sncv7_kernel
     const int c4 = idx % c4n;
     const int hp = idx / c4n;
     const int py = hp / hw_t, pxx = hp % hw_t;
     const int gy = tile_y - R + py, gx = tile_x - R + pxx;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gy >= 0 && gy < a.h && gx >= 0 && gx < a.w)
-      v = *reinterpret_cast<const float4*>(c2b + ((long long)gy * a.w + gx) * C + c4 * 4);
-    *reinterpret_cast<float4*>(tile + hp * CP + c4 * 4) = v;
+    const bool ok = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    const int cy = min(max(gy, 0), a.h - 1), cx = min(max(gx, 0), a.w - 1);
+    const float4 v = *reinterpret_cast<const float4*>(c2b + ((long long)cy * a.w + cx) * C + c4 * 4);
+    *reinterpret_cast<float4*>(tile + hp * CP + c4 * 4) = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   }
   __syncthreads();
 
@@ -143,20 +143,28 @@ sncv_lds_kernel(const SncvArgs a) {
 // identical to the oracle, bit for bit.
 typedef float sncv_f2 __attribute__((ext_vector_type(2)));
 
-template <int NC, int K, int TW, int TH>
-__global__ void __launch_bounds__(256)
+// YS > 1 splits the 7 window rows of an item over YS lane groups (256 * YS threads per workgroup): at batch 1 a level has
+// fewer (pixel, cut) items than the chip has lanes (levels 1-3: 1-2 waves per SIMD), and a lane's 49 sequential channel
+// sums are one long latency chain; with YS = 4 a lane owns 2 rows (14 results) and four times as many waves are in flight.
+template <int NC, int K, int TW, int TH, int YS>
+__global__ void __launch_bounds__(256 * YS)
 sncv7_kernel(const float* __restrict__ c, int b, int h, int w, float* __restrict__ out, int out_stride,
              int tiles_x, int tiles_y, int tiles_per_wg_band) {
   constexpr int R = 3, MO = 7;
+  constexpr int NT = 256 * YS;                        // threads per workgroup
+  constexpr int RPL = (MO + YS - 1) / YS;             // window rows per lane
   constexpr int C = NC * K, CP = C + 4, C4 = C / 4;
   constexpr int HWT = TW + 2 * R, HHT = TH + 2 * R;
   constexpr int P = TW * TH;
   constexpr int HALO_F4 = HHT * HWT * C4;
-  constexpr int U = (HALO_F4 + 255) / 256;           // float4 loads per lane to stage one halo
+  constexpr int U = (HALO_F4 + NT - 1) / NT;          // float4 loads per lane to stage one halo
   constexpr int OCH = MO * MO * K;
-  static_assert(P * K == 256, "one (pixel, cut) item per lane");
+  constexpr int ROUNDS = (P * OCH + NT - 1) / NT;     // store rounds
+  static_assert(P * K == 256, "one (pixel, cut) item per lane group");
   extern __shared__ __align__(16) float tile[];       // halo tile, later re-used as the output stage
   const int t = threadIdx.x;
+  const int item = t & 255;
+  const int ys = YS > 1 ? __builtin_amdgcn_readfirstlane(t >> 8) : 0;        // wave-uniform -> scalar
   const int tiles_img = tiles_x * tiles_y;
   const long long total_tiles = (long long)tiles_img * b;
   // XCD banding: workgroup g runs on XCD g % 8 and owns every (gridDim/8)-th tile of band g % 8
@@ -166,32 +174,40 @@ sncv7_kernel(const float* __restrict__ c, int b, int h, int w, float* __restrict
   const long long band_lo = band * band_len;
   const long long band_hi = band_lo + band_len < total_tiles ? band_lo + band_len : total_tiles;
 
-  const int kk = t % K, lp = t / K;
+  const int kk = item % K, lp = item / K;
   const int ty = lp / TW, tx = lp % TW;
 
+  // The halo loads are UNCONDITIONAL (clamped coordinates, validity applied at the commit): a load under a branch makes
+  // hipcc wait for it at the merge.
   float4 pre[U];
+  unsigned pre_ok = 0;
   auto issue_loads = [&](long long tile_id) {
     const int bi = (int)(tile_id / tiles_img);
     const int tl = (int)(tile_id - (long long)bi * tiles_img);
     const int y0 = (tl / tiles_x) * TH - R, x0 = (tl % tiles_x) * TW - R;
     const float* img = c + (long long)bi * h * w * C;
+    pre_ok = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int idx = u * 256 + t;
+      const int idx = min(u * NT + t, HALO_F4 - 1);
       const int hp = idx / C4, c4 = idx % C4;
       const int py = hp / HWT, pxx = hp % HWT;
       const int gy = y0 + py, gx = x0 + pxx;
-      pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);                                   // zero padding (:293)
-      if (idx < HALO_F4 && gy >= 0 && gy < h && gx >= 0 && gx < w)
-        pre[u] = *reinterpret_cast<const float4*>(img + ((long long)gy * w + gx) * C + c4 * 4);
+      const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
+      pre_ok |= ok ? (1u << u) : 0u;
+      const int cy = min(max(gy, 0), h - 1), cx = min(max(gx, 0), w - 1);
+      pre[u] = *reinterpret_cast<const float4*>(img + ((long long)cy * w + cx) * C + c4 * 4);
     }
   };
   auto commit_loads = [&]() {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int idx = u * 256 + t;
+      const int idx = u * NT + t;
       const int hp = idx / C4, c4 = idx % C4;
-      if (idx < HALO_F4) *reinterpret_cast<float4*>(tile + hp * CP + c4 * 4) = pre[u];
+      const bool ok = (pre_ok >> u) & 1u;
+      const float4 v = pre[u];
+      if (idx < HALO_F4)                                                            // zero padding (:293)
+        *reinterpret_cast<float4*>(tile + hp * CP + c4 * 4) = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
     }
   };
 
@@ -209,7 +225,7 @@ sncv7_kernel(const float* __restrict__ c, int b, int h, int w, float* __restrict
     const int tl = (int)(cur - (long long)bi * tiles_img);
     const int tile_y = (tl / tiles_x) * TH, tile_x = (tl % tiles_x) * TW;
 
-    // ---- correlate: lane = (pixel, cut); c1 = the pixel's own vector (tile centre)
+    // ---- correlate: lane = (pixel, cut, row group); c1 = the pixel's own vector (tile centre)
     const float* base = tile + (ty * HWT + tx) * CP + kk * NC;
     sncv_f2 c1p[NC / 2];
 #pragma unroll
@@ -218,9 +234,12 @@ sncv7_kernel(const float* __restrict__ c, int b, int h, int w, float* __restrict
       c1p[cc / 2] = sncv_f2{v.x, v.y};
       c1p[cc / 2 + 1] = sncv_f2{v.z, v.w};
     }
-    float res[MO * MO];
+    float res[RPL * MO];
+    const int y_lo = ys * RPL;
 #pragma unroll
-    for (int y = 0; y < MO; ++y) {
+    for (int yy = 0; yy < RPL; ++yy) {
+      const int y = y_lo + yy;
+      if (YS > 1 && MO % YS != 0 && y >= MO) break;    // uneven split: the last group has fewer rows (wave-uniform)
 #pragma unroll
       for (int x = 0; x < MO; ++x) {
         float acc = 0.f;
@@ -233,20 +252,25 @@ sncv7_kernel(const float* __restrict__ c, int b, int h, int w, float* __restrict
           acc = acc + pa.y; acc = acc + pb.x; acc = acc + pb.y;
         }
         const float mean = acc / (float)NC;                             // :308
-        res[y * MO + x] = fmaxf(mean, mean * 0.1f);                     // leaky_relu(0.1) == max(x, 0.1 x) (:311)
+        res[yy * MO + x] = fmaxf(mean, mean * 0.1f);                    // leaky_relu(0.1) == max(x, 0.1 x) (:311)
       }
     }
     __syncthreads();                                   // every lane is done reading the halo
     // ---- output rows of the tile, [pixel][(y*7+x)*K + kk], in the same LDS bytes
 #pragma unroll
-    for (int d = 0; d < MO * MO; ++d) tile[lp * OCH + d * K + kk] = res[d];
+    for (int yy = 0; yy < RPL; ++yy) {
+      if (y_lo + yy < MO) {
+#pragma unroll
+        for (int x = 0; x < MO; ++x) tile[lp * OCH + ((y_lo + yy) * MO + x) * K + kk] = res[yy * MO + x];
+      }
+    }
     __syncthreads();
 #pragma unroll 7
-    for (int it = 0; it < MO * MO; ++it) {             // P*OCH floats = (P*K/256) * 49 = 49 rounds of 256 lanes
-      const int e = it * 256 + t;
+    for (int it = 0; it < ROUNDS; ++it) {
+      const int e = it * NT + t;
       const int pxl = e / OCH, ch = e % OCH;
       const int oy = tile_y + pxl / TW, ox = tile_x + pxl % TW;
-      if (oy < h && ox < w)
+      if (e < P * OCH && oy < h && ox < w)
         out[(((long long)bi * h + oy) * w + ox) * out_stride + ch] = tile[e];
     }
     if (!has_next) break;
@@ -257,8 +281,8 @@ sncv7_kernel(const float* __restrict__ c, int b, int h, int w, float* __restrict
   }
 }
 
-template <int NC, int K, int TW, int TH>
-bool launch_sncv7(const float* c, int b, int h, int w, float* out, int out_stride, hipStream_t s) {
+template <int NC, int K, int TW, int TH, int YS>
+bool launch_sncv7_ys(const float* c, int b, int h, int w, float* out, int out_stride, hipStream_t s) {
   constexpr int C = NC * K, CP = C + 4, HWT = TW + 6, HHT = TH + 6, OCH = 49 * K;
   constexpr size_t halo = (size_t)HHT * HWT * CP * sizeof(float);
   constexpr size_t stage = (size_t)TW * TH * OCH * sizeof(float);
@@ -266,19 +290,34 @@ bool launch_sncv7(const float* c, int b, int h, int w, float* out, int out_strid
   static_assert(lds <= 160 * 1024, "tile does not fit LDS");
   const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
   const long long total = (long long)tiles_x * tiles_y * b;
-  const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
-  long long nwg = 256LL * (per_cu > 0 ? per_cu : 1);            // persistent: one resident wave of workgroups
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 3) per_cu = 3;
+  if (per_cu * YS > 8) per_cu = 8 / YS;                             // 2048 threads per CU
+  long long nwg = 256LL * (per_cu > 0 ? per_cu : 1);                // persistent: one resident wave of workgroups
   if (nwg > total) nwg = (total + 7) / 8 * 8;
   if (nwg < 8) nwg = 8;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sncv7_kernel<NC, K, TW, TH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sncv7_kernel<NC, K, TW, TH, YS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((sncv7_kernel<NC, K, TW, TH>), dim3((int)nwg), dim3(256), lds, s, c, b, h, w, out, out_stride,
+  hipLaunchKernelGGL((sncv7_kernel<NC, K, TW, TH, YS>), dim3((int)nwg), dim3(256 * YS), lds, s, c, b, h, w, out, out_stride,
                      tiles_x, tiles_y, 0);
   return true;
+}
+
+// Row split by how many (pixel, cut) items the launch has: enough lanes for ~8 waves per SIMD without a split -> YS = 1.
+template <int NC, int K, int TW, int TH>
+bool launch_sncv7(const float* c, int b, int h, int w, float* out, int out_stride, hipStream_t s) {
+  static int ys_env = -1;                             // M4D_SNCV_YS = 1 | 2 | 4 forces the split (profiling)
+  if (ys_env < 0) { const char* e = getenv("M4D_SNCV_YS"); ys_env = e ? atoi(e) : 0; }
+  const long long items = (long long)b * h * w * K;
+  int ys = ys_env ? ys_env : (items >= 1000000 ? 1 : (items >= 400000 ? 2 : 4));
+  if (NC > 16 && ys > 2) ys = 2;                       // 32 channels per cut do not fit the 128 VGPRs of a 1024-thread workgroup
+  if (ys == 4) return launch_sncv7_ys<NC, K, TW, TH, (NC > 16 ? 2 : 4)>(c, b, h, w, out, out_stride, s);
+  if (ys == 2) return launch_sncv7_ys<NC, K, TW, TH, 2>(c, b, h, w, out, out_stride, s);
+  return launch_sncv7_ys<NC, K, TW, TH, 1>(c, b, h, w, out, out_stride, s);
 }
 
 // Any C / k / alignment / window: one lane per output element, global reads.
