@@ -504,3 +504,22 @@ def test_winograd_kernel_4_is_bitwise_kernel_2(dev, tmp_path):
     res = subprocess.run([sys.executable, tool, "--compare", *outs], check=True, timeout=600, capture_output=True, text=True).stdout
     lines = [l for l in res.strip().splitlines() if l]
     assert len(lines) >= 5 and all(l.endswith("bit-identical") for l in lines), res
+
+
+def test_sncv_variants_are_bitwise_identical(dev, tmp_path):
+    """m4d_sncv_fwd picks, by map size, the small-map kernel or the r = 3 tile kernel with its window rows split over
+    1 / 2 / 4 lane groups; every choice must give the same bits.  The choices are read once per process, hence one
+    subprocess per setting."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "sncv_variant_check.py")
+    outs = []
+    for name, env_add in (("ys1", {"M4D_SNCV_YS": "1", "M4D_SNCV_SMALL_PX": "0"}), ("ys2", {"M4D_SNCV_YS": "2", "M4D_SNCV_SMALL_PX": "0"}),
+                          ("ys4", {"M4D_SNCV_YS": "4", "M4D_SNCV_SMALL_PX": "0"}), ("small", {"M4D_SNCV_SMALL_PX": "100000"}),
+                          ("generic", {"M4D_SNCV_VARIANT": "0"})):
+        out = str(tmp_path / f"{name}.pt")
+        subprocess.run([sys.executable, tool, "--save", out], check=True, env=dict(os.environ, **env_add), timeout=600, capture_output=True)
+        outs.append(out)
+    res = subprocess.run([sys.executable, tool, "--compare", *outs], check=True, timeout=600, capture_output=True, text=True).stdout
+    lines = [l for l in res.strip().splitlines() if l]
+    assert len(lines) == 4 * 5 and all(l.endswith("bit-identical") for l in lines), res
