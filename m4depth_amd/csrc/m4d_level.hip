@@ -3,6 +3,7 @@
 // elementwise stages on either side of the refiner convolutions.  All of these are
 // one-pass, one-lane-per-pixel (or per element) streaming kernels: HBM-bound by
 // construction, no re-reads.
+#include <cstdlib>
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
 
@@ -36,6 +37,44 @@ normalize_cuts_kernel(const float* __restrict__ x, long long items, int C, int k
       for (int c = 0; c < nc; ++c) o[c] = p[c] / nrm;
     }
   }
+}
+
+// Coalesced variant for nc = 4 * LPG channels per cut: LPG consecutive lanes hold one (pixel, cut) run, 16 bytes each
+// (the kernel above gives every lane a whole run: 16-byte loads 64-128 bytes apart, each run read twice).  The sum of
+// squares keeps the reference's channel order: lane j continues the chain of lane j - 1 (LPG dependent steps through a
+// lane shift), so the result is bit-identical to the sequential kernel.
+template <int LPG>
+__global__ void __launch_bounds__(256)
+normalize_cuts_group_kernel(const float* __restrict__ x, long long items, float* __restrict__ out) {
+  constexpr int GPW = 64 / LPG;                 // runs per wave (LPG = 6: 10 runs, 4 idle lanes)
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int g = lane / LPG, j = lane - g * LPG;
+  const long long it = wave * GPW + g;
+  const bool active = g < GPW && it < items;
+  const long long itc = it < items ? it : items - 1;                   // unconditional load (clamped), masked store
+  const float4 v = *reinterpret_cast<const float4*>(x + (itc * LPG + (g < GPW ? j : 0)) * 4);
+  float acc = 0.f;
+#pragma unroll
+  for (int s = 0; s < LPG; ++s) {
+    const float prev = __shfl_up(acc, 1);                             // the running sum of the lane before (same run for j >= 1)
+    if (j == s) {
+      acc = (s == 0) ? v.x * v.x : prev + v.x * v.x;
+      acc = acc + v.y * v.y; acc = acc + v.z * v.z; acc = acc + v.w * v.w;
+    }
+  }
+  const float tot = __shfl(acc, g < GPW ? g * LPG + LPG - 1 : lane);   // the run's last lane holds the full sum
+  const float nrm = sqrtf(tot);
+  if (active)
+    *reinterpret_cast<float4*>(out + (it * LPG + j) * 4) = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+}
+
+template <int LPG>
+void launch_normalize_group(const float* x, long long items, float* out, hipStream_t s) {
+  constexpr int GPW = 64 / LPG;
+  const long long waves = (items + GPW - 1) / GPW;
+  const long long blocks = (waves + 3) / 4;
+  hipLaunchKernelGGL(normalize_cuts_group_kernel<LPG>, dim3((unsigned)blocks), dim3(256), 0, s, x, items, out);
 }
 
 // ---- tf.compat.v1.image.resize_bilinear, legacy coordinates (:202-204) ----------
@@ -236,6 +275,18 @@ extern "C" int m4d_normalize_cuts(const float* x, int b, int h, int w, int C, in
   const int nc = C / nbre_cuts;
   const long long items = (long long)b * h * w * nbre_cuts;
   const bool vec = (nc % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out) & 15u) == 0);
+  static int grouped = -1;                     // M4D_NORMALIZE_GROUPED=0: the one-lane-per-run kernel (same bits)
+  if (grouped < 0) { const char* e = getenv("M4D_NORMALIZE_GROUPED"); grouped = e ? atoi(e) : 1; }
+  if (vec && grouped && items < (1LL << 40)) {
+    hipStream_t s = (hipStream_t)stream;
+    switch (nc) {
+      case 8: launch_normalize_group<2>(x, items, out, s); return M4D_LAUNCH_RESULT();
+      case 16: launch_normalize_group<4>(x, items, out, s); return M4D_LAUNCH_RESULT();
+      case 24: launch_normalize_group<6>(x, items, out, s); return M4D_LAUNCH_RESULT();
+      case 32: launch_normalize_group<8>(x, items, out, s); return M4D_LAUNCH_RESULT();
+      default: break;
+    }
+  }
   if (vec) hipLaunchKernelGGL(normalize_cuts_kernel<true>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, items, C, nbre_cuts, nc, out);
   else hipLaunchKernelGGL(normalize_cuts_kernel<false>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, items, C, nbre_cuts, nc, out);
   return M4D_LAUNCH_RESULT();
