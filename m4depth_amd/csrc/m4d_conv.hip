@@ -430,10 +430,14 @@ extern "C" int m4d_conv3x3s_bias_act_ws(const float* x, const float* wp, const f
   // every split keeps >= 2 chunks, partial sums go through the caller's workspace
   const long long blocks = tiles * b * (n32 / nt);
   int ksplit = 1;
+  static int sk_target = -1, sk_min_chunks = -1, sk_max = -1;     // tuning knobs (profiling): M4D_CONV_SPLITK_TARGET / _MIN_CHUNKS / _MAX
+  if (sk_target < 0) { const char* e = getenv("M4D_CONV_SPLITK_TARGET"); sk_target = e ? atoi(e) : 256; }
+  if (sk_min_chunks < 0) { const char* e = getenv("M4D_CONV_SPLITK_MIN_CHUNKS"); sk_min_chunks = e ? atoi(e) : 2; }
+  if (sk_max < 0) { const char* e = getenv("M4D_CONV_SPLITK_MAX"); sk_max = e ? atoi(e) : 16; }
   if (workspace != nullptr && blocks < 128 && a.n_chunks >= 4) {
-    ksplit = (int)((256 + blocks - 1) / blocks);
-    if (ksplit > a.n_chunks / 2) ksplit = a.n_chunks / 2;
-    if (ksplit > 16) ksplit = 16;
+    ksplit = (int)((sk_target + blocks - 1) / blocks);
+    if (ksplit > a.n_chunks / sk_min_chunks) ksplit = a.n_chunks / sk_min_chunks;
+    if (ksplit > sk_max) ksplit = sk_max;
     while (ksplit > 1 && (long long)ksplit * b * a.oh * a.ow * CoutPad > workspace_floats) --ksplit;
   }
   a.chunks_per_split = (a.n_chunks + ksplit - 1) / ksplit;
