@@ -617,6 +617,9 @@ class DepthEstimatorPyramid(torch.nn.Module):
         n_fr = len(traj_samples)
         f_pyrs = [None] * n_fr
         d_est = [None] * n_fr                         # per frame: estimates so far, coarse -> fine
+        # (Measured, tools/step_profile.py + tools/ab_bench.sh: the late encoder batch below is independent of the first
+        # frames' decoder, yet issuing it FIRST so that it runs beside their coarse-level chain costs 4.5 % -- chip-filling
+        # kernels delay the chain's small ones; where it is issued now it overlaps the first level-1 pass instead.)
         # Issue order = anti-diagonals of the (frame, level) grid: level l of frame t right after level l of frame
         # t-1.  Every stream still sees its own frame coarse -> fine, but the launch (and hipGraph node) order puts
         # the next frame's coarse levels ahead of the current frame's fine ones.
