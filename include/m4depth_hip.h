@@ -294,6 +294,13 @@ int m4d_conv3x3s_bias_act_ws(const float* x, const float* wp, const float* bias,
 int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const float* bias, int b, int h, int w,
                             int Cin, int Cout, int CoutPad, float slope, float* out, float* workspace,
                             long long workspace_floats, void* stream);
+/* The same stride-1 layer for SMALL maps (the DispRefiner convolutions of the coarsest pyramid levels, m4depth_network.py:
+ * 116-135 at 6x20 ... 24x80 pixels): ONE launch -- a workgroup is an 8x4-pixel tile x 32 output channels whose four waves
+ * walk interleaved 16-channel K chunks independently and add their partial tiles in wave order -- instead of the split-K
+ * pair (partial sums + ordered reduce) the general entry needs there.  Cin >= 16, Cin % 4 == 0; same packed weights;
+ * deterministic.  The caller picks it by map size (m4depth_amd.network: refiner layers with b*h*w <= 2048 and Cin <= 256). */
+int m4d_conv3x3_small_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                               int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
 
 /* DomainNormalization (m4depth_network.py:44-48) fused with the leaky_relu(slope) that follows it
  * at encoder level 0 (:82-84; slope = 1 for the normalisation alone).  x, out [b,h,w,C] (C = 16 or

@@ -305,6 +305,158 @@ conv3x3_mfma_kernel(const ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small maps (the coarsest pyramid levels: 120 - 2000 pixels).  The kernel above needs split-K there to produce enough
+// workgroups, i.e. TWO launches per layer (partial sums + ordered reduce) on what is a pure latency chain -- five such
+// layers per level, and the first frame's coarse-level chain runs with the chip otherwise idle (tools/step_profile.py).
+// Here the K split happens INSIDE the workgroup: a workgroup is one 8x4-pixel tile (one MFMA M-tile) x 32 output
+// channels, and its four waves walk interleaved K chunks (chunk c -> wave c % 4) completely independently -- each wave
+// stages its own halo + weight chunk in its own LDS region, no workgroup barrier inside the K loop -- then the four
+// 32x32 partial tiles are added in wave order through LDS, + bias, leaky_relu, store.  One launch per layer,
+// deterministic.  Same packed weights as the kernel above.
+constexpr int kSW = 8, kSH = 4;                      // output tile
+constexpr int kSHW = kSW + 2, kSHP = (kSW + 2) * (kSH + 2);   // halo 10 x 6 = 60 pixels
+constexpr int kSA = kSHP * kRS;                      // floats of one wave's halo chunk   (4.8 KB)
+constexpr int kSB = 9 * 32 * kRS;                    // floats of one wave's weight chunk (23 KB)
+
+__global__ void __launch_bounds__(256, 1)            // one workgroup per CU (111 KB of LDS): the whole register file is available
+conv3x3_small_kernel(const ConvArgs a) {
+  constexpr int A_PER = (kSHP * 4 + 63) / 64;         // 4 float4 per lane
+  constexpr int B_PER = (9 * 32 * 4) / 64;            // 18 float4 per lane
+  extern __shared__ __align__(16) float lds_dyn[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  float* lds_a = lds_dyn + wave * (kSA + kSB);
+  float* lds_b = lds_a + kSA;
+  const int tile = blockIdx.x;
+  const int tile_y = (tile / a.tiles_x) * kSH, tile_x = (tile % a.tiles_x) * kSW;
+  const int n0 = blockIdx.y * 32;
+  const int bi = blockIdx.z;
+  const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
+
+  // hoisted loader geometry: halo pixel (clamped) and validity per A slot, weight row offset per B slot
+  int a_off[A_PER], a_dst[A_PER];
+  unsigned a_ok = 0;
+  const int aq = lane & 3;                            // channels 4aq .. 4aq+3 of the chunk
+#pragma unroll
+  for (int u = 0; u < A_PER; ++u) {
+    const int idx = u * 64 + lane;
+    const int hp = min(idx >> 2, kSHP - 1);
+    const int gy = tile_y - 1 + hp / kSHW, gx = tile_x - 1 + hp % kSHW;
+    const bool ok = (idx >> 2) < kSHP && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    a_ok |= ok ? (1u << u) : 0u;
+    a_off[u] = (min(max(gy, 0), a.h - 1) * a.w + min(max(gx, 0), a.w - 1)) * a.Cin + 4 * aq;
+    a_dst[u] = (idx >> 2) < kSHP ? hp * kRS + 2 * aq : -1;
+  }
+  int b_off[B_PER];
+#pragma unroll
+  for (int u = 0; u < B_PER; ++u) {
+    const int idx = u * 64 + lane;
+    const int row = idx >> 2, c4 = idx & 3;           // row = tap * 32 + n
+    b_off[u] = (((row >> 5) * a.CoutPad + n0 + (row & 31)) * kKC + c4 * 4);
+  }
+  const long long b_chunk = 9LL * a.CoutPad * kKC;
+
+  float4 ra[A_PER], rb0[B_PER / 2], rb1[B_PER / 2];   // two halves: one 72-dword array is not kept in registers by hipcc
+  bool ra_ch_ok = true;
+  auto load_chunk = [&](int chunk) __attribute__((always_inline)) {   // unconditional loads (clamped), validity applied at the commit
+    const int c0 = chunk * kKC;
+    ra_ch_ok = c0 + 4 * aq < a.Cin;
+    const int cc = min(c0, a.Cin - 4 - 4 * aq);       // keeps the 16-byte read inside the pixel's channel run
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) ra[u] = *reinterpret_cast<const float4*>(ximg + a_off[u] + cc);
+    const float* wb = a.wp + chunk * b_chunk;
+#pragma unroll
+    for (int u = 0; u < B_PER / 2; ++u) {
+      rb0[u] = *reinterpret_cast<const float4*>(wb + b_off[u]);
+      rb1[u] = *reinterpret_cast<const float4*>(wb + b_off[B_PER / 2 + u]);
+    }
+  };
+  auto commit_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const bool ok = ((a_ok >> u) & 1u) && ra_ch_ok;
+      const float4 v = ra[u];
+      if (a_dst[u] >= 0) {                            // even channels -> slots 0..7, odd channels -> slots 8..15
+        *reinterpret_cast<float2*>(lds_a + a_dst[u]) = make_float2(ok ? v.x : 0.f, ok ? v.z : 0.f);
+        *reinterpret_cast<float2*>(lds_a + a_dst[u] + 8) = make_float2(ok ? v.y : 0.f, ok ? v.w : 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < B_PER / 2; ++u) {
+      const int idx = u * 64 + lane, idx1 = (B_PER / 2 + u) * 64 + lane;
+      const float4 v0 = rb0[u], v1 = rb1[u];         // component-wise: a whole-struct copy out of the array keeps it in scratch
+      *reinterpret_cast<float4*>(lds_b + (idx >> 2) * kRS + (idx & 3) * 4) = make_float4(v0.x, v0.y, v0.z, v0.w);
+      *reinterpret_cast<float4*>(lds_b + (idx1 >> 2) * kRS + (idx1 & 3) * 4) = make_float4(v1.x, v1.y, v1.z, v1.w);
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int m = lane & 31, kh = lane >> 5;
+  const float* a_lane = lds_a + ((m >> 3) * kSHW + (m & 7)) * kRS + kh * 8;
+  const float* b_lane = lds_b + m * kRS + kh * 8;
+  auto compute_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* ap = a_lane + ((tap / 3) * kSHW + (tap % 3)) * kRS;
+      const float* bp = b_lane + tap * 32 * kRS;
+      const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], bv[ks], acc, 0, 0, 0);
+    }
+  };
+
+  // this wave's chunks: wave, wave + 4, ...  The next chunk's loads are in flight while the current one is multiplied;
+  // the LDS region is private to the wave, whose DS operations execute in order: no workgroup barrier here.
+  if (wave < a.n_chunks) {
+    load_chunk(wave);
+    for (int c = wave; c < a.n_chunks; c += 4) {
+      commit_chunk();
+      __builtin_amdgcn_wave_barrier();
+      load_chunk(min(c + 4, a.n_chunks - 1));          // unconditional (the surplus load of the last round is never committed)
+      compute_chunk();
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();                                     // the reduction buffer aliases the staging regions
+
+  // ---- the four partial tiles, added in wave order, + bias, leaky_relu, NHWC store
+  constexpr int kRP = 36;                              // floats per pixel row of a partial tile: 32 couts + 4 pad
+  float* red = lds_dyn;                                // [4 waves][32 pixels][kRP]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;    // C/D map of the 32x32 MFMA: col = lane & 31, row = mr
+    red[(wave * 32 + mr) * kRP + m] = acc[r];
+  }
+  __syncthreads();
+  {
+    const int p = t >> 3, cq = t & 7;                  // pixel of the tile, output-channel quad
+    const int oy = tile_y + (p >> 3), ox = tile_x + (p & 7);
+    const int co = n0 + 4 * cq;
+    if (oy < a.oh && ox < a.ow && co < a.Cout) {
+      const float4 s0 = *reinterpret_cast<const float4*>(red + (0 * 32 + p) * kRP + 4 * cq);
+      const float4 s1 = *reinterpret_cast<const float4*>(red + (1 * 32 + p) * kRP + 4 * cq);
+      const float4 s2 = *reinterpret_cast<const float4*>(red + (2 * 32 + p) * kRP + 4 * cq);
+      const float4 s3 = *reinterpret_cast<const float4*>(red + (3 * 32 + p) * kRP + 4 * cq);
+      const float sum[4] = {((s0.x + s1.x) + s2.x) + s3.x, ((s0.y + s1.y) + s2.y) + s3.y,
+                            ((s0.z + s1.z) + s2.z) + s3.z, ((s0.w + s1.w) + s2.w) + s3.w};
+      float* op = a.out + (((long long)bi * a.oh + oy) * a.ow + ox) * a.Cout + co;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (co + e < a.Cout) {
+          float v = sum[e] + a.bias[co + e];
+          op[e] = v > 0.f ? v : v * a.slope;
+        }
+      }
+    }
+  }
+}
+
 // out = leaky_relu(bias + sum_ks ws[ks]) with the partial sums added in split order (deterministic)
 __global__ void __launch_bounds__(256)
 conv_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias, long long pixels, int Cout,
@@ -359,6 +511,31 @@ void dispatch_conv(const ConvArgs& a, int nt, dim3 grid, hipStream_t s) {
 extern "C" int m4d_conv3x3_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
                                     int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
   return m4d_conv3x3s_bias_act_ws(x, wp, bias, b, h, w, Cin, Cout, CoutPad, 1, slope, out, nullptr, 0, stream);
+}
+
+// Small maps: one launch with the K split inside the workgroup instead of split-K + reduce (conv3x3_small_kernel).
+extern "C" int m4d_conv3x3_small_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                                          int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  M4D_CHECK_ARG(x && wp && bias && out && b > 0 && h > 0 && w > 0 && Cout > 0);
+  M4D_CHECK_ARG(Cin >= 16 && Cin % 4 == 0 && CoutPad % 32 == 0 && CoutPad >= Cout);
+  M4D_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)wp)) & 15u) == 0);
+  ConvArgs a;
+  a.x = x; a.wp = wp; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
+  a.CoutPad = CoutPad; a.n_chunks = (Cin + kKC - 1) / kKC;
+  a.dn_mean = a.dn_var = a.dn_scale = a.dn_bias = nullptr; a.dn_slope = 1.0f;
+  a.ablate = 0; a.oh = h; a.ow = w; a.pad_y = a.pad_x = 1; a.slope = slope;
+  a.tiles_x = (w + kSW - 1) / kSW; a.tiles_y = (h + kSH - 1) / kSH;
+  a.ksplit = 1; a.chunks_per_split = a.n_chunks; a.ws = nullptr;
+  constexpr size_t lds = (size_t)4 * (kSA + kSB) * sizeof(float);                       // 111 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3x3_small_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b), dim3(256),
+                     lds, (hipStream_t)stream, a);
+  return M4D_LAUNCH_RESULT();
 }
 
 extern "C" long long m4d_conv3x3_workspace_floats(int b, int h, int w, int CoutPad) {

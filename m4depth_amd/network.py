@@ -85,6 +85,12 @@ def _use_winograd(b, h, w, cin, cout, stride):
 # of level 2 becomes eligible for the 8-channel-chunk Winograd kernels (122 -> 128).  0 = exact-width input.
 pad_refiner_input = _os.environ.get("M4D_PAD_REFINER_INPUT", "1") == "1"
 
+# DispRefiner layers on maps of at most this many pixels (batch included) and at most 256 input channels run as ONE
+# launch with the K split inside the workgroup (m4d_conv3x3_small_bias_act) instead of split-K + reduce: levels 4-6 at
+# batch 1, +2.5 % frames/s (tools/ab_bench.sh).  Refiner layers only: their batch is the caller's batch in every launch
+# mode, so the pipelined and the single-stream forward keep choosing the same kernel (bitwise-neutrality test).  0 = off.
+small_map_conv_pixels = int(_os.environ.get("M4D_CONV_SMALL_PX", "2048"))
+
 # Encoder level 0 as two fused kernels (direct 3->16 convolution + bias + DINL statistics; DINL apply fused into the
 # stride-2 convolution's input staging) instead of MIOpen conv + bias pass + 3 DINL passes + conv: no MIOpen kernel is
 # left in the inference path.  0 = the unfused sequence.
@@ -134,6 +140,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.bias = None
         self._packed = None
         self.tag = None                  # e.g. "lvl1.conv1": lets bench.py bracket one layer with HIP events
+        self.small_maps_ok = False       # DispRefiner layers: may take the one-launch small-map kernel
         if in_channels is not None:
             self._build(in_channels, None)
 
@@ -222,6 +229,10 @@ class _Conv3x3SameTF(torch.nn.Module):
                 return _timed("conv", self.tag, lambda: fn(
                     x_nhwc, wu, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope))
             wp, cpad = self._packed_weights(cin_)
+            if (self.small_maps_ok and self.stride == 1 and b_ * h_ * w_ <= small_map_conv_pixels and 16 <= cin_ <= 256
+                    and cin_ % 4 == 0):
+                return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(
+                    x_nhwc, wp, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope))
             return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
                 x_nhwc, wp, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope, stride=self.stride))
         x = x_nhwc.permute(0, 3, 1, 2)                   # channels-last NCHW view, no copy
@@ -363,6 +374,8 @@ class DispRefiner(torch.nn.Module):
         cin = [in_channels] + chans[:-1]
         self.prep_conv_layers = torch.nn.ModuleList([_Conv3x3SameTF(n, 1, ci) for n, ci in zip(chans[:3], cin[:3])])
         self.est_d_conv_layers = torch.nn.ModuleList([_Conv3x3SameTF(n, 1, ci) for n, ci in zip(chans[3:], cin[3:])])
+        for conv in list(self.prep_conv_layers) + list(self.est_d_conv_layers):
+            conv.small_maps_ok = True
 
     def forward(self, feature_map):
         prev_out = feature_map

@@ -523,3 +523,30 @@ def test_sncv_variants_are_bitwise_identical(dev, tmp_path):
     res = subprocess.run([sys.executable, tool, "--compare", *outs], check=True, timeout=600, capture_output=True, text=True).stdout
     lines = [l for l in res.strip().splitlines() if l]
     assert len(lines) == 4 * 5 and all(l.endswith("bit-identical") for l in lines), res
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,slope", [
+    (1, 6, 20, 128, 128, 0.1),        # level-6 geometry
+    (2, 12, 40, 240, 128, 0.1),       # level-5 first layer (padded refiner input), 15 chunks over 4 waves
+    (1, 24, 80, 64, 32, 0.1),
+    (1, 5, 7, 20, 40, 1.0),           # ragged tile, half-empty last chunk, Cout < CoutPad, 2 chunks (two waves idle)
+    (3, 9, 11, 16, 5, 0.1),           # a single chunk
+])
+def test_small_map_conv(M, dev, b, h, w, cin, cout, slope):
+    """m4d_conv3x3_small_bias_act (one launch, K split over the waves of a workgroup) vs the oracle; deterministic."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.standard_normal([b, h, w, cin]).astype(F)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = (0.1 * rng.standard_normal([cout])).astype(F)
+    wp, cpad = nops.pack_conv_weights(k)
+    xd, wd, bd = to_dev(x, dev), to_dev(wp, dev), to_dev(bias, dev)
+    got = nops.conv3x3_small_bias_act(xd, wd, bd, cout, cpad, slope)
+    ref = O.conv2d_same(x, k, bias, 1)
+    ref = np.where(ref > 0, ref, ref * F(slope)).astype(F)
+    err = np.max(np.abs(npy(got) - ref))
+    assert err < 1e-5 * max(1.0, np.abs(ref).max()), err
+    assert torch.equal(got, nops.conv3x3_small_bias_act(xd, wd, bd, cout, cpad, slope))
+    # the general entry (split-K + ordered reduce on such maps) agrees to rounding
+    alt = nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, slope)
+    assert np.max(np.abs(npy(alt) - npy(got))) < 1e-5 * max(1.0, np.abs(ref).max())
