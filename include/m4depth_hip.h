@@ -250,6 +250,15 @@ int m4d_level_pre(const float* prev_l_depth, const float* prev_l_parallax, const
                   float* para_prev_l, float* depth_prev_l, float* other_prev_l, float* para_prev_t,
                   float* f_input, int f_stride, int log_off, int other_off, float log_scale,
                   void* stream);
+/* m4d_level_pre and m4d_normalize_cuts(norm_x -> norm_out) -- the two independent kernels that open a level
+ * (m4depth_network.py:179-189 and :196-227) -- in ONE launch: one kernel boundary less on the coarse-level latency chain.
+ * Same results, bit for bit. */
+int m4d_level_pre_normalize(const float* prev_l_depth, const float* prev_l_parallax, const float* prev_l_other,
+                            int ph, int pw, const float* depth_prev_t, const float* trans,
+                            const float* cam_f, const float* cam_c, int b, int h, int w,
+                            float* para_prev_l, float* depth_prev_l, float* other_prev_l, float* para_prev_t,
+                            float* f_input, int f_stride, int log_off, int other_off, float log_scale,
+                            const float* norm_x, int C, int nbre_cuts, float* norm_out, void* stream);
 
 /* Fused "depth_estimator" tail of one level (:247-260): refiner_out [b,h,w,5] ->
  * parallax = exp(clip(out0,-7,7)) / scale, other = out[1:5], depth =

@@ -44,11 +44,11 @@ normalize_cuts_kernel(const float* __restrict__ x, long long items, int C, int k
 // squares keeps the reference's channel order: lane j continues the chain of lane j - 1 (LPG dependent steps through a
 // lane shift), so the result is bit-identical to the sequential kernel.
 template <int LPG>
-__global__ void __launch_bounds__(256)
-normalize_cuts_group_kernel(const float* __restrict__ x, long long items, float* __restrict__ out) {
+__device__ __forceinline__ void normalize_cuts_group_body(const float* __restrict__ x, long long items, float* __restrict__ out,
+                                                          long long block) {
   constexpr int GPW = 64 / LPG;                 // runs per wave (LPG = 6: 10 runs, 4 idle lanes)
   const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long wave = (block * blockDim.x + threadIdx.x) >> 6;
   const int g = lane / LPG, j = lane - g * LPG;
   const long long it = wave * GPW + g;
   const bool active = g < GPW && it < items;
@@ -67,6 +67,12 @@ normalize_cuts_group_kernel(const float* __restrict__ x, long long items, float*
   const float nrm = sqrtf(tot);
   if (active)
     *reinterpret_cast<float4*>(out + (it * LPG + j) * 4) = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+}
+
+template <int LPG>
+__global__ void __launch_bounds__(256)
+normalize_cuts_group_kernel(const float* __restrict__ x, long long items, float* __restrict__ out) {
+  normalize_cuts_group_body<LPG>(x, items, out, blockIdx.x);
 }
 
 template <int LPG>
@@ -141,9 +147,7 @@ struct LevelPreArgs {
   float* f_input; int f_stride, log_off, other_off; float log_scale;
 };
 
-__global__ void __launch_bounds__(256)
-level_pre_kernel(const LevelPreArgs a) {
-  const int bi = blockIdx.y;
+__device__ __forceinline__ void level_pre_body(const LevelPreArgs& a, int bx, int bi, int gdx) {
   const int hw = a.h * a.w;
   const bool has_prev = a.pl_depth != nullptr;
   const float sy = has_prev ? (float)a.ph / (float)a.h : 0.f;
@@ -155,7 +159,7 @@ level_pre_kernel(const LevelPreArgs a) {
     tx = a.trans[bi * 3]; ty = a.trans[bi * 3 + 1]; tz = a.trans[bi * 3 + 2];
   }
   const float stx = tx * fx, sty = ty * fy;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
+  for (int p = bx * blockDim.x + threadIdx.x; p < hw; p += gdx * blockDim.x) {
     const int i = p % a.w, j = p / a.w;
     const long long gp = (long long)bi * hw + p;
     float para = 1.0f, depth = 1000.0f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;   // :198-200
@@ -184,6 +188,20 @@ level_pre_kernel(const LevelPreArgs a) {
       if (a.other_off >= 0) { f[a.other_off] = o0; f[a.other_off + 1] = o1; f[a.other_off + 2] = o2; f[a.other_off + 3] = o3; }
     }
   }
+}
+
+__global__ void __launch_bounds__(256)
+level_pre_kernel(const LevelPreArgs a) { level_pre_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
+
+// The level's two independent opening kernels in ONE launch (one boundary less on the coarse-level latency chain): the
+// first pre_gx * b workgroups run level_pre, the rest the per-cut normalisation of the current features.
+template <int LPG>
+__global__ void __launch_bounds__(256)
+level_pre_normalize_kernel(const LevelPreArgs a, int pre_gx, int pre_blocks, const float* __restrict__ nx, long long items,
+                           float* __restrict__ nout) {
+  const int blk = blockIdx.x;
+  if (blk < pre_blocks) level_pre_body(a, blk % pre_gx, blk / pre_gx, pre_gx);
+  else normalize_cuts_group_body<LPG>(nx, items, nout, blk - pre_blocks);
 }
 
 // ---- fused "depth_estimator" tail (:247-260) --------------------------------------
@@ -308,6 +326,49 @@ extern "C" int m4d_resize_nearest(const float* x, int b, int ih, int iw, int c, 
   hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
                      x, ih, iw, c, oh, ow, total, out);
   return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_level_pre_normalize(const float* prev_l_depth, const float* prev_l_parallax, const float* prev_l_other,
+                                       int ph, int pw, const float* depth_prev_t, const float* trans,
+                                       const float* cam_f, const float* cam_c, int b, int h, int w,
+                                       float* para_prev_l, float* depth_prev_l, float* other_prev_l, float* para_prev_t,
+                                       float* f_input, int f_stride, int log_off, int other_off, float log_scale,
+                                       const float* norm_x, int C, int nbre_cuts, float* norm_out, void* stream) {
+  M4D_CHECK_ARG(b > 0 && h > 0 && w > 0);
+  M4D_CHECK_ARG(norm_x && norm_out && C > 0 && nbre_cuts > 0 && C % nbre_cuts == 0);
+  const bool any_prev = prev_l_depth || prev_l_parallax || prev_l_other;
+  if (any_prev) M4D_CHECK_ARG(prev_l_depth && prev_l_parallax && prev_l_other && ph > 0 && pw > 0);
+  if (depth_prev_t) M4D_CHECK_ARG(trans && cam_f && cam_c && para_prev_t);
+  if (f_input) M4D_CHECK_ARG(f_stride > 0 && log_off >= 0 && log_off < f_stride && other_off + 4 <= f_stride);
+  if (other_prev_l) M4D_CHECK_ARG((((uintptr_t)other_prev_l) & 15u) == 0);
+  LevelPreArgs a;
+  a.pl_depth = prev_l_depth; a.pl_para = prev_l_parallax; a.pl_other = prev_l_other; a.ph = ph; a.pw = pw;
+  a.depth_prev_t = depth_prev_t; a.trans = trans; a.cam_f = cam_f; a.cam_c = cam_c; a.h = h; a.w = w;
+  a.para_prev_l = para_prev_l; a.depth_prev_l = depth_prev_l; a.other_prev_l = other_prev_l; a.para_prev_t = para_prev_t;
+  a.f_input = f_input; a.f_stride = f_stride; a.log_off = log_off; a.other_off = other_off; a.log_scale = log_scale;
+  int gx = m4d_blocks((long long)h * w, 256);
+  if (gx > 4096) gx = 4096;
+  const int nc = C / nbre_cuts;
+  const long long items = (long long)b * h * w * nbre_cuts;
+  const bool vec = ((((uintptr_t)norm_x | (uintptr_t)norm_out) & 15u) == 0);
+  const int lpg = nc / 4;
+  if (vec && (nc == 8 || nc == 16 || nc == 24 || nc == 32)) {
+    const long long gpw = 64 / lpg, waves = (items + gpw - 1) / gpw, nblocks = (waves + 3) / 4;
+    const int pre_blocks = gx * b;
+    const dim3 grid((unsigned)(pre_blocks + nblocks));
+    hipStream_t s = (hipStream_t)stream;
+    switch (lpg) {
+      case 2: hipLaunchKernelGGL(level_pre_normalize_kernel<2>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
+      case 4: hipLaunchKernelGGL(level_pre_normalize_kernel<4>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
+      case 6: hipLaunchKernelGGL(level_pre_normalize_kernel<6>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
+      default: hipLaunchKernelGGL(level_pre_normalize_kernel<8>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
+    }
+    return M4D_LAUNCH_RESULT();
+  }
+  hipLaunchKernelGGL(level_pre_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, a);      // other channel counts: two launches
+  const int rc = M4D_LAUNCH_RESULT();
+  if (rc != 0) return rc;
+  return m4d_normalize_cuts(norm_x, b, h, w, C, nbre_cuts, norm_out, stream);
 }
 
 extern "C" int m4d_level_pre(const float* prev_l_depth, const float* prev_l_parallax, const float* prev_l_other,

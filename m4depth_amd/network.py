@@ -91,6 +91,9 @@ pad_refiner_input = _os.environ.get("M4D_PAD_REFINER_INPUT", "1") == "1"
 # mode, so the pipelined and the single-stream forward keep choosing the same kernel (bitwise-neutrality test).  0 = off.
 small_map_conv_pixels = int(_os.environ.get("M4D_CONV_SMALL_PX", "2048"))
 
+# level_pre and the per-cut normalisation of a level in one launch (m4d_level_pre_normalize).  0 = two launches.
+fused_level_front = _os.environ.get("M4D_FUSED_LEVEL_FRONT", "1") == "1"
+
 # Encoder level 0 as two fused kernels (direct 3->16 convolution + bias + DINL statistics; DINL apply fused into the
 # stride-2 convolution's input staging) instead of MIOpen conv + bias pass + 3 DINL passes + conv: no MIOpen kernel is
 # left in the inference path.  0 = the unfused sequence.
@@ -460,7 +463,15 @@ class DepthEstimatorLevel(torch.nn.Module):
             self._ensure_state((b, h, w, c), dev)
         # normalised current features land in the spare state buffer: after the level
         # ran they ARE the new prev_f_maps (:211, :259) -- a pointer swap, not a copy.
-        curr_f = self._vector_processing(curr_f_maps, out=self._spare_f if not self.is_training else None)
+        # (inference, state mode) the normalisation shares a launch with level_pre below: both open the level, neither
+        # depends on the other
+        norm_job = None
+        if (fused_level_front and self.ablation.normalize_features and dev.type == "cuda" and not self.is_training
+                and prev_f_maps is None and self._spare_f is not None and c % self.nbre_cuts == 0):
+            curr_f = self._spare_f
+            norm_job = (curr_f_maps, self.nbre_cuts, curr_f)
+        else:
+            curr_f = self._vector_processing(curr_f_maps, out=self._spare_f if not self.is_training else None)
         if prev_f_maps is not None:
             prev_f_maps = self._vector_processing(as_f32(prev_f_maps, "prev_f_maps"))
         if use_state:
@@ -474,7 +485,8 @@ class DepthEstimatorLevel(torch.nn.Module):
             nt = bool(np.asarray(nt).reshape(-1)[0])
 
         if prev_t_depth is None or nt:                                                 # :208-214
-            para_prev_l, depth_prev_l, other_prev_l, _ = nops.level_pre(prev_l_est, None, None, None, b, h, w, dev)
+            para_prev_l, depth_prev_l, other_prev_l, _ = nops.level_pre(prev_l_est, None, None, None, b, h, w, dev,
+                                                                        normalize=norm_job)
             if not self.is_training:
                 self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
                 self.depth_prev_t.fill_(1000.)
@@ -498,7 +510,7 @@ class DepthEstimatorLevel(torch.nn.Module):
         # "preprocessor" (:216-242): upsample coarser estimate, prev_d2para, log / memory features
         para_prev_l, depth_prev_l, other_prev_l, para_prev_t = nops.level_pre(
             prev_l_est, as_f32(prev_t_depth, "prev_t_depth"), trans, camera, b, h, w, dev,
-            f_input=f_input, log_off=log_off, other_off=other_off, log_scale=scale)
+            f_input=f_input, log_off=log_off, other_off=other_off, log_scale=scale, normalize=norm_job)
         rot_t = as_f32(rot, "rot")
         tr = as_f32(trans, "trans").reshape(b, 3)
         cf = as_f32(camera["f"], "camera['f']").reshape(b, 2)

@@ -43,11 +43,12 @@ def resize_nearest(x, out_h, out_w):
 
 
 def level_pre(prev_l_est, depth_prev_t, trans, camera, b, h, w, device, f_input=None, log_off=0,
-              other_off=-1, log_scale=1.0):
+              other_off=-1, log_scale=1.0, normalize=None):
     """Fused upsample of the coarser level's estimate (+ prev_d2para of the
     temporal depth state, + the log-parallax / level-memory features written
     straight into ``f_input``).  Returns (para_prev_l, depth_prev_l,
-    other_prev_l, para_prev_t or None)."""
+    other_prev_l, para_prev_t or None).  ``normalize`` = (raw features [b,h,w,C], cuts, out): the per-cut
+    normalisation of the level's current features rides in the same launch (m4d_level_pre_normalize)."""
     para = torch.empty((b, h, w, 1), dtype=torch.float32, device=device)
     depth = torch.empty_like(para)
     other = torch.empty((b, h, w, 4), dtype=torch.float32, device=device)
@@ -66,6 +67,15 @@ def level_pre(prev_l_est, depth_prev_t, trans, camera, b, h, w, device, f_input=
         f = as_f32(camera["f"], "camera['f']").reshape(b, 2)
         c = as_f32(camera["c"], "camera['c']").reshape(b, 2)
     f_stride = f_input.shape[-1] if f_input is not None else 0
+    if normalize is not None:
+        raw, cuts, nout = normalize
+        raw = as_f32(raw, "curr_f_maps")
+        check(lib.m4d_level_pre_normalize(dptr(pd), dptr(pp), dptr(po), ph, pw, dptr(depth_prev_t, "depth_prev_t"), dptr(tr),
+                                          dptr(f), dptr(c), b, h, w, dptr(para), dptr(depth), dptr(other), dptr(para_t),
+                                          dptr(f_input, "f_input"), f_stride, int(log_off), int(other_off), float(log_scale),
+                                          dptr(raw, "curr_f_maps"), int(raw.shape[-1]), int(cuts), dptr(nout, "normalised features"),
+                                          stream_ptr()), "m4d_level_pre_normalize")
+        return para, depth, other, para_t
     check(lib.m4d_level_pre(dptr(pd), dptr(pp), dptr(po), ph, pw, dptr(depth_prev_t, "depth_prev_t"), dptr(tr),
                             dptr(f), dptr(c), b, h, w, dptr(para), dptr(depth), dptr(other), dptr(para_t),
                             dptr(f_input, "f_input"), f_stride, int(log_off), int(other_off), float(log_scale),
