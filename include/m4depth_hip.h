@@ -137,6 +137,16 @@ void m4d_dscv_set_stamps(unsigned long long* device_buffer);
  * out[p*out_stride + channel]. */
 int m4d_sncv_fwd(const float* c1, const float* c2, int b, int h, int w, int C, int search_range,
                  int dilation_rate, int nbre_cuts, float* out, int out_stride, void* stream);
+/* m4d_dscv_fwd and m4d_sncv_fwd(c1, c1, ...) of one level (depth_operations.py:224-281 and :284-313 as called from
+ * m4depth_network.py:220-233).  On small maps (the coarsest pyramid levels) the two independent volumes share ONE launch --
+ * one kernel boundary less on the coarse-level latency chain; otherwise the two entries are called one after the other.
+ * Same results, bit for bit. */
+int m4d_dscv_sncv_fwd(const float* c1, const float* c2, const float* disp_prev_t, const float* disp,
+                      const float* rot, int rot_c, const float* trans, const float* cam_f,
+                      const float* cam_c, int b, int h, int w, int C, int search_range, int nbre_cuts,
+                      int cv_accum, float* cv, int cv_stride, float* prev_disp,
+                      float* log_center, int log_stride, float log_scale,
+                      int sncv_search_range, float* sncv_out, int sncv_out_stride, void* stream);
 
 /* The same stride-1 layer by Winograd F(2x2,3x3) on the fp32 matrix cores: 2.25x fewer multiply-adds, result
  * equal to the direct convolution up to float32 rounding (the transforms only add and halve).  wu = the filter

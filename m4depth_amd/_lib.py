@@ -32,6 +32,9 @@ _SIGNATURES = {
     "m4d_dscv_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
                      _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                      _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_f, _c_fp, _c_fp],
+    "m4d_dscv_sncv_fwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
+                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                          _c_fp, _c_int, _c_fp, _c_fp, _c_int, _c_f, _c_int, _c_fp, _c_int, _c_fp],
     "m4d_sncv_fwd": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp],
     "m4d_dscv_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
                      _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

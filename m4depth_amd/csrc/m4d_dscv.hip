@@ -17,6 +17,7 @@
 // contiguous band of the image: the gathers of neighbouring pixels then hit the
 // XCD's own 4 MiB L2.
 #include "m4d_common.h"
+#include "m4d_sncv_small.h"
 #include "../../include/m4depth_hip.h"
 
 namespace {
@@ -174,15 +175,11 @@ __device__ __forceinline__ void dscv_pixel(const DscvArgs& a, const M4dMotion& m
 
 // Wave kernel: pixels in raster order, 64/LP per wave, corners gathered through L2/L1.
 template <int LP, int G, int NCP>
-__global__ void __launch_bounds__(256)
-dscv_wave_kernel(const DscvArgs a) {
+__device__ __forceinline__ void dscv_wave_body(const DscvArgs& a, int blk, int nb, int bi) {
   constexpr int PPW = 64 / LP;                 // pixels per wave
   constexpr int C = 4 * LP;
-  const int bi = blockIdx.y;
   const int hw = a.h * a.w;
   // XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous band.
-  int blk = blockIdx.x;
-  const int nb = gridDim.x;
   if ((nb & 7) == 0) blk = (blk & 7) * (nb >> 3) + (blk >> 3);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -196,6 +193,21 @@ dscv_wave_kernel(const DscvArgs a) {
   fetch.base = a.c2 + (long long)bi * hw * C + 4 * q;
   fetch.w = a.w; fetch.C = C; fetch.rs = (long long)a.w * C;
   dscv_pixel<LP, G, NCP>(a, m, bi, pix % a.w, pix / a.w, active, q, q % G, q / G, slot * LP, fetch);
+}
+
+template <int LP, int G, int NCP>
+__global__ void __launch_bounds__(256)
+dscv_wave_kernel(const DscvArgs a) { dscv_wave_body<LP, G, NCP>(a, blockIdx.x, gridDim.x, blockIdx.y); }
+
+// Coarse levels: the two cost volumes of a level are independent and both tiny -- one launch for both (one kernel boundary
+// less on the latency chain): the first nb * b workgroups run the DSCV wave kernel, the rest the small-map SNCV body
+// (channels per cut = 4 * G).
+template <int LP, int G, int NCP>
+__global__ void __launch_bounds__(256)
+dscv_sncv_small_kernel(const DscvArgs a, int nb, int b, const m4d_sncv::SncvArgs sa, int total_px, int nb_sncv) {
+  const int blk = blockIdx.x;
+  if (blk < nb * b) dscv_wave_body<LP, G, NCP>(a, blk % nb, nb, blk / nb);
+  else m4d_sncv::sncv_small_body<4 * G>(sa, total_px, blk - nb * b, nb_sncv);
 }
 
 // Stage a WH x WW window of an NHWC image into LDS (pixel stride C+4 floats).  A window
@@ -749,4 +761,63 @@ extern "C" int m4d_dscv_fwd(const float* c1, const float* c2, const float* disp_
     hipLaunchKernelGGL(dscv_generic_kernel, dim3(m4d_blocks(threads, 256), b), dim3(256), 0, s, a);
   }
   return M4D_LAUNCH_RESULT();
+}
+
+template <int LP, int G>
+bool launch_wave_sncv(const DscvArgs& a, int b, const m4d_sncv::SncvArgs& sa, hipStream_t s) {
+  constexpr int PPW = 64 / LP;
+  const int hw = a.h * a.w;
+  const int nb = (hw + 4 * PPW - 1) / (4 * PPW);
+  const int nb_sncv = (int)m4d_sncv::sncv_small_blocks(sa, b);
+  const dim3 grid((unsigned)(nb * b + nb_sncv));
+  const int total_px = b * hw;
+  if (a.r == 4) hipLaunchKernelGGL((dscv_sncv_small_kernel<LP, G, 9>), grid, dim3(256), 0, s, a, nb, b, sa, total_px, nb_sncv);
+  else if (a.r == 2) hipLaunchKernelGGL((dscv_sncv_small_kernel<LP, G, 5>), grid, dim3(256), 0, s, a, nb, b, sa, total_px, nb_sncv);
+  else return false;
+  return true;
+}
+
+// m4d_dscv_fwd followed by m4d_sncv_fwd(c1, c1, ...) of the same level; on small maps (<= 6000 pixels, the pyramid's
+// channel / cut pairs) both run in ONE launch, otherwise one after the other.  Same results bit for bit.
+extern "C" int m4d_dscv_sncv_fwd(const float* c1, const float* c2, const float* disp_prev_t, const float* disp,
+                                 const float* rot, int rot_c, const float* trans, const float* cam_f,
+                                 const float* cam_c, int b, int h, int w, int C, int search_range, int nbre_cuts,
+                                 int cv_accum, float* cv, int cv_stride, float* prev_disp,
+                                 float* log_center, int log_stride, float log_scale,
+                                 int sncv_search_range, float* sncv_out, int sncv_out_stride, void* stream) {
+  M4D_CHECK_ARG(c1 && c2 && disp_prev_t && disp && rot && trans && cam_f && cam_c && cv && sncv_out);
+  M4D_CHECK_ARG(b > 0 && h >= 2 && w >= 2 && C > 0 && search_range >= 0 && nbre_cuts > 0 && C % nbre_cuts == 0);
+  const int nc = C / nbre_cuts, mo = 2 * sncv_search_range + 1;
+  const bool aligned = (((uintptr_t)c1 | (uintptr_t)c2) & 15u) == 0 && (nc % 4 == 0);
+  const int lp = C / 4, g = nc / 4;
+  static int small_px = -1;                            // the same threshold as m4d_sncv_fwd's small-map kernel
+  if (small_px < 0) { const char* e = getenv("M4D_SNCV_SMALL_PX"); small_px = e ? atoi(e) : 6000; }
+  const bool merged_ok = aligned && g_dscv_variant == 1 && (rot_c == 3 || rot_c == 4) && (cv_accum == 0 || cv_accum == 1) &&
+                         cv_stride >= nbre_cuts * (2 * search_range + 1) && sncv_search_range >= 0 &&
+                         sncv_out_stride >= mo * mo * nbre_cuts && (long long)b * h * w <= small_px &&
+                         (log_center == nullptr || log_stride >= 1);
+  if (merged_ok) {
+    DscvArgs a;
+    a.c1 = c1; a.c2 = c2; a.disp_prev_t = disp_prev_t; a.disp = disp;
+    a.rot = rot; a.rot_c = rot_c; a.trans = trans; a.cam_f = cam_f; a.cam_c = cam_c;
+    a.h = h; a.w = w; a.C = C; a.r = search_range; a.k = nbre_cuts; a.nc = nc; a.cv_accum = cv_accum;
+    a.cv = cv; a.cv_stride = cv_stride; a.prev_disp = prev_disp; a.log_center = log_center;
+    a.log_stride = log_stride; a.log_scale = log_scale; a.index_out = nullptr; a.ablate = g_dscv_ablate;
+    m4d_sncv::SncvArgs sa;
+    sa.c1 = c1; sa.c2 = c1; sa.h = h; sa.w = w; sa.C = C; sa.r = sncv_search_range; sa.d = 1; sa.k = nbre_cuts; sa.nc = nc;
+    sa.out = sncv_out; sa.out_stride = sncv_out_stride; sa.th = sa.tw = sa.tiles_x = 0;
+    hipStream_t s = (hipStream_t)stream;
+    bool done = false;
+    if (lp == 24 && g == 6) done = launch_wave_sncv<24, 6>(a, b, sa, s);        // C=96  k=4
+    else if (lp == 32 && g == 8) done = launch_wave_sncv<32, 8>(a, b, sa, s);   // C=128 k=4
+    else if (lp == 48 && g == 6) done = launch_wave_sncv<48, 6>(a, b, sa, s);   // C=192 k=8
+    else if (lp == 16 && g == 8) done = launch_wave_sncv<16, 8>(a, b, sa, s);   // C=64  k=2
+    else if (lp == 8 && g == 4) done = launch_wave_sncv<8, 4>(a, b, sa, s);     // C=32  k=2
+    else if (lp == 4 && g == 4) done = launch_wave_sncv<4, 4>(a, b, sa, s);     // C=16  k=1
+    if (done) return M4D_LAUNCH_RESULT();
+  }
+  const int rc = m4d_dscv_fwd(c1, c2, disp_prev_t, disp, rot, rot_c, trans, cam_f, cam_c, b, h, w, C, search_range, nbre_cuts,
+                              cv_accum, cv, cv_stride, prev_disp, log_center, log_stride, log_scale, nullptr, stream);
+  if (rc != 0) return rc;
+  return m4d_sncv_fwd(c1, c1, b, h, w, C, sncv_search_range, 1, nbre_cuts, sncv_out, sncv_out_stride, stream);
 }

@@ -12,14 +12,12 @@
 // pixel.
 #include <cstdlib>
 #include "m4d_common.h"
+#include "m4d_sncv_small.h"
 #include "../../include/m4depth_hip.h"
 
 namespace {
 
-struct SncvArgs {
-  const float* c1; const float* c2; int h, w, C, r, d, k, nc;
-  float* out; int out_stride; int th, tw; int tiles_x;
-};
+using m4d_sncv::SncvArgs;
 
 // MO = 2r+1 known at compile time (MO > 0): the (2r+1)^2 results of a lane are kept in
 // registers, then -- after a barrier, once every lane has finished reading the halo tile --
@@ -349,54 +347,16 @@ sncv_generic_kernel(const SncvArgs a, long long total) {
   }
 }
 
-// Small maps (the three coarsest levels: a few hundred to a few thousand pixels, C >= 96): the halo-tile kernel above
-// runs a handful of workgroups that each spend most of their time staging a halo several times the size of their
-// tile (19-28 us for 120-1920 pixels).  Here: one lane per OUTPUT element, channel runs read as float4 straight from
-// global memory (the whole map is L2 / vector-L1 resident), consecutive lanes = consecutive output channels of a pixel
-// (coalesced stores).  Same arithmetic, same order: products rounded individually, summed in channel order, / NC,
-// leaky_relu.
+// Small maps (the three coarsest levels): the halo-tile kernel above runs a handful of workgroups that each spend most of
+// their time staging a halo several times the size of their tile (19-28 us for 120-1920 pixels); m4d_sncv_small.h has the
+// one-lane-per-output body used instead (3-6 us).
 template <int NC>
 __global__ void __launch_bounds__(256)
-sncv_small_kernel(const SncvArgs a, int total_px) {
-  const int mo = 2 * a.r + 1;
-  const int och = mo * mo * a.k;
-  const long long total = (long long)total_px * och;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int ch = (int)(idx % och);
-    const int gp = (int)(idx / och);
-    const int kk = ch % a.k;
-    const int dsp = ch / a.k;
-    const int y = dsp / mo, x = dsp - y * mo;
-    const int gx = gp % a.w;
-    const int gyb = gp / a.w;                      // bi * h + gy
-    const int gy = gyb % a.h;
-    const int sy = gy + (y - a.r) * a.d, sx = gx + (x - a.r) * a.d;
-    const bool in = sy >= 0 && sy < a.h && sx >= 0 && sx < a.w;
-    const float* p1 = a.c1 + (long long)gp * a.C + kk * NC;
-    const float* p2 = a.c2 + ((long long)(gyb - gy + (in ? sy : gy)) * a.w + (in ? sx : gx)) * a.C + kk * NC;
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; c += 4) {
-      const float4 u = *reinterpret_cast<const float4*>(p1 + c);
-      float4 v = *reinterpret_cast<const float4*>(p2 + c);
-      if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);                     // zero padding (:293)
-      if (c == 0) acc = u.x * v.x; else acc = acc + u.x * v.x;
-      acc = acc + u.y * v.y;
-      acc = acc + u.z * v.z;
-      acc = acc + u.w * v.w;
-    }
-    const float mean = acc / (float)NC;
-    a.out[(long long)gp * a.out_stride + ch] = mean > 0.f ? mean : mean * 0.1f;
-  }
-}
+sncv_small_kernel(const SncvArgs a, int total_px) { m4d_sncv::sncv_small_body<NC>(a, total_px, blockIdx.x, gridDim.x); }
 
 template <int NC>
 void launch_small(const SncvArgs& a, int b, hipStream_t s) {
-  const int total_px = b * a.h * a.w;
-  const long long total = (long long)total_px * (2 * a.r + 1) * (2 * a.r + 1) * a.k;
-  long long g = (total + 255) / 256;
-  if (g > 256 * 16) g = 256 * 16;
-  hipLaunchKernelGGL((sncv_small_kernel<NC>), dim3((int)g), dim3(256), 0, s, a, total_px);
+  hipLaunchKernelGGL((sncv_small_kernel<NC>), dim3((int)m4d_sncv::sncv_small_blocks(a, b)), dim3(256), 0, s, a, b * a.h * a.w);
 }
 
 template <int NC, int MO>

@@ -91,6 +91,8 @@ pad_refiner_input = _os.environ.get("M4D_PAD_REFINER_INPUT", "1") == "1"
 # mode, so the pipelined and the single-stream forward keep choosing the same kernel (bitwise-neutrality test).  0 = off.
 small_map_conv_pixels = int(_os.environ.get("M4D_CONV_SMALL_PX", "2048"))
 
+# DSCV and SNCV of a small level (<= 6000 pixels) in one launch (m4d_dscv_sncv_fwd).  0 = two launches.
+fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
 # level_pre and the per-cut normalisation of a level in one launch (m4d_level_pre_normalize).  0 = two launches.
 fused_level_front = _os.environ.get("M4D_FUSED_LEVEL_FRONT", "1") == "1"
 
@@ -522,14 +524,23 @@ class DepthEstimatorLevel(torch.nn.Module):
         log_ptr = ctypes.c_void_p(fin_ptr + 4 * (F_in - 1)) if time_recurr else None      # channel F_in - 1 of a stride-F_st row
         # DSCV (:220-221) -> f_input[..., 0:9k]; time-recurrence feature (:238) -> f_input[..., -1]
         prev_f = as_f32(prev_f_maps, "prev_f_maps")
-        check(_timed("dscv", self.lvl_depth, lambda: lib.m4d_dscv_fwd(
-            dptr(curr_f), dptr(prev_f), dptr(para_prev_t), dptr(para_prev_l), dptr(rot_t), rot_t.shape[1],
-            dptr(tr), dptr(cf), dptr(cc), b, h, w, c, r, k, _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr),
-            F_st, None, log_ptr, F_st, scale, None, stream_ptr())), "m4d_dscv_fwd")
-        if self.ablation.SNCV:                                                         # :231-233
-            check(_timed("sncv", self.lvl_depth, lambda: lib.m4d_sncv_fwd(
-                dptr(curr_f), dptr(curr_f), b, h, w, c, self.sncv_range, 1, k,
-                ctypes.c_void_p(fin_ptr + 4 * sncv_off), F_st, stream_ptr())), "m4d_sncv_fwd")
+        kt_on = kernel_timer is not None and getattr(kernel_timer, "enabled", True)
+        if fused_cost_volumes and self.ablation.SNCV and dev.type == "cuda" and not kt_on and b * h * w <= 6000:
+            # small maps: both (independent) cost volumes in one launch
+            check(lib.m4d_dscv_sncv_fwd(
+                dptr(curr_f), dptr(prev_f), dptr(para_prev_t), dptr(para_prev_l), dptr(rot_t), rot_t.shape[1],
+                dptr(tr), dptr(cf), dptr(cc), b, h, w, c, r, k, _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr),
+                F_st, None, log_ptr, F_st, scale, self.sncv_range, ctypes.c_void_p(fin_ptr + 4 * sncv_off), F_st,
+                stream_ptr()), "m4d_dscv_sncv_fwd")
+        else:
+            check(_timed("dscv", self.lvl_depth, lambda: lib.m4d_dscv_fwd(
+                dptr(curr_f), dptr(prev_f), dptr(para_prev_t), dptr(para_prev_l), dptr(rot_t), rot_t.shape[1],
+                dptr(tr), dptr(cf), dptr(cc), b, h, w, c, r, k, _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr),
+                F_st, None, log_ptr, F_st, scale, None, stream_ptr())), "m4d_dscv_fwd")
+            if self.ablation.SNCV:                                                     # :231-233
+                check(_timed("sncv", self.lvl_depth, lambda: lib.m4d_sncv_fwd(
+                    dptr(curr_f), dptr(curr_f), b, h, w, c, self.sncv_range, 1, k,
+                    ctypes.c_void_p(fin_ptr + 4 * sncv_off), F_st, stream_ptr())), "m4d_sncv_fwd")
         self.last_f_input = f_input if F_st == F_in else f_input[..., :F_in]      # the reference-width view (inspection / tests)
         self.last_cv_inputs = (curr_f, prev_f, para_prev_t, para_prev_l, rot_t, tr, cf, cc)   # for tools/bench_kernels.py
         # "depth_estimator" (:244-260)

@@ -550,3 +550,37 @@ def test_small_map_conv(M, dev, b, h, w, cin, cout, slope):
     # the general entry (split-K + ordered reduce on such maps) agrees to rounding
     alt = nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, slope)
     assert np.max(np.abs(npy(alt) - npy(got))) < 1e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("b,h,w,C,k", [(2, 12, 20, 128, 4), (1, 6, 20, 192, 8), (1, 90, 120, 32, 2)])
+def test_merged_cost_volume_launch(M, dev, b, h, w, C, k):
+    """m4d_dscv_sncv_fwd (one launch for both volumes on small maps, the two entries in sequence above 6000 pixels) gives the
+    bits of m4d_dscv_fwd + m4d_sncv_fwd."""
+    import ctypes
+    from m4depth_amd._lib import lib, check, dptr, stream_ptr
+    rng = np.random.default_rng(C + k)
+    cam = camera_np(b, h, w)
+    rot, trans = motion_np(rng, b, t_scale=(3.0, 3.0, 1.0))
+    c1 = O.normalize_cuts(rng.standard_normal([b, h, w, C]).astype(F), k)
+    c2 = O.normalize_cuts(rng.standard_normal([b, h, w, C]).astype(F), k)
+    disp = (0.2 + 6.0 * rng.random([b, h, w, 1])).astype(F)
+    dpt = (0.2 + 6.0 * rng.random([b, h, w, 1])).astype(F)
+    t = {n: to_dev(v, dev) for n, v in dict(c1=c1, c2=c2, disp=disp, dpt=dpt, rot=rot, trans=trans, f=cam["f"], c=cam["c"]).items()}
+    stride = 9 * k + 49 * k + 3
+    outs = []
+    for merged in (True, False):
+        buf = torch.zeros(b, h, w, stride, device=dev)
+        base = buf.data_ptr()
+        args = (dptr(t["c1"]), dptr(t["c2"]), dptr(t["dpt"]), dptr(t["disp"]), dptr(t["rot"]), t["rot"].shape[1], dptr(t["trans"]),
+                dptr(t["f"]), dptr(t["c"]), b, h, w, C, 4, k, 0, ctypes.c_void_p(base), stride, None, None, 1, 1.0)
+        if merged:
+            check(lib.m4d_dscv_sncv_fwd(*args, 3, ctypes.c_void_p(base + 4 * (9 * k + 1)), stride, stream_ptr()), "m4d_dscv_sncv_fwd")
+        else:
+            check(lib.m4d_dscv_fwd(*args, None, stream_ptr()), "m4d_dscv_fwd")
+            check(lib.m4d_sncv_fwd(dptr(t["c1"]), dptr(t["c1"]), b, h, w, C, 3, 1, k, ctypes.c_void_p(base + 4 * (9 * k + 1)), stride,
+                                   stream_ptr()), "m4d_sncv_fwd")
+        outs.append(buf)
+    assert torch.equal(outs[0], outs[1])
+    ocv, _ = O.get_parallax_sweeping_cv(c1, c2, dpt, disp, rot, trans, cam, 4, k)
+    assert_bits_equal(npy(outs[0][..., :9 * k]), ocv, "dscv through the merged entry")
+    assert_bits_equal(npy(outs[0][..., 9 * k + 1:9 * k + 1 + 49 * k]), O.cost_volume(c1, c1, 3, nbre_cuts=k), "sncv through the merged entry")
