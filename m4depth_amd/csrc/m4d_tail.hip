@@ -30,6 +30,9 @@ struct TailArgs {
 
 // (Measured: an 8 x 4-tile instantiation for the small maps of the coarse levels -- a quarter of the work per workgroup --
 // changes nothing end to end: there the launch is bound by the staging round trip and the three barriers, not by the tile.)
+// (Measured as well: the weights as register-resident B fragments read straight from global memory instead of staged in
+// LDS -- 49 KB, three workgroups per CU, no weight staging in the prologue: 17.9 us average instead of 17.5, i.e. nothing.
+// At level 1 the kernel is matrix-core bound at ~60 % (2.8 GFLOP with the ring recompute and conv7's 5-of-16 columns).)
 constexpr int kTW = 16, kTH = 8;
 constexpr int kXW = kTW + 4, kXH = kTH + 4, kXP = kXW * kXH;     // input halo 20 x 12 = 240
 constexpr int kMW = kTW + 2, kMH = kTH + 2, kMP = kMW * kMH;     // conv6 positions 18 x 10 = 180
