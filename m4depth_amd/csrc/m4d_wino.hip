@@ -525,6 +525,9 @@ conv3x3_wino2_kernel(const WinoArgs a) {
 //   * a workgroup is 8 waves = 4 position rows x TWO N-tiles (64 couts): the transformed tile is used twice, each
 //     wave transforms half an item (8 of the 16 positions), and both waves of a SIMD are always in the same phase;
 //   * raw halo double buffered as well: commit of chunk c+2 and loads of chunk c+3 ride in the same phase.
+// (Measured and dropped: the refiner's 96-wide layer on this kernel with CoutPad = 128, the wave of the all-padding N-tile
+// taking part in the staging but issuing no MFMAs: -1.8 % end to end against kernel 2 for that layer -- the half-idle
+// workgroup still holds its CU for most of a full one's time.)
 // One workgroup per CU (126 KB of LDS in the K loop, 147 KB for the epilogue staging).  Needs CoutPad % 64 == 0.
 constexpr int kRawF = kHP2 * kRS2;               // floats per raw buffer   (15.2 KB)
 constexpr int kVF = 16 * kNT64 * kRS2;           // floats per V buffer     (48 KB)
