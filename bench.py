@@ -9,24 +9,29 @@ reference's ``test_step`` on a 5-D sequence batch (m4depth_network.py:433-474):
 encoder + 6-level parallax-cost-volume decoder over ``seq_len`` frames (frame 0
 carries ``new_traj`` and only seeds the recurrent state, exactly as
 dataloaders/generic.py:139 produces it) + the 7 depth metrics on the last frame.
-Default workload = BASELINE.json configs[1]: 384x1280, 6 levels, seq_len 4, DSCV
-range 4 / SNCV range 3, batch 1 per GPU.  Inputs are resident in HBM before the
-timed region.  ``value`` = all frames processed by all ranks / max-over-ranks time.
+Workload: 1 GPU -> BASELINE.json configs[1] (384x1280, 6 levels, seq_len 4, DSCV range 4 / SNCV range 3,
+batch 1); N > 1 GPUs -> configs[3] (global batch 32 N: 32 sequences per rank, 256 on 8 GPUs); ``--batch`` overrides
+(32 on one GPU = configs[2]).  Inputs are resident in HBM before the timed region.
+``value`` = all frames processed by all ranks / max-over-ranks time.
 
 The JSON line also carries
-  roofline     -- the dominant hand-written kernel of the step: the level-1 refiner
-                  128->128 convolution (Winograd F(2x2,3x3) on fp32 MFMA): the layer's algorithmic
-                  (direct-convolution) flops / HIP-event time on the launch stream, against the 157.3 TFLOP/s
-                  fp32-MFMA peak (> 1 possible: Winograd executes 2.25x fewer), + the executed-flops fraction;
-                  roofline_dscv / roofline_sncv: the level-1 cost-volume kernels, algorithmic
-                  bytes / time against the 8 TB/s HBM3E peak;
-  cpu_baseline -- the CPU oracle (a numpy restatement of the reference: TensorFlow is
-                  not installable here, so kind = "port") timed on a bounded sample.
+  roofline          -- the dominant kernel of the step, the level-1 refiner 128->128 convolution (Winograd F(2x2,3x3) on
+                       fp32 MFMA): the MFMA flops the kernel EXECUTES / HIP-event time on the launch stream, against the
+                       157.3 TFLOP/s fp32-MFMA peak (frac <= 1); the layer's algorithmic (direct-convolution) rate is a
+                       side field;
+  roofline_hotpath  -- SURVEY 8(d): the hot path's algorithmic bytes per full frame (106.72 MB at the default config) /
+                       the summed time of the hand-written level kernels of one full frame / 8 TB/s;
+  roofline_<kernel> -- the level-1 cost-volume kernels alone, algorithmic bytes / time against the 8 TB/s HBM3E peak;
+  ``traffic``       -- HBM bytes per launch from rocprofv3 --pmc passes (tools/pmc_traffic.py), accepted only when the
+                       recorded kernel name and the hash of the kernel's source files match this checkout, else null;
+  cpu_baseline      -- the CPU oracle (a numpy restatement of the reference: TensorFlow is not installable here, so
+                       kind = "port"), SURVEY 8(d) protocol: batch 1, T = 4, one warm-up + 3 repeats, median.
 Multi-GPU: sequences are independent -> batch sharded across ranks, weights
 replicated, no data-path collective ("weak" scaling); one RCCL all-gather of the
-14 metric accumulators per rank at the end.
+14 metric accumulators per rank at the end, one of the per-rank wall times for the report.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -40,6 +45,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= fp32 vector peak), MI355X_MICROARCH.md
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+HOT_KERNELS = ("pre", "front", "dscv", "sncv", "dscv_sncv", "tail", "post", "resize")     # network._timed names of the hot path
 
 
 def parse():
@@ -47,7 +54,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--batch", type=int, default=1, help="sequences per GPU (configs[1]: 1, configs[2]: 32)")
+    p.add_argument("--batch", type=int, default=None,
+                   help="sequences per GPU; default 1 on one GPU (configs[1]), 32 per rank on several (configs[3]); 32 on one GPU = configs[2]")
     p.add_argument("--seq-len", type=int, default=4)
     p.add_argument("--height", type=int, default=384)
     p.add_argument("--width", type=int, default=1280)
@@ -57,35 +65,35 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--eager", action="store_true", help="do not replay the step from a hipGraph")
+    p.add_argument("--host-input", action="store_true",
+                   help="also report the PCIe-inclusive rate: the RGB / pose batch starts in pinned host memory every step (never `value`)")
     p.add_argument("--in-flight", type=int, default=1,
                    help="independent sequence batches in flight (each on its own stream and model state); 1 = the quoted number")
-    p.add_argument("--launch", default="graph", choices=["tasks", "graph"],
-                   help="tasks: one hipGraph per (frame, level) task on one stream per frame; graph: one hipGraph per step")
     return p.parse_args()
 
 
 class EventTimer:
-    """Brackets chosen kernels with HIP events on torch's current stream (the stream
-    the C-ABI launches on)."""
+    """Brackets the hand-written kernels with HIP events on torch's current stream (the stream
+    the C-ABI launches on).  Keys: (name, level)."""
 
-    def __init__(self, torch, level):
+    def __init__(self, torch):
         self.torch = torch
-        self.targets = {("dscv", level), ("sncv", level), ("conv", f"lvl{level}.conv1")}
         self.enabled = False
         self.events = {}
 
     def run(self, name, level, thunk):
-        if not self.enabled or (name, level) not in self.targets:
+        if not self.enabled or not (name in HOT_KERNELS or (name == "conv" and level == "lvl1.conv1")):
             return thunk()
         e0 = self.torch.cuda.Event(enable_timing=True)
         e1 = self.torch.cuda.Event(enable_timing=True)
         e0.record()
         r = thunk()
         e1.record()
-        self.events.setdefault(name, []).append((e0, e1))
+        self.events.setdefault((name, level), []).append((e0, e1))
         return r
 
     def summary(self):
+        """{(name, level): (launches, mean seconds)}"""
         return {k: (len(v), float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3) for k, v in self.events.items()}
 
 
@@ -106,39 +114,103 @@ def make_batch(args, rank, dev, torch):
     return data
 
 
-def level_bytes(args, b, lvl=1):
-    """Algorithmic HBM bytes of the two cost-volume kernels at pyramid level ``lvl``
-    (each unique input read once, each output written once; DESIGN.md section 4)."""
-    from m4depth_amd.synthetic import ENCODER_CHANNELS, nbre_cuts_for
+def level_geometry(args, lvl):
+    from m4depth_amd.synthetic import ENCODER_CHANNELS, nbre_cuts_for, f_input_channels
     h, w = args.height >> lvl, args.width >> lvl
     C = ENCODER_CHANNELS[lvl - 1]
     k = nbre_cuts_for(lvl)
+    return h, w, C, k, f_input_channels(k, args.dscv_range, args.sncv_range)
+
+
+def level_bytes(args, b, lvl=1):
+    """Algorithmic HBM bytes of the two cost-volume kernels at pyramid level ``lvl``
+    (each unique input read once, each output written once; DESIGN.md section 4)."""
+    h, w, C, k, _ = level_geometry(args, lvl)
     px = b * h * w
     ncp = 2 * args.dscv_range + 1
     mo = 2 * args.sncv_range + 1
     return {"dscv": 4 * px * (2 * C + 2 + ncp * k + 1),        # c1, c2, 2 parallax maps | cv, log feature
-            "sncv": 4 * px * (C + mo * mo * k)}                 # c (c1 == c2) | cost volume
+            "sncv": 4 * px * (C + mo * mo * k),                 # c (c1 == c2) | cost volume
+            # the fused level front (normalise + level_pre + DSCV + SNCV): raw features, previous state, depth state,
+            # coarser estimate (1.5 floats / pixel) | normalised state, the whole refiner-input row, 6 upsampled maps
+            "front": int(px * (4 * (3 * C + 1 + (ncp * k + mo * mo * k + 6) + 6) + 6))}
 
 
-def cpu_baseline(args):
-    """Oracle (numpy restatement, kind 'port') on a bounded sample of the same workload:
-    ONE full frame (frame 1 of a reset+full pair), batch 1, same resolution / levels."""
+def hotpath_bytes_per_frame(args, b):
+    """per full frame sum_l 4 h w (3C + F_in + 13) + 6 h w [l < L], + the final nearest x2 (4 (H W + H W / 4))."""
+    total = 0
+    for lvl in range(1, args.levels + 1):
+        h, w, C, k, f_in = level_geometry(args, lvl)
+        total += 4 * h * w * (3 * C + f_in + 13) + (6 * h * w if lvl < args.levels else 0)
+    return b * total, b * 4 * (args.height * args.width + (args.height // 2) * (args.width // 2))
+
+
+def _sha(paths):
+    hsh = hashlib.sha256()
+    for p in paths:
+        with open(os.path.join(ROOT, p), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def load_traffic(batch):
+    """{name: {"bytes": n, "kernel": "..."}} of profiles/pmc_traffic.json for this batch size, only entries whose kernel
+    sources are unchanged since the counters were collected (tools/pmc_traffic.py stamps a hash of them); + a note."""
+    try:
+        tj = json.load(open(TRAFFIC_JSON))
+    except Exception:
+        return {}, "no profiles/pmc_traffic.json"
+    out, stale = {}, []
+    for name, ent in tj.get(f"batch{batch}", {}).items():
+        try:
+            fresh = _sha(ent["sources"]) == ent["sources_sha"]
+        except Exception:
+            fresh = False
+        if fresh:
+            out[name] = ent
+        else:
+            stale.append(name)
+    note = f"rocprofv3 --pmc (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), tools/pmc_traffic.py, collected {tj.get('collected', '?')}"
+    if stale:
+        note += f"; REFUSED as stale (kernel sources changed since): {', '.join(stale)}"
+    return out, note
+
+
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(height, width, levels, rd, rs, seq_len=4, repeats=3, seed=1235, keep=False):
+    """SURVEY 8(d) protocol on the numpy oracle (kind 'port'): batch 1, T = seq_len frames (frame 0 = new_traj), one
+    warm-up run + ``repeats`` timed runs, median; BLAS limited to ``cores`` threads (elementwise numpy is single-threaded)."""
     from threadpoolctl import threadpool_limits
     from oracle import m4depth_oracle as O
     from m4depth_amd import synthetic as S
     cores = min(os.cpu_count() or 1, 16)
-    W = S.init_weights(args.levels, seed=42, dscv_range=args.dscv_range, sncv_range=args.sncv_range)
-    samples, cam = S.make_sequence(1, 2, args.height, args.width, seed=1235)
+    W = S.init_weights(levels, seed=42, dscv_range=rd, sncv_range=rs)
+    samples, cam = S.make_sequence(1, seq_len, height, width, seed=seed)
+    times, out = [], None
     with threadpool_limits(limits=cores):
-        model = O.M4Depth(W, args.levels, dscv_range=args.dscv_range, sncv_range=args.sncv_range)
-        model(samples[:1], cam)
-        t0 = time.perf_counter()
-        out, _ = model(samples[1:], cam)
-        dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 full frame (second frame of a 2-frame sequence), batch 1, {args.height}x{args.width}, "
-                      f"{args.levels} levels, numpy float32 oracle; BLAS limited to {cores} threads, "
-                      "elementwise numpy is single-threaded"}, (W, samples, cam, out)
+        for i in range(1 + repeats):
+            model = O.M4Depth(W, levels, dscv_range=rd, sncv_range=rs)
+            t0 = time.perf_counter()
+            out, seq = model(samples, cam)
+            if i > 0:
+                times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    res = {"value": round(seq_len / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+           "full_frames_per_s": round((seq_len - 1) / med, 4), "cpu": cpu_model_string(), "host_cores": os.cpu_count(),
+           "seconds_per_sequence": [round(t, 3) for t in times],
+           "sample": f"one {seq_len}-frame sequence (frame 0 = new_traj), batch 1, {height}x{width}, {levels} levels, "
+                     f"dscv_range={rd} sncv_range={rs}; numpy float32 oracle (a restatement, not TensorFlow); 1 warm-up + "
+                     f"{repeats} timed runs, median; BLAS limited to {cores} threads, elementwise numpy single-threaded"}
+    return res, ((W, samples, cam, out, seq) if keep else None)
 
 
 def main():
@@ -150,27 +222,28 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if args.batch is None:
+        args.batch = 1 if world == 1 else 32                 # configs[1] / configs[3] (32 sequences per rank)
     import m4depth_amd as M
     from m4depth_amd import network as net
     from m4depth_amd import synthetic as S
 
-    torch.backends.cudnn.benchmark = True
     weights = S.init_weights(args.levels, seed=42, dscv_range=args.dscv_range, sncv_range=args.sncv_range)
     model = M.M4Depth(nbre_levels=args.levels, dscv_range=args.dscv_range, sncv_range=args.sncv_range)
     model.load_numpy_weights(weights, dev)
     model.compile(metrics=M.default_metrics())
     data = make_batch(args, rank, dev, torch)
 
-    timer = EventTimer(torch, level=1)
+    timer = EventTimer(torch)
     if not args.no_kernel_timing:
         net.kernel_timer = timer
 
-    for _ in range(max(args.warmup, 1)):                 # eager warm-up: MIOpen solver search, state allocation
+    for _ in range(max(args.warmup, 1)):                 # eager warm-up: state and scratch allocation
         model.test_step(data)
     runner = None
     replicas = [model]
     if not args.eager:
-        runner = net.TaskGraphSequence(model, data) if args.launch == "tasks" and args.seq_len > 1 else net.GraphedSequence(model, data)
+        runner = net.GraphedSequence(model, data)
         step = lambda: model.graphed_test_step(data, runner)
         if args.in_flight > 1:
             # Sequence batches are independent (every one starts with new_traj): keep several in flight, each with its own
@@ -206,18 +279,36 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     D.barrier(dev)
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, dev)
+    per_rank_s = D.all_gather_floats(dt_local, dev)                          # RCCL all-gather (report only)
     for mr in replicas[1:]:                                                   # fold the replicas' Keras-Mean accumulators together
         for m, m2 in zip(model.compiled_metrics, mr.compiled_metrics):
             if m2.total is not None:
                 m.total = m2.total if m.total is None else m.total + m2.total
                 m.count += m2.count
-    gathered = D.all_gather_metric_states(model.compiled_metrics, dev)       # the one collective (RCCL)
+    gathered = D.all_gather_metric_states(model.compiled_metrics, dev)       # the one data collective (RCCL): 14 floats / rank
     metrics = D.reduce_metric_states(gathered).tolist()
 
-    # Per-kernel roofline: the SAME workload, eager launches bracketed by HIP events on the
+    # PCIe-inclusive rate (never `value`): the batch's network inputs start in pinned host memory every step
+    host_rate = None
+    if args.host_input and runner is not None:
+        pinned = {k: data[k].cpu().pin_memory() for k in ("RGB_im", "rot", "trans")}
+        pinned["camera"] = {k: v.cpu().pin_memory() for k, v in data["camera"].items()}
+        pinned["new_traj"] = data["new_traj"]
+        pinned["depth"] = data["depth"]
+        for _ in range(2):
+            model.graphed_test_step(pinned, runner)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            model.graphed_test_step(pinned, runner)
+        torch.cuda.synchronize()
+        host_rate = args.batch * args.seq_len * args.steps / (time.perf_counter() - t1)
+
+    # Per-kernel timing: the SAME workload, eager launches bracketed by HIP events on the
     # launch stream (events cannot bracket nodes of a replayed graph), right after the timed region.
     if not args.no_kernel_timing:
         timer.enabled = True
@@ -231,79 +322,111 @@ def main():
 
     frames = world * args.batch * args.seq_len * args.steps
     value = frames / dt
+    cfg_name = ("BASELINE.json configs[1]" if (world, args.batch) == (1, 1) else "configs[2]" if (world, args.batch) == (1, 32)
+                else "configs[3] (32 sequences per rank)" if args.batch == 32 else "custom batch")
     out = {
         "metric": "frames/s", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic", "per_gpu": round(value / world, 2),
         "full_frames_per_s": round(value * (args.seq_len - 1) / args.seq_len, 2),
+        "metric_note": "value counts every frame of the sequence the reference's test_step processes, including frame 0, "
+                       "which carries new_traj and only runs the encoder + state reset; full_frames_per_s excludes it",
+        "per_rank_frames_per_s": [round(args.batch * args.seq_len * args.steps / s, 2) for s in per_rank_s],
         "config": {"workload": f"{args.height}x{args.width} {args.levels}-level seq_len={args.seq_len} "
-                               f"dscv_range={args.dscv_range} sncv_range={args.sncv_range} batch {args.batch}/GPU "
-                               "(BASELINE.json configs[1] when batch=1, configs[2] when batch=32)",
+                               f"dscv_range={args.dscv_range} sncv_range={args.sncv_range} batch {args.batch}/GPU = {cfg_name}",
                    "global_batch": world * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",
-                   "conv_backend": "hand-written fp32-MFMA convolutions with fused bias+leaky-relu (libm4depth_hip.so): "
-                                   "Winograd F(2x2,3x3) for the wide stride-1 layers of levels 1-3, direct implicit GEMM "
-                                   "(stride 1 / 2, split-K on the coarse levels) elsewhere; encoder head (3->16 convolution + DINL) as two fused "
-                                   "HIP kernels -- no MIOpen / framework kernel in the forward",
+                   "kernels": "every kernel of the captured forward is hand-written HIP (libm4depth_hip.so, gfx950): fp32-MFMA "
+                              "convolutions with fused bias+leaky-relu (Winograd F(2x2,3x3) on the wide stride-1 layers, direct "
+                              "implicit GEMM elsewhere), fused encoder head / refiner tail, the level kernels; no MIOpen, rocBLAS "
+                              "or PyTorch kernel in the graph (torch only launches the 7-metric kernel's host wrapper eagerly)",
                    "hot_path": "libm4depth_hip.so (HIP, gfx950)"},
         "AbsRel": round(metrics[0], 6), "sequence_batches_in_flight": args.in_flight,
         "launch": "eager" if args.eager else "hipGraph replay of the sequence forward; frames pipelined over the decoder "
                                                   "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)",
     }
+    if host_rate is not None:
+        out["host_input_frames_per_s"] = round(host_rate, 2)
     if timer.events:
         summ = timer.summary()
-        bytes_l1 = level_bytes(args, args.batch, 1)
-        # HBM traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
-        # WRITE_SIZE, KiB; profiles/r01_pmc_traffic.json), measured on the same kernels at the same
-        # geometry; null when no measurement exists for this batch size.
-        traffic = {}
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = tj.get(f"batch{args.batch}", {})
-        except Exception:
-            pass
-        # Dominant hand-written kernel of the step: the level-1 128->128 refiner convolution (fp32 MFMA
-        # implicit GEMM; algorithmic flops = 2*9*Cin*Cout per output pixel) -> "roofline"; the two
-        # level-1 cost-volume kernels (HBM-bound by bytes) -> "roofline_dscv" / "roofline_sncv".
+        traffic, traffic_note = load_traffic(args.batch)
+        out["traffic_note"] = traffic_note
+
+        def tr(name):
+            ent = traffic.get(name)
+            return None if ent is None else ent["bytes"]
+
+        # -- the dominant kernel of the step: the level-1 128->128 refiner convolution
+        conv = summ.get(("conv", "lvl1.conv1"))
         h1, w1 = args.height >> 1, args.width >> 1
-        for name, (n, sec) in summ.items():
-            if name == "conv":
-                # The layer's algorithmic work is the direct convolution's 2*9*Cin*Cout flops per pixel.  The kernel that
-                # runs it is Winograd F(2x2,3x3) (2.25x fewer multiply-adds, m4d_wino.hip) unless M4D_WINOGRAD=0, so the
-                # contract's `achieved` (algorithmic flops / time) can exceed the peak; the flops the kernel actually executes on
-                # the matrix cores (2*4*Cin*Cout per pixel, whole 2x2 tiles) and their fraction of the peak are reported next to it.
-                flops_direct = 2.0 * 9 * 128 * 128 * h1 * w1 * args.batch
-                wino = net.winograd_conv
-                flops_exec = 2.0 * 16 * 128 * 128 * ((h1 + 1) // 2) * ((w1 + 1) // 2) * args.batch if wino else flops_direct
-                tf = flops_direct / sec / 1e12                 # the contract's definition: ALGORITHMIC flops / time
-                tf_exec = flops_exec / sec / 1e12
-                out["roofline"] = {"kernel": ("conv3x3_wino4_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3) on fp32 MFMA, "
-                                              "bias+leaky-relu fused)") if wino else
-                                             "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)",
-                                   "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                                   "traffic": traffic.get("wino_l1_128_128" if wino else "conv_l1_128_128"),
-                                   "algorithmic_flops_per_launch": flops_direct,
-                                   "note": ("achieved / frac use the layer's algorithmic (direct-convolution) flops, 2*9*Cin*Cout per "
-                                            "pixel; the Winograd kernel executes 2.25x fewer on the matrix cores, so frac can exceed 1 -- "
-                                            "executed_* is the matrix-core utilisation") if wino else "direct convolution",
-                                   "executed_mfma_flops_per_launch": flops_exec,
-                                   "executed_tflops": round(tf_exec, 2), "executed_frac": round(tf_exec / FP32_MFMA_PEAK_TFLOPS, 4),
-                                   "algorithmic_bytes_per_launch": 4 * (2 * 128 * h1 * w1 * args.batch + 9 * 128 * 128),
-                                   "avg_launch_us": round(sec * 1e6, 2), "launches": n}
+        if conv is not None:
+            n, sec = conv
+            wino = net._use_winograd(args.batch, h1, w1, 128, 128, 1)
+            flops_direct = 2.0 * 9 * 128 * 128 * h1 * w1 * args.batch
+            flops_exec = 2.0 * 16 * 128 * 128 * ((h1 + 1) // 2) * ((w1 + 1) // 2) * args.batch if wino else flops_direct
+            tf_exec = flops_exec / sec / 1e12
+            key = "wino_l1_128_128" if wino else "conv_l1_128_128"
+            out["roofline"] = {
+                "kernel": ("conv3x3_wino4_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3) on fp32 MFMA, bias+leaky-relu fused)"
+                           if wino else "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)"),
+                "bound": "mfma", "achieved": round(tf_exec, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf_exec / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": tr(key),
+                "traffic_kernel": None if key not in traffic else traffic[key].get("kernel"),
+                "executed_mfma_flops_per_launch": flops_exec,
+                "note": "achieved / frac = MFMA flops the kernel executes (2*16*Cin*Cout per 2x2 output tile for Winograd; the "
+                        "direct kernel executes the algorithmic 2*9*Cin*Cout per pixel) / time; algorithmic_* prices the layer's "
+                        "direct-convolution flops over the same time (> peak is possible for Winograd: 2.25x fewer multiplies)",
+                "algorithmic_flops_per_launch": flops_direct,
+                "algorithmic_tflops": round(flops_direct / sec / 1e12, 2),
+                "algorithmic_bytes_per_launch": 4 * (2 * 128 * h1 * w1 * args.batch + 9 * 128 * 128),
+                "avg_launch_us": round(sec * 1e6, 2), "launches": n}
+        # -- the level-1 cost-volume kernels alone
+        bytes_l1 = level_bytes(args, args.batch, 1)
+        for name in ("front", "dscv", "sncv"):
+            ent = summ.get((name, 1))
+            if ent is None:
                 continue
+            n, sec = ent
             gbs = bytes_l1[name] / sec / 1e9
             out[f"roofline_{name}"] = {"kernel": f"{name}_level1", "bound": "hbm", "achieved": round(gbs, 1),
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                       "traffic": traffic.get(name), "algorithmic_bytes_per_launch": bytes_l1[name],
+                                       "traffic": tr(name),
+                                       "traffic_kernel": None if name not in traffic else traffic[name].get("kernel"),
+                                       "algorithmic_bytes_per_launch": bytes_l1[name],
                                        "avg_launch_us": round(sec * 1e6, 2), "launches": n}
-        if "roofline" not in out and "roofline_dscv" in out:            # hand-written convolutions disabled
-            out["roofline"] = out["roofline_dscv"]
+        # -- the whole hand-written hot path of one full frame against the HBM roofline
+        full_frames = min(args.steps, 5) * (args.seq_len - 1)
+        per_kernel = {}
+        for (name, lvl), (n, sec) in summ.items():
+            if name in HOT_KERNELS and name != "resize" and lvl != "reset":
+                per_kernel[name] = per_kernel.get(name, 0.0) + n * sec / max(full_frames, 1)
+        if per_kernel:
+            hp_bytes, resize_bytes = hotpath_bytes_per_frame(args, args.batch)
+            t_all = sum(per_kernel.values())
+            t_no_tail = sum(v for k, v in per_kernel.items() if k != "tail")
+            gbs = hp_bytes / t_all / 1e9
+            out["roofline_hotpath"] = {
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_frame": hp_bytes, "us_per_frame": round(t_all * 1e6, 1),
+                "us_per_frame_by_kernel": {k: round(v * 1e6, 1) for k, v in sorted(per_kernel.items())},
+                "frac_excluding_tail": round(hp_bytes / t_no_tail / 1e9 / HBM_PEAK_GBS, 4) if t_no_tail > 0 else None,
+                "note": "SURVEY 8(d) bytes of one full frame (all levels; x batch) / the summed HIP-event time of the hand-written "
+                        "level kernels of that frame (level_pre + normalise, DSCV, SNCV, refiner tail) / 8 TB/s.  The tail kernel "
+                        "also contains the last two refiner convolutions (32->16, 16->5), so `frac` is a lower bound for the "
+                        "path proper; frac_excluding_tail drops that kernel's time but keeps its level_post bytes.  Eager "
+                        "launches: levels <= 6000 pixels run DSCV and SNCV as two launches here, one merged launch in the graph"}
+        if "roofline" not in out and "roofline_hotpath" in out:
+            out["roofline"] = out["roofline_hotpath"]
     if not args.no_cpu_baseline and world == 1:
-        cb, (W, samples, cam, ref) = cpu_baseline(args)
+        cb, (W, samples, cam, ref, ref_seq) = cpu_baseline(args.height, args.width, args.levels, args.dscv_range, args.sncv_range,
+                                                           seq_len=args.seq_len, keep=True)
         out["cpu_baseline"] = cb
-        # parity of the same sample on the GPU: depth and AbsRel vs the oracle
+        cb1, _ = cpu_baseline(128, 256, 3, 2, 2, seq_len=4, seed=1234)
+        cb1["sample"] = "BASELINE.json configs[0] geometry (128x256, 3 levels, ranges 2/2): " + cb1["sample"]
+        out["cpu_baseline_config1"] = cb1
+        # parity of the same sequence on the GPU: depth and AbsRel vs the float32 oracle, and both float32 evaluations
+        # against the float64 evaluation of the oracle (the rounding-noise floor of the 1e-4 tolerance)
         model.reset_state()
 
         def dv(x):
@@ -315,11 +438,20 @@ def main():
 
         got = model([dv(samples), dv(cam)])["depth"].cpu().numpy()
         from oracle import m4depth_oracle as O
+        with O.float64_reference():
+            truth, _ = O.M4Depth(W, args.levels, dscv_range=args.dscv_range, sncv_range=args.sncv_range)(samples, cam)
         rel = np.abs(got - ref["depth"]) / np.maximum(np.abs(ref["depth"]), 1e-9)
+        rel_g64 = np.abs(got - truth["depth"]) / np.maximum(np.abs(truth["depth"]), 1e-9)
+        rel_o64 = np.abs(ref["depth"] - truth["depth"]) / np.maximum(np.abs(truth["depth"]), 1e-9)
         a_gpu = float(O.metrics_batch(samples[-1]["depth"], got)[0])
         a_ref = float(O.metrics_batch(samples[-1]["depth"], ref["depth"])[0])
-        out["parity"] = {"depth_rel_median": float(np.median(rel)), "depth_within_1e-4": float(np.mean(rel < 1e-4)),
-                         "AbsRel_gpu": a_gpu, "AbsRel_oracle": a_ref, "AbsRel_rel_diff": abs(a_gpu - a_ref) / a_ref}
+        out["parity"] = {"sample": f"the cpu_baseline sequence ({args.seq_len} frames), last frame's depth",
+                         "depth_rel_median": float(np.median(rel)), "depth_within_1e-4": float(np.mean(rel < 1e-4)),
+                         "AbsRel_gpu": a_gpu, "AbsRel_oracle": a_ref, "AbsRel_rel_diff": abs(a_gpu - a_ref) / a_ref,
+                         "vs_float64_oracle": {"gpu_depth_within_1e-4": float(np.mean(rel_g64 < 1e-4)),
+                                               "oracle_f32_depth_within_1e-4": float(np.mean(rel_o64 < 1e-4)),
+                                               "gpu_depth_rel_median": float(np.median(rel_g64)),
+                                               "oracle_f32_depth_rel_median": float(np.median(rel_o64))}}
     print(json.dumps(out))
 
 

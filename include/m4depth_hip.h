@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 1
+#define M4D_ABI_VERSION 2
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -253,13 +253,14 @@ int m4d_resize_nearest(const float* x, int b, int ih, int iw, int c, int oh, int
  *   depth_prev_l [b,h,w,1], other_prev_l [b,h,w,4];
  *   para_prev_t [b,h,w,1] = prev_d2para(depth_prev_t) (skipped when depth_prev_t NULL);
  *   if f_input != NULL: f_input[p*f_stride + log_off] = log(para_prev_l * log_scale) and,
- *   when other_off >= 0, f_input[p*f_stride + other_off + 0..3] = other_prev_l. */
+ *   when other_off >= 0, f_input[p*f_stride + other_off + 0..3] = other_prev_l;
+ *   if depth_state_reset != NULL (the new_traj branch, :208-214): depth_state_reset [b,h,w,1] := 1000 (:209). */
 int m4d_level_pre(const float* prev_l_depth, const float* prev_l_parallax, const float* prev_l_other,
                   int ph, int pw, const float* depth_prev_t, const float* trans,
                   const float* cam_f, const float* cam_c, int b, int h, int w,
                   float* para_prev_l, float* depth_prev_l, float* other_prev_l, float* para_prev_t,
                   float* f_input, int f_stride, int log_off, int other_off, float log_scale,
-                  void* stream);
+                  float* depth_state_reset, void* stream);
 /* m4d_level_pre and m4d_normalize_cuts(norm_x -> norm_out) -- the two independent kernels that open a level
  * (m4depth_network.py:179-189 and :196-227) -- in ONE launch: one kernel boundary less on the coarse-level latency chain.
  * Same results, bit for bit. */
@@ -268,7 +269,13 @@ int m4d_level_pre_normalize(const float* prev_l_depth, const float* prev_l_paral
                             const float* cam_f, const float* cam_c, int b, int h, int w,
                             float* para_prev_l, float* depth_prev_l, float* other_prev_l, float* para_prev_t,
                             float* f_input, int f_stride, int log_off, int other_off, float log_scale,
+                            float* depth_state_reset,
                             const float* norm_x, int C, int nbre_cuts, float* norm_out, void* stream);
+
+/* Level-local intrinsics of DepthEstimatorPyramid.call (m4depth_network.py:300-302) for all levels in one launch:
+ * f_out / c_out [levels,b,2], level l (0 = finest) = cam / 2^(l+1). */
+int m4d_camera_pyramid(const float* cam_f, const float* cam_c, int b, int levels, float* f_out, float* c_out,
+                       void* stream);
 
 /* Fused "depth_estimator" tail of one level (:247-260): refiner_out [b,h,w,5] ->
  * parallax = exp(clip(out0,-7,7)) / scale, other = out[1:5], depth =
@@ -334,11 +341,15 @@ int m4d_dinl_fwd(const float* x, const float* scale, const float* bias, int b, i
                  float slope, float* workspace, float* out, void* stream);
 
 /* Encoder level 0 (FeaturePyramid.call, m4depth_network.py:79-87 with DINL): the head of the network as two calls.
- * m4d_enc_head_fwd: conv3x3(images [b,h,w,3], w_hwio [3,3,3,16]) + bias -> raw_out [b,h,w,16], and the DINL statistics of
+ * m4d_enc_head_fwd: conv3x3(images, w_hwio [3,3,3,16]) + bias -> raw_out [b,h,w,16], and the DINL statistics of
  *   raw_out into workspace (n = m4d_dinl_workspace_floats(b,16) floats): mean = the b*16 floats at n - 2*b*16, var the last b*16.
+ *   Image n of the b = frames*bsz images starts at images + (n % bsz)*stride_b + (n / bsz)*stride_t floats: the frames of
+ *   a [bsz,T,H,W,3] sequence batch (M4Depth.call encodes every frame, :358-360) are read in place, frame-major; a dense
+ *   [b,h,w,3] batch is bsz = b, stride_b = h*w*3, stride_t = 0.
  * m4d_conv3x3s2_dinl_bias_act: the stride-2 convolution on leaky_relu(DomainNormalization(raw), dn_slope), the
  *   normalisation fused into its input staging; wp packed as for m4d_conv3x3s_bias_act_ws (CoutPad = 32). */
-int m4d_enc_head_fwd(const float* images, const float* w_hwio, const float* bias, int b, int h, int w, int C,
+int m4d_enc_head_fwd(const float* images, int bsz, long long stride_b, long long stride_t,
+                     const float* w_hwio, const float* bias, int b, int h, int w, int C,
                      float* workspace, float* raw_out, void* stream);
 int m4d_conv3x3s2_dinl_bias_act(const float* x_raw, const float* mean, const float* var, const float* dn_scale,
                                 const float* dn_bias, float dn_slope, const float* wp, const float* bias,
@@ -347,10 +358,11 @@ int m4d_conv3x3s2_dinl_bias_act(const float* x_raw, const float* mean, const flo
 /* The 7 metrics of metrics.py (AbsRel, SqRel, RMSE, RMSE_log, Delta1..3) of one batch in one
  * pass, including test_step's clipping gt in [0,max_d], est in [0.001,max_d]
  * (m4depth_network.py:465-467).  gt, est: n floats; out7: 7 floats (main.py:127-130 order);
- * workspace: m4d_metrics_workspace_bytes() bytes. */
+ * workspace: m4d_metrics_workspace_bytes() bytes.  total7 (may be NULL): the 7 Keras-Mean totals, += out7 in the same
+ * launch (compiled_metrics.update_state, :470); mean7 (may be NULL) = total7 / count, what test_step returns (:473-474). */
 long long m4d_metrics_workspace_bytes(void);
 int m4d_depth_metrics(const float* gt, const float* est, long long n, float max_d, void* workspace,
-                      float* out7, void* stream);
+                      float* out7, float* total7, float count, float* mean7, void* stream);
 
 /* ---- dataloaders (midair / kitti / tartanair .py): _decode_samples after decompression ----------------------- */
 

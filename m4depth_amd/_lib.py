@@ -14,6 +14,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libm4depth_hip.so")
 
+ABI_VERSION = 2               # M4D_ABI_VERSION of include/m4depth_hip.h this binding was written for
+
 _c_fp = ctypes.c_void_p       # device pointers travel as void*
 _c_int = ctypes.c_int
 _c_f = ctypes.c_float
@@ -68,17 +70,19 @@ _SIGNATURES = {
     "m4d_conv3x3_small_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino2_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
-    "m4d_enc_head_fwd": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
+    "m4d_enc_head_fwd": [_c_fp, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int,
+                         _c_fp, _c_fp, _c_fp],
     "m4d_conv3x3s2_dinl_bias_act": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_f, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                     _c_f, _c_fp, _c_fp],
     "m4d_refiner_tail": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
                          _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
-    "m4d_depth_metrics": [_c_fp, _c_fp, ctypes.c_longlong, _c_f, _c_fp, _c_fp, _c_fp],
+    "m4d_depth_metrics": [_c_fp, _c_fp, ctypes.c_longlong, _c_f, _c_fp, _c_fp, _c_fp, _c_f, _c_fp, _c_fp],
     "m4d_level_pre": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int,
-                      _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp],
+                      _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_level_pre_normalize": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int,
-                                _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
+                                _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp,
                                 _c_fp, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_camera_pyramid": [_c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
     "m4d_level_post": [_c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
                        _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
 }
@@ -115,8 +119,8 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = None
         fn.argtypes = args
-    if lib.m4d_abi_version() != 1:
-        raise ImportError(f"m4depth_amd: ABI mismatch, library reports {lib.m4d_abi_version()}, binding expects 1")
+    if lib.m4d_abi_version() != ABI_VERSION:
+        raise ImportError(f"m4depth_amd: ABI mismatch, library reports {lib.m4d_abi_version()}, binding expects {ABI_VERSION}")
     return lib
 
 

@@ -5,5 +5,5 @@
 extern "C" int m4d_abi_version(void) { return M4D_ABI_VERSION; }
 
 extern "C" const char* m4d_build_info(void) {
-  return "libm4depth_hip gfx950 (CDNA4) -ffp-contract=off abi=1 built " __DATE__ " " __TIME__;
+  return "libm4depth_hip gfx950 (CDNA4) -ffp-contract=off abi=2 built " __DATE__ " " __TIME__;
 }

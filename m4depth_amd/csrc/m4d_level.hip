@@ -145,6 +145,7 @@ struct LevelPreArgs {
   int h, w;
   float* para_prev_l; float* depth_prev_l; float* other_prev_l; float* para_prev_t;
   float* f_input; int f_stride, log_off, other_off; float log_scale;
+  float* depth_state_reset;      // reset branch (:209): the level's depth memory := 1000 in the same pass
 };
 
 __device__ __forceinline__ void level_pre_body(const LevelPreArgs& a, int bx, int bi, int gdx) {
@@ -175,6 +176,7 @@ __device__ __forceinline__ void level_pre_body(const LevelPreArgs& a, int bx, in
     if (a.para_prev_l) a.para_prev_l[gp] = para;
     if (a.depth_prev_l) a.depth_prev_l[gp] = depth;
     if (a.other_prev_l) *reinterpret_cast<float4*>(a.other_prev_l + gp * 4) = make_float4(o0, o1, o2, o3);
+    if (a.depth_state_reset) a.depth_state_reset[gp] = 1000.0f;
     if (a.depth_prev_t && a.para_prev_t) {                                           // prev_d2para, :218
       const float mx = ((float)i + 0.5f) - cx, my = ((float)j + 0.5f) - cy;
       const float ccx = (mx / fx) * fx, ccy = (my / fy) * fy;
@@ -279,6 +281,18 @@ bias_act_padded_kernel(const float* __restrict__ x, const float* __restrict__ bi
   }
 }
 
+// level-local intrinsics camera / 2^(l+1) for every level in one launch (m4depth_network.py:300-302; x * 2^-k is exactly
+// x / 2^k in float32)
+__global__ void camera_pyramid_kernel(const float* __restrict__ f, const float* __restrict__ c, int n, int levels,
+                                      float* __restrict__ f_out, float* __restrict__ c_out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * levels) return;
+  const int l = idx / n, e = idx - l * n;
+  const float sc = 1.0f / (float)(1u << (l + 1));
+  f_out[idx] = f[e] * sc;
+  c_out[idx] = c[e] * sc;
+}
+
 inline int grid1d(long long total) {
   long long g = (total + 255) / 256;
   if (g > 256 * 32) g = 256 * 32;
@@ -333,12 +347,14 @@ extern "C" int m4d_level_pre_normalize(const float* prev_l_depth, const float* p
                                        const float* cam_f, const float* cam_c, int b, int h, int w,
                                        float* para_prev_l, float* depth_prev_l, float* other_prev_l, float* para_prev_t,
                                        float* f_input, int f_stride, int log_off, int other_off, float log_scale,
+                                       float* depth_state_reset,
                                        const float* norm_x, int C, int nbre_cuts, float* norm_out, void* stream) {
   M4D_CHECK_ARG(b > 0 && h > 0 && w > 0);
   M4D_CHECK_ARG(norm_x && norm_out && C > 0 && nbre_cuts > 0 && C % nbre_cuts == 0);
   const bool any_prev = prev_l_depth || prev_l_parallax || prev_l_other;
   if (any_prev) M4D_CHECK_ARG(prev_l_depth && prev_l_parallax && prev_l_other && ph > 0 && pw > 0);
   if (depth_prev_t) M4D_CHECK_ARG(trans && cam_f && cam_c && para_prev_t);
+  M4D_CHECK_ARG(!(depth_state_reset && depth_state_reset == depth_prev_t));
   if (f_input) M4D_CHECK_ARG(f_stride > 0 && log_off >= 0 && log_off < f_stride && other_off + 4 <= f_stride);
   if (other_prev_l) M4D_CHECK_ARG((((uintptr_t)other_prev_l) & 15u) == 0);
   LevelPreArgs a;
@@ -346,6 +362,7 @@ extern "C" int m4d_level_pre_normalize(const float* prev_l_depth, const float* p
   a.depth_prev_t = depth_prev_t; a.trans = trans; a.cam_f = cam_f; a.cam_c = cam_c; a.h = h; a.w = w;
   a.para_prev_l = para_prev_l; a.depth_prev_l = depth_prev_l; a.other_prev_l = other_prev_l; a.para_prev_t = para_prev_t;
   a.f_input = f_input; a.f_stride = f_stride; a.log_off = log_off; a.other_off = other_off; a.log_scale = log_scale;
+  a.depth_state_reset = depth_state_reset;
   int gx = m4d_blocks((long long)h * w, 256);
   if (gx > 4096) gx = 4096;
   const int nc = C / nbre_cuts;
@@ -376,11 +393,12 @@ extern "C" int m4d_level_pre(const float* prev_l_depth, const float* prev_l_para
                              const float* cam_f, const float* cam_c, int b, int h, int w,
                              float* para_prev_l, float* depth_prev_l, float* other_prev_l, float* para_prev_t,
                              float* f_input, int f_stride, int log_off, int other_off, float log_scale,
-                             void* stream) {
+                             float* depth_state_reset, void* stream) {
   M4D_CHECK_ARG(b > 0 && h > 0 && w > 0);
   const bool any_prev = prev_l_depth || prev_l_parallax || prev_l_other;
   if (any_prev) M4D_CHECK_ARG(prev_l_depth && prev_l_parallax && prev_l_other && ph > 0 && pw > 0);
   if (depth_prev_t) M4D_CHECK_ARG(trans && cam_f && cam_c && para_prev_t);
+  M4D_CHECK_ARG(!(depth_state_reset && depth_state_reset == depth_prev_t));
   if (f_input) M4D_CHECK_ARG(f_stride > 0 && log_off >= 0 && log_off < f_stride && other_off + 4 <= f_stride);
   if (other_prev_l) M4D_CHECK_ARG((((uintptr_t)other_prev_l) & 15u) == 0);
   LevelPreArgs a;
@@ -388,9 +406,19 @@ extern "C" int m4d_level_pre(const float* prev_l_depth, const float* prev_l_para
   a.depth_prev_t = depth_prev_t; a.trans = trans; a.cam_f = cam_f; a.cam_c = cam_c; a.h = h; a.w = w;
   a.para_prev_l = para_prev_l; a.depth_prev_l = depth_prev_l; a.other_prev_l = other_prev_l; a.para_prev_t = para_prev_t;
   a.f_input = f_input; a.f_stride = f_stride; a.log_off = log_off; a.other_off = other_off; a.log_scale = log_scale;
+  a.depth_state_reset = depth_state_reset;
   int gx = m4d_blocks((long long)h * w, 256);
   if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(level_pre_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, a);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_camera_pyramid(const float* cam_f, const float* cam_c, int b, int levels, float* f_out, float* c_out,
+                                  void* stream) {
+  M4D_CHECK_ARG(cam_f && cam_c && f_out && c_out && b > 0 && levels > 0 && levels < 31);
+  const int n = 2 * b;
+  hipLaunchKernelGGL(camera_pyramid_kernel, dim3((n * levels + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     cam_f, cam_c, n, levels, f_out, c_out);
   return M4D_LAUNCH_RESULT();
 }
 

@@ -111,11 +111,14 @@ dinl_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, c
 template <int C>
 __global__ void __launch_bounds__(256)
 enc_head_conv_kernel(const float* __restrict__ img, const float* __restrict__ w27, const float* __restrict__ bias,
-                     int h, int w, float* __restrict__ out, float* __restrict__ partial) {
+                     int h, int w, int bsz, long long stride_b, long long stride_t,
+                     float* __restrict__ out, float* __restrict__ partial) {
   __shared__ float sh[4][C];
   const int bi = blockIdx.y;
   const int hw = h * w;
-  const float* ib = img + (long long)bi * hw * 3;
+  // image bi = frame (bi / bsz) of sequence (bi % bsz): the frames of a [b,T,H,W,3] batch are encoded in one launch,
+  // frame-major, straight from the sequence tensor (no stacking copy)
+  const float* ib = img + (long long)(bi % bsz) * stride_b + (long long)(bi / bsz) * stride_t;
   float* ob = out + (long long)bi * hw * C;
   float csum[C];
 #pragma unroll
@@ -209,7 +212,8 @@ metrics_partial_kernel(const float* __restrict__ gt_raw, const float* __restrict
 }
 
 __global__ void __launch_bounds__(kMetricSums * 32)
-metrics_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out7) {
+metrics_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ out7,
+                        float* __restrict__ total7, float count, float* __restrict__ mean7) {
   __shared__ double sub[kMetricSums * 32];
   __shared__ double tot[kMetricSums];
   const int q = threadIdx.x % kMetricSums, j = threadIdx.x / kMetricSums;    // 32 sub-sums per quantity
@@ -231,6 +235,14 @@ metrics_finalize_kernel(const double* __restrict__ partial, int nblk, float* __r
     out7[4] = (float)(tot[6] / cnt);                 // Delta1..3
     out7[5] = (float)(tot[7] / cnt);
     out7[6] = (float)(tot[8] / cnt);
+    if (total7) {                                    // Keras Mean (metrics.py): total += per-batch value; result = total / count
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const float t = total7[i] + out7[i];
+        total7[i] = t;
+        if (mean7) mean7[i] = t / count;
+      }
+    }
   }
 }
 
@@ -271,10 +283,12 @@ extern "C" int m4d_dinl_fwd_padded(const float* x, const float* scale, const flo
   return M4D_LAUNCH_RESULT();
 }
 
-extern "C" int m4d_enc_head_fwd(const float* images, const float* w_hwio, const float* bias, int b, int h, int w, int C,
+extern "C" int m4d_enc_head_fwd(const float* images, int bsz, long long stride_b, long long stride_t,
+                                const float* w_hwio, const float* bias, int b, int h, int w, int C,
                                 float* workspace, float* raw_out, void* stream) {
   M4D_CHECK_ARG(images && w_hwio && bias && workspace && raw_out && b > 0 && h > 0 && w > 0);
   M4D_CHECK_ARG(C == 16);                            // encoder level 0 of the reference (m4depth_network.py:59)
+  M4D_CHECK_ARG(bsz > 0 && b % bsz == 0 && stride_b >= 0 && stride_t >= 0);
   M4D_CHECK_ARG(((((uintptr_t)raw_out | (uintptr_t)workspace)) & 15u) == 0);
   hipStream_t s = (hipStream_t)stream;
   const int hw = h * w;
@@ -284,7 +298,8 @@ extern "C" int m4d_enc_head_fwd(const float* images, const float* w_hwio, const 
   float* partial = workspace;
   float* mean = workspace + (long long)b * kDinlMaxBlocks * C;
   float* var = mean + (long long)b * C;
-  hipLaunchKernelGGL(enc_head_conv_kernel<16>, dim3(nblk, b), dim3(256), 0, s, images, w_hwio, bias, h, w, raw_out, partial);
+  hipLaunchKernelGGL(enc_head_conv_kernel<16>, dim3(nblk, b), dim3(256), 0, s, images, w_hwio, bias, h, w, bsz, stride_b, stride_t,
+                     raw_out, partial);
   hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
   const int ppi = 256 / (C / 4);
   int nblk2 = (hw + ppi * 8 - 1) / (ppi * 8);
@@ -297,12 +312,13 @@ extern "C" int m4d_enc_head_fwd(const float* images, const float* w_hwio, const 
 extern "C" long long m4d_metrics_workspace_bytes(void) { return (long long)kMetricBlocks * kMetricSums * sizeof(double); }
 
 extern "C" int m4d_depth_metrics(const float* gt, const float* est, long long n, float max_d, void* workspace,
-                                 float* out7, void* stream) {
+                                 float* out7, float* total7, float count, float* mean7, void* stream) {
   M4D_CHECK_ARG(gt && est && workspace && out7 && n > 0);
+  M4D_CHECK_ARG(!mean7 || (total7 && count > 0.f));
   hipStream_t s = (hipStream_t)stream;
   long long g = (n + 255) / 256;
   const int nblk = (int)(g < kMetricBlocks ? g : kMetricBlocks);
   hipLaunchKernelGGL(metrics_partial_kernel, dim3(nblk), dim3(256), 0, s, gt, est, n, max_d, (double*)workspace);
-  hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(kMetricSums * 32), 0, s, (const double*)workspace, nblk, out7);
+  hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(kMetricSums * 32), 0, s, (const double*)workspace, nblk, out7, total7, count, mean7);
   return M4D_LAUNCH_RESULT();
 }

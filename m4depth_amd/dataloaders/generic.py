@@ -255,10 +255,16 @@ class DataLoaderGeneric():
         return batch
 
     # -- dataset construction ---------------------------------------------------------------
-    def get_dataset(self, usecase, settings, batch_size=3, out_size=None, device=None, seed=42, prefetch=2):
+    def get_dataset(self, usecase, settings, batch_size=3, out_size=None, device=None, seed=42, prefetch=2,
+                    shard=(0, 1)):
         ''' Builds the dataset (dataloaders/generic.py:50-82).
             * usecase : train, finetune, eval or predict
-            * settings: DataloaderParameters (db_path_config, records_path, db_seq_len, seq_len, augment) '''
+            * settings: DataloaderParameters (db_path_config, records_path, db_seq_len, seq_len, augment)
+            * shard   : (rank, world) -- build extension for data-parallel runs.  ``batch_size`` is the PER-RANK batch;
+                        a global batch is ``world`` consecutive per-rank batches of the (identically seeded, identically
+                        shuffled) chunk list and rank r reads, decompresses and decodes only its own slice.  Every rank
+                        gets the same number of batches (the remainder that does not fill a global batch is dropped,
+                        like ``batch(drop_remainder=True)``), so per-step collectives never deadlock. '''
         if out_size is None:
             self._set_output_size()
         else:
@@ -272,7 +278,15 @@ class DataLoaderGeneric():
         self.usecase = usecase
         self.device = torch.device(device) if device is not None else \
             torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        self.rng = np.random.default_rng(seed)
+        # two independent generators: the plan (shuffle, _cut_sequence offsets) is drawn in the prefetch thread, the
+        # augmentation parameters in the consumer thread -- a shared Generator is neither thread-safe nor reproducible.
+        # The plan generator is the same on every rank (same seed); the augmentation generator is per rank.
+        self.shard_rank, self.shard_world = int(shard[0]), int(shard[1])
+        if not 0 <= self.shard_rank < self.shard_world:
+            raise ValueError(f"shard={shard}: rank must be in [0, world)")
+        plan_seq, aug_seq = np.random.SeedSequence(seed).spawn(2)
+        self.plan_rng = np.random.default_rng(plan_seq)
+        self.rng = np.random.default_rng(aug_seq.spawn(self.shard_world)[self.shard_rank])
         self.prefetch = prefetch
         self.streaming = False
         if usecase == "train" and (self.db_seq_len is None or self.seq_len is None):
@@ -300,16 +314,16 @@ class DataLoaderGeneric():
         for traj in self._get_trajectories():                                  # batch(db_seq_len, drop_remainder)
             for i in range(0, len(traj) - self.db_seq_len + 1, self.db_seq_len):
                 chunks.append(traj[i:i + self.db_seq_len])
-        n_batches = len(chunks) // self.batch_size
+        rank, world, bs = self.shard_rank, self.shard_world, self.batch_size
+        n_batches = len(chunks) // (bs * world)                                 # global batches: the same count on every rank
 
         def plan():                                                             # one epoch
-            order = self.rng.permutation(len(chunks))                           # shuffle(cardinality, reshuffle_each_iteration)
+            order = self.plan_rng.permutation(len(chunks))                      # shuffle(cardinality, reshuffle_each_iteration)
             for bi in range(n_batches):
-                batch = []
-                for ci in order[bi * self.batch_size:(bi + 1) * self.batch_size]:
-                    off = int(self.rng.integers(0, self.db_seq_len - self.seq_len + 1))   # _cut_sequence (:148-158)
-                    batch.append(chunks[ci][off:off + self.seq_len])
-                yield batch
+                glob_ids = order[bi * bs * world:(bi + 1) * bs * world]
+                offs = self.plan_rng.integers(0, self.db_seq_len - self.seq_len + 1, size=len(glob_ids))   # _cut_sequence (:148-158)
+                yield [chunks[ci][int(off):int(off) + self.seq_len]
+                       for ci, off in zip(glob_ids[rank * bs:(rank + 1) * bs], offs[rank * bs:(rank + 1) * bs])]
 
         return SequenceDataset(self, plan, n_batches, self.prefetch)
 
@@ -323,13 +337,17 @@ class DataLoaderGeneric():
             for traj in trajectories:
                 for i in range(0, len(traj) - self.db_seq_len + 1, self.db_seq_len):
                     chunks.append(traj[i:i + self.db_seq_len])
-            n_batches = len(chunks) // self.batch_size
+            rank, world, bs = self.shard_rank, self.shard_world, self.batch_size
+            n_batches = len(chunks) // (bs * world)
 
             def plan():
                 for bi in range(n_batches):
-                    yield chunks[bi * self.batch_size:(bi + 1) * self.batch_size]
+                    lo = (bi * world + rank) * bs
+                    yield chunks[lo:lo + bs]
             return SequenceDataset(self, plan, n_batches, self.prefetch)
         # streaming: one frame at a time, batch 1, trajectories back to back (:137-138)
+        if self.shard_world > 1:
+            raise ValueError("streaming evaluation (db_seq_len None) is sequential: it cannot be sharded")
         self.streaming = True
         frames = [row for traj in trajectories for row in traj]
 

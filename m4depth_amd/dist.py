@@ -69,6 +69,20 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def all_gather_floats(value, device):
+    """One python float per rank -> the list over ranks (report only: per-rank frames/s of the scaling bench)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    world = dist.get_world_size()
+    local = torch.tensor([float(value)], dtype=torch.float32, device=device)
+    out = torch.empty(world, dtype=torch.float32, device=device)
+    if device.type == "cuda":
+        dist.all_gather_into_tensor(out, local)
+    else:
+        dist.all_gather(list(out.unbind(0)), local[0])
+    return [float(v) for v in out.tolist()]
+
+
 def barrier(device):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         if device.type == "cuda":

@@ -77,8 +77,9 @@ def synthetic_batches(args, rank, world, dev):
 
 def dataset_batches(args, usecase, rank, world, dev):
     """Batches of one of the reference's datasets (main.py:67,77,120,152).  Returns (iterable, depth_type).
-    With several ranks the PER-RANK batch is batch_size / world and rank r takes every world-th batch
-    (sequences are independent); streaming evaluation is inherently sequential and stays single-rank."""
+    With several ranks the PER-RANK batch is batch_size / world; the loader shards the chunk list itself
+    (``shard=(rank, world)``): every rank gets the same number of batches and reads / decodes only its own
+    sequences.  Streaming evaluation is inherently sequential and stays single-rank."""
     import json
     from . import dataloaders as dl
     if args.db_path_config is None or args.records_path is None:
@@ -94,13 +95,9 @@ def dataset_batches(args, usecase, rank, world, dev):
         raise SystemExit("streaming evaluation (no --db_seq_len) is sequential: run it on one rank")
     per_rank = 1 if streaming else D.shard_range(args.batch_size, rank, world)[1] - D.shard_range(args.batch_size, rank, world)[0]
     kw = {"out_size": [args.height, args.width]} if args.height and args.width else {}
-    ds = loader.get_dataset(usecase, settings, batch_size=per_rank, device=dev, seed=args.seed, **kw)
-
-    def it():
-        for i, batch in enumerate(ds):
-            if i % world == rank:
-                yield batch
-    return it(), loader.depth_type
+    ds = loader.get_dataset(usecase, settings, batch_size=per_rank, device=dev, seed=args.seed,
+                            shard=(0, 1) if streaming else (rank, world), **kw)
+    return ds, loader.depth_type
 
 
 def _train_dir(args):

@@ -1,15 +1,13 @@
 """M4Depth network, inference path -- same layer names and call signatures as
 the reference ``m4depth_network.py``.
 
-Host code is Python on PyTorch-ROCm: the encoder (``FeaturePyramid``) and
-decoder (``DispRefiner``) 3x3 convolutions run on MIOpen with TF ``SAME``
-padding semantics; everything else inside ``DepthEstimatorLevel`` -- per-cut
-normalisation, x2 upsampling of the coarser estimate, prev_d2para, the DSCV
-and SNCV cost volumes, the log-parallax features, exp/clip and parallax2depth --
-is hand-written HIP (libm4depth_hip.so) writing straight into the refiner's
-input tensor.  Activations are NHWC float32 (``[b,h,w,c]``), exactly the
-reference's layout; for the convolutions they are viewed as channels-last NCHW
-without a copy.
+Host code is Python on PyTorch-ROCm (modules, control flow, device memory, streams, hipGraph capture); every kernel
+the inference forward launches on the GPU is hand-written HIP from libm4depth_hip.so: the encoder (``FeaturePyramid``)
+and decoder (``DispRefiner``) 3x3 convolutions with TF ``SAME`` padding (fp32-MFMA implicit GEMM / Winograd, fused
+bias + leaky_relu, fused encoder head and refiner tail), and everything inside ``DepthEstimatorLevel`` -- per-cut
+normalisation, x2 upsampling of the coarser estimate, prev_d2para, the DSCV and SNCV cost volumes, the log-parallax
+features, exp/clip and parallax2depth -- writing straight into the refiner's input tensor.  No MIOpen / rocBLAS kernel
+is involved.  Activations are NHWC float32 (``[b,h,w,c]``), exactly the reference's layout.
 """
 from __future__ import annotations
 
@@ -32,24 +30,7 @@ M4depthAblationParameters = namedtuple('M4depthAblationParameters',
 
 _CV_ACCUM = {"fp32_round": 0, "fp16_seq": 1}
 
-# 3x3 convolutions with at least this many input pixels (b*h*w) run on the hand-written
-# fp32-MFMA kernel with fused bias/leaky-relu epilogue (csrc/m4d_conv.hip; stride 1 and 2, TF
-# 'SAME' padding inside), which beats MIOpen + epilogue on every layer of every level
-# (tools/bench_conv.py) and is deterministic; 0 disables it (MIOpen everywhere).
 import os as _os
-mfma_conv_min_pixels = int(_os.environ.get("M4D_MFMA_CONV_MIN_PIXELS", "1"))
-
-# The 3-channel image convolution (K = 27 padded to 144, N = 16 padded to 32) wastes 10x the MFMA
-# work and is faster on MIOpen (tools/bench_conv_enc.py): only layers with at least this many
-# input channels take the hand-written kernel.
-mfma_conv_min_cin = int(_os.environ.get("M4D_MFMA_CONV_MIN_CIN", "8"))
-
-# Encoder on the hand-written kernel too (stride 1 and 2)?  A/B on one MI355X, whole bench at batch 1:
-# 7.11 ms / step with it, 7.13 ms with MIOpen + padded-buffer epilogues -- equal, so the default is the
-# hand-written kernel (deterministic, no padded buffers).  With mfma_conv_min_cin = 1 on top (+0.1 ms:
-# the 3-channel layer) no MIOpen kernel is left in the model and two runs are bit-identical
-# (tests/test_gpu_model.py::test_fully_deterministic_mode_is_bitwise).
-mfma_conv_encoder = _os.environ.get("M4D_MFMA_CONV_ENCODER", "1") == "1"
 
 # bench.py installs an object with ``run(name, level, thunk)`` here to bracket the
 # hand-written kernels with HIP events on the launch stream; None = no overhead.
@@ -119,6 +100,25 @@ pipeline_encoder_per_frame = _os.environ.get("M4D_PIPELINE_ENCODER", "0") == "1"
 pipeline_encoder_split = int(_os.environ.get("M4D_PIPELINE_ENCODER_SPLIT", "2"))
 
 
+def _stack_frames(samples):
+    """The RGB frames of ``samples`` as ONE encoder batch, frame-major (image t*b + i).  When the frames are views of one
+    [b,T,H,W,3] sequence tensor (what test_step's unstacking produces, m4depth_network.py:439-447) the result is a
+    ``FrameStack`` the fused encoder head reads in place; otherwise they are concatenated."""
+    ims = [s['RGB_im'] for s in samples]
+    x0 = ims[0]
+    if (x0.is_cuda and x0.dtype == torch.float32 and x0.dim() == 4 and x0[0].is_contiguous()
+            and all(x.dtype == x0.dtype and x.shape == x0.shape and x.stride() == x0.stride()
+                    and x.untyped_storage().data_ptr() == x0.untyped_storage().data_ptr() for x in ims)):
+        if len(ims) == 1:
+            return nops.FrameStack(x0.unsqueeze(1))
+        st = ims[1].storage_offset() - x0.storage_offset()
+        if st > 0 and all(ims[t].storage_offset() - x0.storage_offset() == t * st for t in range(len(ims))):
+            b, h, w, c = x0.shape
+            return nops.FrameStack(torch.as_strided(x0, (b, len(ims), h, w, c), (x0.stride(0), st, w * c, c, 1),
+                                                    x0.storage_offset()))
+    return torch.cat([as_f32(x, "RGB_im") for x in ims], dim=0)
+
+
 def _timed(name, level, thunk):
     kt = kernel_timer
     return thunk() if kt is None else kt.run(name, level, thunk)
@@ -130,12 +130,53 @@ def _to_device_f32(x, device):
     return torch.as_tensor(np.asarray(x), dtype=torch.float32, device=device)
 
 
+def _stamp(*params):
+    """Identity + in-place version of parameters: changes after ``optimizer.step()``, ``load_state_dict`` or any other
+    in-place update, so packed copies keyed on it can never go stale silently (training.py keys its caches the same way)."""
+    return tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+
+
+class _PackCache:
+    """Packed / transformed copies of a layer's weights, each remembered with the ``_stamp`` of the parameters it was
+    built from.  A stale entry is rebuilt INTO THE SAME DEVICE TENSOR (``copy_``), so a hipGraph that captured the
+    packed tensor's address sees the new weights at its next replay."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, key, stamp, build):
+        hit = self.entries.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("packed convolution weights are missing or stale inside a hipGraph capture: call "
+                               "M4Depth.prepack() before capturing")
+        fresh = build()
+        if hit is not None:
+            old = hit[1]
+            olds, news = (old if isinstance(old, tuple) else (old,)), (fresh if isinstance(fresh, tuple) else (fresh,))
+            if len(olds) == len(news) and all(isinstance(o, torch.Tensor) == isinstance(n, torch.Tensor) and (
+                    not isinstance(o, torch.Tensor) or (o.shape == n.shape and o.device == n.device)) for o, n in zip(olds, news)):
+                for o, n in zip(olds, news):
+                    if isinstance(o, torch.Tensor):
+                        o.copy_(n)
+                fresh = old
+        self.entries[key] = (stamp, fresh)
+        return fresh
+
+    def clear(self):
+        self.entries.clear()
+
+
 class _Conv3x3SameTF(torch.nn.Module):
     """Keras Conv2D(filters, 3, strides, padding='same') on NHWC tensors.
 
     TF 'SAME': out = ceil(in/stride), total pad = max((out-1)*stride + 3 - in, 0),
     pad_before = total // 2 -- so stride 2 on an even size pads bottom/right only,
-    which torch's symmetric ``padding=1`` does not reproduce."""
+    which torch's symmetric ``padding=1`` does not reproduce.
+
+    On the GPU every call is one hand-written HIP kernel (m4d_conv.hip / m4d_wino.hip) with the bias add and the
+    leaky_relu fused; the padding rule lives inside the kernels."""
 
     def __init__(self, out_channels, stride, in_channels=None):
         super().__init__()
@@ -143,7 +184,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.stride = stride
         self.weight = None
         self.bias = None
-        self._packed = None
+        self._cache = _PackCache()
         self.tag = None                  # e.g. "lvl1.conv1": lets bench.py bracket one layer with HIP events
         self.small_maps_ok = False       # DispRefiner layers: may take the one-launch small-map kernel
         if in_channels is not None:
@@ -154,20 +195,14 @@ class _Conv3x3SameTF(torch.nn.Module):
         torch.nn.init.kaiming_normal_(w, nonlinearity='relu')       # ks.initializers.HeNormal (:61,:100)
         self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.bias = torch.nn.Parameter(torch.zeros(self.out_channels, device=device), requires_grad=False)
-        self._packed = None
-        self._packed_wino = None
-        self._packed_padded = None
-        self._hwio = None
+        self._cache.clear()
 
     def load_hwio(self, kernel, bias, device):
         """Load a TF-layout [3,3,Cin,Cout] kernel."""
         w = _to_device_f32(kernel, device).permute(3, 2, 0, 1)
         self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.bias = torch.nn.Parameter(_to_device_f32(bias, device).contiguous(), requires_grad=False)
-        self._packed = None
-        self._packed_wino = None
-        self._packed_padded = None
-        self._hwio = None
+        self._cache.clear()
 
     def _hwio_numpy(self, cin_pad=None):
         """The TF-layout kernel on the host; ``cin_pad`` > Cin appends zero input channels (for a zero-padded input)."""
@@ -177,32 +212,28 @@ class _Conv3x3SameTF(torch.nn.Module):
         return hwio
 
     def _packed_weights(self, cin_pad=None):
-        """(wp, CoutPad) for m4d_conv3x3_bias_act, packed once from the OIHW parameter."""
-        if cin_pad is not None and cin_pad != self.weight.shape[1]:
-            cache = getattr(self, "_packed_padded", None)
-            if cache is None:
-                cache = self._packed_padded = {}
-            hit = cache.get(cin_pad)
-            if hit is None or hit[0].device != self.weight.device:
-                wp, cpad = nops.pack_conv_weights(self._hwio_numpy(cin_pad))
-                hit = cache[cin_pad] = (torch.from_numpy(wp).to(self.weight.device), cpad)
-            return hit
-        if self._packed is None or self._packed[0].device != self.weight.device:
-            wp, cpad = nops.pack_conv_weights(self._hwio_numpy())
-            self._packed = (torch.from_numpy(wp).to(self.weight.device), cpad)
-        return self._packed
+        """(wp, CoutPad) for m4d_conv3x3_bias_act, packed from the live OIHW parameter (re-packed when it changes)."""
+        if cin_pad is not None and cin_pad == self.weight.shape[1]:
+            cin_pad = None
+
+        def build():
+            wp, cpad = nops.pack_conv_weights(self._hwio_numpy(cin_pad))
+            return torch.from_numpy(wp).to(self.weight.device), cpad
+        return self._cache.get(("direct", cin_pad), _stamp(self.weight), build)
 
     def _packed_weights_winograd(self, chunk=16, cin_pad=None):
-        """(wu, CoutPad) for m4d_conv3x3_wino_bias_act (chunk 16) / wino2 (chunk 8): U = G g G^T, transformed once on the host."""
-        cache = getattr(self, "_packed_wino", None)
-        if cache is None:
-            cache = self._packed_wino = {}
-        key = chunk if cin_pad is None or cin_pad == self.weight.shape[1] else (chunk, cin_pad)
-        hit = cache.get(key)
-        if hit is None or hit[0].device != self.weight.device:
+        """(wu, CoutPad) for m4d_conv3x3_wino_bias_act (chunk 16) / wino2 (chunk 8): U = G g G^T, transformed on the host."""
+        if cin_pad is not None and cin_pad == self.weight.shape[1]:
+            cin_pad = None
+
+        def build():
             wu, cpad = nops.pack_conv_weights_winograd(self._hwio_numpy(cin_pad), chunk=chunk)
-            hit = cache[key] = (torch.from_numpy(wu).to(self.weight.device), cpad)
-        return hit
+            return torch.from_numpy(wu).to(self.weight.device), cpad
+        return self._cache.get(("wino", chunk, cin_pad), _stamp(self.weight), build)
+
+    def _hwio_device(self):
+        """The TF-layout [3,3,Cin,Cout] kernel as a contiguous device tensor (the encoder-head kernel reads it directly)."""
+        return self._cache.get(("hwio",), _stamp(self.weight), lambda: self.weight.detach().permute(2, 3, 1, 0).contiguous())
 
     def same_pads(self, h, w):
         """TF 'SAME' (before, after) pads for rows and columns at this stride."""
@@ -211,52 +242,32 @@ class _Conv3x3SameTF(torch.nn.Module):
         pw = max((-(-w // s) - 1) * s + 3 - w, 0)
         return (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)
 
-    def conv_raw(self, x_nhwc, padding):
-        """The bare MIOpen convolution (no bias) of an NHWC tensor; NHWC result."""
-        if self.weight is None:
-            self._build(x_nhwc.shape[-1], x_nhwc.device)
-        y = F.conv2d(x_nhwc.permute(0, 3, 1, 2), self.weight, None, self.stride, padding).permute(0, 2, 3, 1)
-        return y if y.is_contiguous() else y.contiguous()
-
     def forward(self, x_nhwc, slope=None):
-        """Convolution + bias (+ leaky_relu(slope) when ``slope`` is given).  On the GPU the
-        bias add and the activation are one in-place HIP epilogue pass instead of two more
-        PyTorch kernels; on CPU tensors (host-logic tests) plain torch ops are used."""
+        """Convolution + bias (+ leaky_relu(slope) when ``slope`` is given): one HIP kernel on the GPU.  CPU tensors are
+        only accepted so that the host-logic tests can check the padding rule / layer wiring of the modules without a GPU
+        (plain torch ops; the level kernels themselves have no CPU form and raise)."""
         if self.weight is None:
             self._build(x_nhwc.shape[-1], x_nhwc.device)
-        if (x_nhwc.is_cuda and self.stride in (1, 2) and mfma_conv_min_pixels > 0 and x_nhwc.shape[-1] >= mfma_conv_min_cin
-                and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= mfma_conv_min_pixels):
+        if x_nhwc.is_cuda:
+            if self.stride not in (1, 2):
+                raise ValueError(f"stride {self.stride} is not supported by the HIP convolution")
             b_, h_, w_, cin_ = x_nhwc.shape
+            act = 1.0 if slope is None else slope
             wino = _use_winograd(b_, h_, w_, cin_, self.out_channels, self.stride)
             if wino:
                 wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8, cin_)     # cin_ > Cin: zero-padded input
                 fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
-                return _timed("conv", self.tag, lambda: fn(
-                    x_nhwc, wu, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope))
+                return _timed("conv", self.tag, lambda: fn(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
             wp, cpad = self._packed_weights(cin_)
             if (self.small_maps_ok and self.stride == 1 and b_ * h_ * w_ <= small_map_conv_pixels and 16 <= cin_ <= 256
                     and cin_ % 4 == 0):
                 return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(
-                    x_nhwc, wp, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope))
+                    x_nhwc, wp, self.bias, self.out_channels, cpad, act))
             return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
-                x_nhwc, wp, self.bias, self.out_channels, cpad, 1.0 if slope is None else slope, stride=self.stride))
-        x = x_nhwc.permute(0, 3, 1, 2)                   # channels-last NCHW view, no copy
-        h, w = x.shape[2:]
-        s = self.stride
-        fused = x_nhwc.is_cuda
-        bias = None if fused else self.bias
-        if s == 1:
-            y = F.conv2d(x, self.weight, bias, 1, 1)
-        else:
-            ph = max((-(-h // s) - 1) * s + 3 - h, 0)
-            pw = max((-(-w // s) - 1) * s + 3 - w, 0)
-            x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
-            y = F.conv2d(x, self.weight, bias, s, 0)
-        y = y.permute(0, 2, 3, 1)
-        if not y.is_contiguous():
-            y = y.contiguous()
-        if fused:
-            return nops.bias_act_(y, self.bias, 1.0 if slope is None else slope)
+                x_nhwc, wp, self.bias, self.out_channels, cpad, act, stride=self.stride))
+        x = x_nhwc.permute(0, 3, 1, 2)
+        (pt, pb), (pl, pr) = self.same_pads(*x.shape[2:])
+        y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), self.weight, self.bias, self.stride, 0).permute(0, 2, 3, 1).contiguous()
         return y if slope is None else F.leaky_relu(y, slope)
 
 
@@ -307,55 +318,24 @@ class FeaturePyramid(torch.nn.Module):
         self.conv_layers_s1 = torch.nn.ModuleList([_Conv3x3SameTF(n, 1, ci) for n, ci in zip(self.out_sizes, cin)])
         self.conv_layers_s2 = torch.nn.ModuleList([_Conv3x3SameTF(n, 2, n) for n in self.out_sizes])
         self.dn_layers = torch.nn.ModuleList([DomainNormalization(regularizer_weight) for _ in self.out_sizes])
-        self._padded = {}
-
-    def _padded_buffer(self, shape, device):
-        """Persistent zero-bordered buffers: the stride-1 epilogue writes the interior, the
-        border stays zero, and the stride-2 convolution reads it with padding 0."""
-        key = (tuple(shape), device)
-        buf = self._padded.get(key)
-        if buf is None:
-            buf = torch.zeros(shape, dtype=torch.float32, device=device)
-            self._padded[key] = buf
-        return buf
-
-    def _forward_gpu(self, images):
-        """MIOpen variant (only used when the hand-written MFMA convolutions are disabled): same
-        arithmetic as ``forward``; the bias / DINL / leaky_relu epilogue of the stride-1 convolution
-        writes straight into the padded input of the stride-2 one."""
-        feature_maps = as_f32(images, "images")
-        outputs = []
-        for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):
-            y = conv_s1.conv_raw(feature_maps, 1)
-            b, h, w, c = y.shape
-            (pt, pb), (pl, pr) = conv_s2.same_pads(h, w)
-            padded = self._padded_buffer((b, h + pt + pb, w + pl + pr, c), y.device)
-            if self.use_dinl and i == 0:
-                nops.bias_act_(y, conv_s1.bias, 1.0)
-                if dn_layer.scale is None:
-                    dn_layer._build(c, y.device)
-                nops.dinl_act(y, dn_layer.scale, dn_layer.bias, 0.1, out=padded, offset=(pt, pl))
-            else:
-                nops.bias_act_padded(y, conv_s1.bias, 0.1, padded, (pt, pl))
-            feature_maps = nops.bias_act_(conv_s2.conv_raw(padded, 0), conv_s2.bias, 0.1)
-            outputs.append(feature_maps)
-        return outputs
 
     def forward(self, images):
-        if isinstance(images, torch.Tensor) and images.is_cuda and (mfma_conv_min_pixels <= 0 or not mfma_conv_encoder):
-            return self._forward_gpu(images)           # MIOpen path
-        feature_maps = as_f32(images, "images")
+        """``images``: [b,H,W,3], or a ``network_ops.FrameStack`` (the frames of a sequence batch, encoded in one pass)."""
+        head_ok = (self.use_dinl and fused_encoder_head and images.is_cuda and images.shape[-1] == 3
+                   and self.conv_layers_s1[0].out_channels == 16 and self.conv_layers_s2[0].out_channels <= 32
+                   and self.conv_layers_s1[0].weight is not None)
+        if isinstance(images, nops.FrameStack):
+            feature_maps = images if head_ok else images.dense()
+        else:
+            feature_maps = as_f32(images, "images")
         outputs = []
         for i, (conv_s1, conv_s2, dn_layer) in enumerate(zip(self.conv_layers_s1, self.conv_layers_s2, self.dn_layers)):
-            if (self.use_dinl and i == 0 and fused_encoder_head and feature_maps.is_cuda and feature_maps.shape[-1] == 3
-                    and conv_s1.out_channels == 16 and conv_s2.out_channels <= 32 and conv_s1.weight is not None):
+            if i == 0 and head_ok:
                 # level 0 in two fused calls: conv 3->16 + bias + DINL statistics; stride-2 conv normalising its input on the fly
                 if dn_layer.scale is None:
                     dn_layer._build(16, feature_maps.device)
-                if getattr(conv_s1, "_hwio", None) is None or conv_s1._hwio.device != conv_s1.weight.device:
-                    conv_s1._hwio = conv_s1.weight.detach().permute(2, 3, 1, 0).contiguous()
                 wp2, cpad2 = conv_s2._packed_weights()
-                feature_maps = nops.encoder_head(feature_maps, conv_s1._hwio, conv_s1.bias, dn_layer.scale, dn_layer.bias,
+                feature_maps = nops.encoder_head(feature_maps, conv_s1._hwio_device(), conv_s1.bias, dn_layer.scale, dn_layer.bias,
                                                  wp2, conv_s2.bias, conv_s2.out_channels, cpad2, 0.1)
                 outputs.append(feature_maps)
                 continue
@@ -438,14 +418,15 @@ class DepthEstimatorLevel(torch.nn.Module):
 
     def _tail_weights(self, convs):
         """Packed weights of the fused level tail (conv 32->16, conv 16->5), built once per device."""
-        tw = getattr(self, "_tail_w", None)
-        if tw is None or tw[0].device != convs[5].weight.device:
+        def build():
             k6 = convs[5].weight.detach().permute(2, 3, 1, 0).cpu().numpy()
             k7 = convs[6].weight.detach().permute(2, 3, 1, 0).cpu().numpy()
             w6, w7 = nops.pack_refiner_tail_weights(k6, k7)
             dev = convs[5].weight.device
-            tw = self._tail_w = (torch.from_numpy(w6).to(dev), torch.from_numpy(w7).to(dev))
-        return tw
+            return torch.from_numpy(w6).to(dev), torch.from_numpy(w7).to(dev)
+        if getattr(self, "_tail_cache", None) is None:
+            self._tail_cache = _PackCache()
+        return self._tail_cache.get("tail", _stamp(convs[5].weight, convs[6].weight), build)
 
     def _vector_processing(self, f_map, out=None):
         if self.ablation.normalize_features:                                          # :179-182
@@ -487,19 +468,18 @@ class DepthEstimatorLevel(torch.nn.Module):
             nt = bool(np.asarray(nt).reshape(-1)[0])
 
         if prev_t_depth is None or nt:                                                 # :208-214
-            para_prev_l, depth_prev_l, other_prev_l, _ = nops.level_pre(prev_l_est, None, None, None, b, h, w, dev,
-                                                                        normalize=norm_job)
+            para_prev_l, depth_prev_l, other_prev_l, _ = _timed("pre", "reset", lambda: nops.level_pre(
+                prev_l_est, None, None, None, b, h, w, dev, normalize=norm_job,
+                depth_state_reset=None if self.is_training else self.depth_prev_t))         # :209, in the same launch
             if not self.is_training:
                 self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
-                self.depth_prev_t.fill_(1000.)
             return {"depth": depth_prev_l, "parallax": para_prev_l, "other": other_prev_l}
 
         r = self.dscv_range
         ncp = 2 * r + 1
         F_in = self.f_in
         F_st = F_in                                   # channel stride of the refiner input buffer
-        if (pad_refiner_input and dev.type == "cuda" and not self.is_training and F_in % 8 != 0
-                and mfma_conv_min_pixels > 0 and F_in >= mfma_conv_min_cin and b * h * w >= mfma_conv_min_pixels):   # the first layer takes the hand-written path
+        if pad_refiner_input and dev.type == "cuda" and not self.is_training and F_in % 8 != 0:
             F_st = (F_in + 7) // 8 * 8
             f_buf = nops.zeroed_workspace(("f_input", self.lvl_depth), (b, h, w, F_st), dev)
         else:
@@ -510,9 +490,9 @@ class DepthEstimatorLevel(torch.nn.Module):
         sncv_off = log_off + 1 + (4 if self.ablation.level_memory else 0)
         scale = float(2.0 ** self.lvl_mul)
         # "preprocessor" (:216-242): upsample coarser estimate, prev_d2para, log / memory features
-        para_prev_l, depth_prev_l, other_prev_l, para_prev_t = nops.level_pre(
+        para_prev_l, depth_prev_l, other_prev_l, para_prev_t = _timed("pre", self.lvl_depth, lambda: nops.level_pre(
             prev_l_est, as_f32(prev_t_depth, "prev_t_depth"), trans, camera, b, h, w, dev,
-            f_input=f_input, log_off=log_off, other_off=other_off, log_scale=scale, normalize=norm_job)
+            f_input=f_input, log_off=log_off, other_off=other_off, log_scale=scale, normalize=norm_job))
         rot_t = as_f32(rot, "rot")
         tr = as_f32(trans, "trans").reshape(b, 3)
         cf = as_f32(camera["f"], "camera['f']").reshape(b, 2)
@@ -556,8 +536,8 @@ class DepthEstimatorLevel(torch.nn.Module):
                 depth_state=self.depth_prev_t if not self.is_training else None))
         else:
             prev_out = self.disp_refiner(f_input)
-            para_curr_l, depth, other = nops.level_post(prev_out[0], rot_t, tr, {"f": cf, "c": cc}, scale,
-                                                        depth_state=self.depth_prev_t if not self.is_training else None)
+            para_curr_l, depth, other = _timed("post", self.lvl_depth, lambda: nops.level_post(
+                prev_out[0], rot_t, tr, {"f": cf, "c": cc}, scale, depth_state=self.depth_prev_t if not self.is_training else None))
         if not self.is_training:
             self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
         return {"other": other, "depth": depth, "parallax": para_curr_l}
@@ -594,13 +574,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
         # level-local intrinsics camera / 2**depth (:300-302): the same for every sequence step
         dev = camera["f"].device
         if isinstance(camera["f"], torch.Tensor) and camera["f"].is_cuda:
-            # all levels in two launches instead of 2 * n_lvls: x * 2^-k is exactly x / 2^k in float32
-            sc = getattr(self, "_cam_scales", None)
-            if sc is None or sc.device != dev or sc.shape[0] != n_lvls:
-                sc = torch.tensor([2.0 ** -(lvl + 1) for lvl in range(n_lvls)], dtype=torch.float32, device=dev).reshape(-1, 1, 1)
-                self._cam_scales = sc
-            f_all, c_all = camera["f"].unsqueeze(0) * sc, camera["c"].unsqueeze(0) * sc
-            local_cameras = [{"f": f_all[lvl], "c": c_all[lvl]} for lvl in range(n_lvls)]
+            local_cameras = nops.camera_pyramid(camera, n_lvls)       # all levels in one launch
         else:
             local_cameras = [{"f": camera["f"] / 2. ** (lvl + 1), "c": camera["c"] / 2. ** (lvl + 1)}
                              for lvl in range(n_lvls)]
@@ -674,7 +648,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
                         elif f_pyrs[seq_i] is None:      # first frame of the late encoder batch: encode all remaining frames here
                             rest = [i for i in range(seq_i, n_fr) if f_maps_pyrs[i] is None]
                             bsz = sample['RGB_im'].shape[0]
-                            tail = encoder(torch.cat([traj_samples[i]['RGB_im'] for i in rest], dim=0))
+                            tail = encoder(_stack_frames([traj_samples[i] for i in rest]))
                             for j, i in enumerate(rest):
                                 f_pyrs[i] = [lvl[j * bsz:(j + 1) * bsz] for lvl in tail]
                             enc_done = torch.cuda.Event()
@@ -756,8 +730,7 @@ class M4Depth(torch.nn.Module):
         for conv in self.modules():
             if isinstance(conv, _Conv3x3SameTF) and conv.weight is not None and conv.weight.is_cuda:
                 cin = conv.weight.shape[1]
-                if cin >= mfma_conv_min_cin or cin == 3:
-                    conv._packed_weights()
+                conv._packed_weights()
                 if conv.stride == 1 and cin >= 16 and cin % 2 == 0:
                     conv._packed_weights_winograd(16)
                     if cin % 4 == 0:
@@ -772,9 +745,13 @@ class M4Depth(torch.nn.Module):
                 c0._packed_weights_winograd(8, cin_pad)
             if len(convs) == 7 and convs[5].weight is not None and convs[5].weight.is_cuda \
                     and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16):
-                lvl._tail_w = None
                 lvl._tail_weights(convs)
         return self
+
+    def weights_stamp(self):
+        """Cheap identity/version fingerprint of every convolution parameter (see ``_stamp``)."""
+        return tuple((c.weight.data_ptr(), c.weight._version) for c in self.modules()
+                     if isinstance(c, _Conv3x3SameTF) and c.weight is not None)
 
     def load_tf_checkpoint(self, prefix_or_dir, device):
         """Weights from a TensorFlow object-based checkpoint of the reference model (callbacks.py:98-111,
@@ -826,7 +803,7 @@ class M4Depth(torch.nn.Module):
         self.step_counter += 1
         # The encoder is independent per frame (:358-360): run it ONCE on the frames stacked along
         # the batch axis (same per-sample arithmetic incl. the per-sample DINL statistics, a
-        # quarter of the launches, larger MIOpen problems), then hand each frame its slice.
+        # quarter of the launches), then hand each frame its slice.
         n_fr = len(traj_samples)
         dev = camera["f"].device
         same_shape = all(s['RGB_im'].shape == traj_samples[0]['RGB_im'].shape for s in traj_samples)
@@ -838,11 +815,11 @@ class M4Depth(torch.nn.Module):
             # the (launch-latency-bound) coarse levels of the first full frame instead of in front of them
             k = pipeline_encoder_split
             bsz = traj_samples[0]['RGB_im'].shape[0]
-            head = self.encoder(torch.cat([s['RGB_im'] for s in traj_samples[:k]], dim=0))
+            head = self.encoder(_stack_frames(traj_samples[:k]))
             f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in head] for t in range(k)] + [None] * (n_fr - k)
         elif n_fr > 1 and same_shape:
             bsz = traj_samples[0]['RGB_im'].shape[0]
-            stacked = self.encoder(torch.cat([s['RGB_im'] for s in traj_samples], dim=0))
+            stacked = self.encoder(_stack_frames(traj_samples))
             f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in stacked] for t in range(n_fr)]
         else:
             f_maps_pyrs = [self.encoder(sample['RGB_im']) for sample in traj_samples]
@@ -851,7 +828,7 @@ class M4Depth(torch.nn.Module):
         if training:
             return d_maps_pyrs
         h, w = traj_samples[-1]['RGB_im'].shape[1:3]
-        return {"depth": nops.resize_nearest(d_maps_pyrs[-1][0]["depth"], h, w)}
+        return {"depth": _timed("resize", 0, lambda: nops.resize_nearest(d_maps_pyrs[-1][0]["depth"], h, w))}
 
     # -- Keras-harness mirror (main.py:127-133) -------------------------------------------
     def compile(self, metrics=None, optimizer=None, **_unused):
@@ -880,23 +857,26 @@ class M4Depth(torch.nn.Module):
                    and isinstance(ms[2], MT.RootMeanSquaredError) and isinstance(ms[3], MT.RootMeanSquaredLogError)
                    and all(isinstance(ms[4 + i], MT.ThresholdRelError) and ms[4 + i].threshold == i + 1 for i in range(3)))
         if default:
-            vals = nops.depth_metrics(gt_raw, est_raw, max_d)
-            # the 7 Keras-Mean totals live in ONE tensor the metric objects hold views of: one in-place add per step
-            # instead of 7 (+ 7 divisions for the returned results) -- 14 launches of ~4.5 us each at batch 1
+            # the 7 Keras-Mean totals live in ONE tensor the metric objects hold views of; the metric kernel adds the batch's
+            # values to it and writes the running means (what test_step returns) in the same launch
             acc = getattr(self, "_metric_acc", None)
-            shared = (acc is not None and acc.device == vals.device and all(
+            shared = (acc is not None and acc.device == gt_raw.device and all(
                 m.total is not None and m.total.data_ptr() == acc[i].data_ptr() and m.count == ms[0].count
                 for i, m in enumerate(ms)))
-            if shared:
-                acc.add_(vals)
-                for m in ms:
-                    m.count += 1
-            elif all(m.total is None for m in ms):
-                acc = self._metric_acc = vals.clone()
+            if not shared and all(m.total is None for m in ms):
+                acc = self._metric_acc = torch.zeros(7, dtype=torch.float32, device=gt_raw.device)
+                self._metric_mean = torch.zeros(7, dtype=torch.float32, device=gt_raw.device)
                 for i, m in enumerate(ms):
                     m.total = acc[i]
-                    m.count = 1
+                    m.count = 0
+                shared = True
+            if shared:
+                nops.depth_metrics(gt_raw, est_raw, max_d, total=acc, count=ms[0].count + 1, mean=self._metric_mean)
+                for m in ms:
+                    m.count += 1
+                self._metric_mean_count = ms[0].count
             else:                                      # accumulators were touched from outside: per-metric update
+                vals = nops.depth_metrics(gt_raw, est_raw, max_d)
                 self._metric_acc = None
                 for i, m in enumerate(ms):
                     m._update(vals[i])
@@ -912,7 +892,10 @@ class M4Depth(torch.nn.Module):
         acc = getattr(self, "_metric_acc", None)
         if acc is not None and ms and all(m.total is not None and m.total.data_ptr() == acc[i].data_ptr()
                                           and m.count == ms[0].count for i, m in enumerate(ms)):
-            res = acc / float(max(ms[0].count, 1))          # one launch for all of them
+            if getattr(self, "_metric_mean_count", -1) == ms[0].count and ms[0].count > 0:
+                res = self._metric_mean                      # written by the metric kernel itself (views: valid until the next update)
+            else:
+                res = acc / float(max(ms[0].count, 1))
             return {m.name: res[i] for i, m in enumerate(ms)}
         return {m.name: m.result() for m in ms}
 
@@ -964,34 +947,40 @@ class M4Depth(torch.nn.Module):
 class GraphedSequence:
     """One ``M4Depth`` sequence forward captured in a hipGraph.
 
-    A 384x1280 / 6-level frame is ~110 kernel launches (12 encoder + 42 refiner
-    convolutions with their epilogues, 6 x 5 hand-written level kernels); at batch 1
-    the eager loop is host-launch bound (GPU ~50 % idle, profiles/).  Capturing the
-    whole sequence once and replaying it removes the host from the loop.  The capture
+    A 384x1280 / 6-level frame is ~110 kernel launches; at batch 1 the eager loop is host-launch bound (GPU ~50 % idle,
+    profiles/).  Capturing the whole sequence once and replaying it removes the host from the loop.  The capture
     is valid because the step has no host synchronisation: ``new_traj`` lives on the
     host and is baked in as the control flow of the captured sequence, every kernel of
     libm4depth_hip.so is enqueued on the capturing stream, and the level state buffers
     are persistent allocations made before the capture.
 
+    Every instance warms up and captures on ITS OWN stream: the scratch buffers of network_ops are keyed by stream, so
+    two replicas (bench.py --in-flight N) never share scratch, and everything a replay touches is allocated by the
+    eager warm-up, not inside the capture.
+
     ``runner(data)`` copies a new batch into the static input buffers (device-side
-    copies), replays, and returns the static ``depth`` output tensor."""
+    copies), replays, and returns the static ``depth`` output tensor.  The batch must have the captured shapes and
+    the captured ``new_traj`` pattern (it is control flow here); anything else raises."""
 
     def __init__(self, model, example, warmup=2):
         self.model = model
-        self.new_traj = example["new_traj"].clone() if isinstance(example["new_traj"], torch.Tensor) else example["new_traj"]
+        nt = example["new_traj"]
+        self.new_traj = nt.clone() if isinstance(nt, torch.Tensor) else torch.as_tensor(np.asarray(nt))
         self.static = {k: example[k].clone() for k in ("RGB_im", "rot", "trans")}
         self.camera = {k: v.clone() for k, v in example["camera"].items()}
         self.seq_len = self.static["RGB_im"].shape[1]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
+        model.prepack()
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(warmup, 1)):
                 self._run()
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=self.stream):
             self.depth = self._run()
+        self.weights_stamp = model.weights_stamp()
 
     def _samples(self):
         nt = torch.unbind(self.new_traj, dim=1)
@@ -1001,133 +990,29 @@ class GraphedSequence:
     def _run(self):
         return self.model([self._samples(), self.camera])["depth"]
 
+    def _check(self, name, got, want):
+        if tuple(got.shape) != tuple(want.shape):
+            raise ValueError(f"GraphedSequence: {name} has shape {tuple(got.shape)}, the graph was captured for {tuple(want.shape)}")
+
     def __call__(self, data=None):
         if data is not None:
+            nt = data.get("new_traj") if isinstance(data, dict) else None
+            if nt is not None:
+                nt = nt if isinstance(nt, torch.Tensor) else torch.as_tensor(np.asarray(nt))
+                # only new_traj[0, t] steers the control flow (m4depth_network.py:207-208), so that is what must match
+                if tuple(nt.shape) != tuple(self.new_traj.shape) or not torch.equal(nt[0].cpu(), self.new_traj[0].cpu()):
+                    raise ValueError("GraphedSequence: the batch's new_traj pattern differs from the captured control flow")
             for k in self.static:
+                self._check(k, data[k], self.static[k])
                 if data[k].data_ptr() != self.static[k].data_ptr():
                     self.static[k].copy_(data[k], non_blocking=True)
             for k in self.camera:
+                self._check(f"camera[{k}]", data["camera"][k], self.camera[k])
                 if data["camera"][k].data_ptr() != self.camera[k].data_ptr():
                     self.camera[k].copy_(data["camera"][k], non_blocking=True)
+        stamp = self.model.weights_stamp()
+        if stamp != self.weights_stamp:                 # the parameters changed (optimizer step, load_state_dict): refresh the
+            self.model.prepack()                        # packed copies in place -- the graph reads the same addresses
+            self.weights_stamp = stamp
         self.graph.replay()
-        return self.depth
-
-
-class TaskGraphSequence:
-    """A sequence forward as ONE hipGraph PER TASK -- the batched encoder, every (frame, level) of the decoder, the
-    final upsample -- replayed by the host on one real HIP stream per frame, ordered by events.
-
-    Why not one big graph (``GraphedSequence``): captured from several streams it has the right dependencies, but
-    ROCm 7.2's graph executor starts the next frame's coarse levels only when the current frame reaches level 1
-    (profiles/r01_timeline_b1_pipelined.txt), so most of the possible overlap is lost.  With the tasks as separate
-    graphs the (frame, level) wavefront runs on real streams: level l of frame t+1 starts the moment level l of
-    frame t has signalled its event, and later frames' streams get a higher priority so that their small kernels
-    slip into the workgroup slots a chip-filling level-1 convolution of the frame before frees.  Per step the host
-    issues ~30 graph launches and ~50 event operations (< 0.5 ms) instead of ~700 kernel launches.
-
-    Streams share nothing but the level state buffers (event ordered); every frame-stream captures into its own
-    memory pool, so tasks that run concurrently never alias scratch memory."""
-
-    def __init__(self, model, example, warmup=2, use_priorities=False):
-        # MEASURED (tools/debug_taskgraph.py, batch 1): 6.45 ms/step, the same as the single multi-stream graph
-        # (6.25 ms) -- the per-task event timeline shows the wavefront overlapping exactly as designed, the step is
-        # simply throughput-bound by then.  With stream priorities it is 10.7 ms/step (high-priority queues starve the
-        # chip-filling convolutions), hence use_priorities=False.  Kept as the instrument that produced that timeline.
-        self.model = model
-        self.new_traj = example["new_traj"].clone() if isinstance(example["new_traj"], torch.Tensor) else example["new_traj"]
-        self.static = {k: example[k].clone() for k in ("RGB_im", "rot", "trans")}
-        self.camera = {k: v.clone() for k, v in example["camera"].items()}
-        T = self.seq_len = self.static["RGB_im"].shape[1]
-        pyr = model.d_estimator
-        L = self.n_lvls = len(pyr.levels)
-        if pyr.is_training:
-            raise ValueError("TaskGraphSequence replays the inference path")
-        # later frames = higher priority (numerically lower); clamp to what the device offers
-        def make_stream(t):
-            if use_priorities:
-                for prio in (min(0, 1 - t), -1 if t >= 2 else 0, 0):
-                    try:
-                        return torch.cuda.Stream(priority=prio)
-                    except Exception:
-                        continue
-            return torch.cuda.Stream()
-        self.streams = [make_stream(t) for t in range(T)]
-        self.main = torch.cuda.Stream()
-        pyr._streams = self.streams                      # the eager warm-up allocates per-stream scratch on the same streams
-        self.main.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.main):
-            for _ in range(warmup):
-                model([self._samples(), self.camera])
-        torch.cuda.synchronize()
-
-        nt = torch.unbind(self.new_traj, dim=1) if isinstance(self.new_traj, torch.Tensor) else list(self.new_traj.T)
-        bsz = self.static["RGB_im"].shape[0]
-        # -- task 0: encoder, batched over the frames, + the level-local intrinsics
-        self.g_enc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_enc, stream=self.main):
-            stacked = model.encoder(torch.cat([self.static["RGB_im"][:, t] for t in range(T)], dim=0))
-            self.f_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in stacked] for t in range(T)]
-            self.cams = [{"f": self.camera["f"] / 2. ** (lvl + 1), "c": self.camera["c"] / 2. ** (lvl + 1)} for lvl in range(L)]
-        # -- one task per (frame, level), captured in wavefront order on the frame's stream and pool
-        pools = [torch.cuda.graph_pool_handle() for _ in range(T)]
-        self.tasks = {}
-        ests = [None] * T
-        for diag in range(T + L - 1):
-            for t in range(max(0, diag - L + 1), min(T, diag + 1)):
-                l = diag - t
-                lvl = L - 1 - l
-                g = torch.cuda.CUDAGraph()
-                prev = None if ests[t] is None else dict(ests[t][-1])
-                with torch.cuda.graph(g, pool=pools[t], stream=self.streams[t]):
-                    est = pyr.levels[lvl](self.f_pyrs[t][lvl], prev, self.static["rot"][:, t], self.static["trans"][:, t],
-                                          self.cams[lvl], nt[t])
-                ests[t] = [est] if ests[t] is None else ests[t] + [est]
-                self.tasks[(t, lvl)] = g
-        self.estimates = [e[::-1] for e in ests]
-        h, w = self.static["RGB_im"].shape[2:4]
-        self.g_out = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_out, stream=self.main):
-            self.depth = nops.resize_nearest(self.estimates[-1][0]["depth"], h, w)
-        self.ev_enc = torch.cuda.Event()
-        self.ev = {k: torch.cuda.Event() for k in self.tasks}
-        model.last_estimates = self.estimates
-        torch.cuda.synchronize()
-
-    def _samples(self):
-        nt = torch.unbind(self.new_traj, dim=1) if isinstance(self.new_traj, torch.Tensor) else list(self.new_traj.T)
-        return [{"RGB_im": self.static["RGB_im"][:, t], "rot": self.static["rot"][:, t],
-                 "trans": self.static["trans"][:, t], "new_traj": nt[t]} for t in range(self.seq_len)]
-
-    def __call__(self, data=None):
-        caller = torch.cuda.current_stream()
-        main = self.main
-        main.wait_stream(caller)
-        with torch.cuda.stream(main):
-            if data is not None:
-                for k in self.static:
-                    if data[k].data_ptr() != self.static[k].data_ptr():
-                        self.static[k].copy_(data[k], non_blocking=True)
-                for k in self.camera:
-                    if data["camera"][k].data_ptr() != self.camera[k].data_ptr():
-                        self.camera[k].copy_(data["camera"][k], non_blocking=True)
-            self.g_enc.replay()
-            self.ev_enc.record(main)
-        T, L = self.seq_len, self.n_lvls
-        for st in self.streams:
-            st.wait_event(self.ev_enc)
-        for diag in range(T + L - 1):
-            for t in range(max(0, diag - L + 1), min(T, diag + 1)):
-                lvl = L - 1 - (diag - t)
-                st = self.streams[t]
-                with torch.cuda.stream(st):
-                    if t > 0:
-                        st.wait_event(self.ev[(t - 1, lvl)])
-                    self.tasks[(t, lvl)].replay()
-                    self.ev[(t, lvl)].record(st)
-        for t in range(T):
-            main.wait_event(self.ev[(t, 0)])              # join: the finest level is every stream's last task
-        with torch.cuda.stream(main):
-            self.g_out.replay()
-        caller.wait_stream(main)
-        self.model.step_counter += 1
         return self.depth

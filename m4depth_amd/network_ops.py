@@ -3,6 +3,8 @@ exposed as tensor functions.  All dispatch to libm4depth_hip.so.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from ._lib import lib, dptr, stream_ptr, check, as_f32
@@ -43,12 +45,13 @@ def resize_nearest(x, out_h, out_w):
 
 
 def level_pre(prev_l_est, depth_prev_t, trans, camera, b, h, w, device, f_input=None, log_off=0,
-              other_off=-1, log_scale=1.0, normalize=None):
+              other_off=-1, log_scale=1.0, normalize=None, depth_state_reset=None):
     """Fused upsample of the coarser level's estimate (+ prev_d2para of the
     temporal depth state, + the log-parallax / level-memory features written
     straight into ``f_input``).  Returns (para_prev_l, depth_prev_l,
     other_prev_l, para_prev_t or None).  ``normalize`` = (raw features [b,h,w,C], cuts, out): the per-cut
-    normalisation of the level's current features rides in the same launch (m4d_level_pre_normalize)."""
+    normalisation of the level's current features rides in the same launch (m4d_level_pre_normalize).
+    ``depth_state_reset`` [b,h,w,1] (reset branch, m4depth_network.py:209) is set to 1000 in the same pass."""
     para = torch.empty((b, h, w, 1), dtype=torch.float32, device=device)
     depth = torch.empty_like(para)
     other = torch.empty((b, h, w, 4), dtype=torch.float32, device=device)
@@ -73,13 +76,13 @@ def level_pre(prev_l_est, depth_prev_t, trans, camera, b, h, w, device, f_input=
         check(lib.m4d_level_pre_normalize(dptr(pd), dptr(pp), dptr(po), ph, pw, dptr(depth_prev_t, "depth_prev_t"), dptr(tr),
                                           dptr(f), dptr(c), b, h, w, dptr(para), dptr(depth), dptr(other), dptr(para_t),
                                           dptr(f_input, "f_input"), f_stride, int(log_off), int(other_off), float(log_scale),
-                                          dptr(raw, "curr_f_maps"), int(raw.shape[-1]), int(cuts), dptr(nout, "normalised features"),
+                                          dptr(depth_state_reset, "depth_state_reset"), dptr(raw, "curr_f_maps"), int(raw.shape[-1]), int(cuts), dptr(nout, "normalised features"),
                                           stream_ptr()), "m4d_level_pre_normalize")
         return para, depth, other, para_t
     check(lib.m4d_level_pre(dptr(pd), dptr(pp), dptr(po), ph, pw, dptr(depth_prev_t, "depth_prev_t"), dptr(tr),
                             dptr(f), dptr(c), b, h, w, dptr(para), dptr(depth), dptr(other), dptr(para_t),
                             dptr(f_input, "f_input"), f_stride, int(log_off), int(other_off), float(log_scale),
-                            stream_ptr()), "m4d_level_pre")
+                            dptr(depth_state_reset, "depth_state_reset"), stream_ptr()), "m4d_level_pre")
     return para, depth, other, para_t
 
 
@@ -167,9 +170,10 @@ def bias_act_padded(x, bias, slope, out, offset=(0, 0)):
     return out
 
 
-def depth_metrics(gt, est, max_d=80.0):
+def depth_metrics(gt, est, max_d=80.0, total=None, count=0, mean=None):
     """The 7 metrics of metrics.py for one batch, one pass: returns a [7] device tensor
-    (AbsRel, SqRel, RMSE, RMSE_log, Delta1, Delta2, Delta3); clipping as in test_step."""
+    (AbsRel, SqRel, RMSE, RMSE_log, Delta1, Delta2, Delta3); clipping as in test_step.
+    ``total`` [7] (Keras-Mean totals) is incremented and ``mean`` [7] = total / count written in the same launch."""
     gt = as_f32(gt, "gt")
     est = as_f32(est, "est")
     if gt.numel() != est.numel():
@@ -177,7 +181,7 @@ def depth_metrics(gt, est, max_d=80.0):
     ws = _workspace("metrics", int(lib.m4d_metrics_workspace_bytes()), gt.device)
     out = torch.empty(7, dtype=torch.float32, device=gt.device)
     check(lib.m4d_depth_metrics(dptr(gt, "gt"), dptr(est, "est"), gt.numel(), float(max_d), dptr(ws), dptr(out),
-                                stream_ptr()), "m4d_depth_metrics")
+                                dptr(total, "total"), float(count), dptr(mean, "mean"), stream_ptr()), "m4d_depth_metrics")
     return out
 
 
@@ -275,23 +279,65 @@ def conv3x3_wino2_bias_act(x, wu8, bias, cout, cout_pad, slope=0.1):
     return out
 
 
+class FrameStack:
+    """``frames`` [bsz,T',H,W,3]-shaped VIEW into a sequence batch [bsz,T,H,W,3] (frames t0..t1 of every sequence): what
+    M4Depth.call hands the encoder so that all frames are encoded in one launch, frame-major (image t*bsz + i), read in
+    place.  Only the fused encoder head understands it; ``dense()`` materialises the stacked batch for any other layer."""
+
+    def __init__(self, frames):
+        if frames.dim() != 5 or frames.dtype != torch.float32 or not frames[0, 0].is_contiguous():
+            raise ValueError("FrameStack: expected a float32 [b,T,H,W,3] view with dense frames")
+        self.frames = frames
+
+    @property
+    def shape(self):
+        bsz, t, h, w, c = self.frames.shape
+        return (bsz * t, h, w, c)
+
+    @property
+    def is_cuda(self):
+        return self.frames.is_cuda
+
+    @property
+    def device(self):
+        return self.frames.device
+
+    def dense(self):
+        bsz, t, h, w, c = self.frames.shape
+        return self.frames.transpose(0, 1).reshape(bsz * t, h, w, c)
+
+
 def encoder_head(images, w_hwio, bias1, dn_scale, dn_bias, wp2, bias2, cout2, cout2_pad, slope=0.1):
     """Encoder level 0 with DINL (m4depth_network.py:79-87) in two fused calls: conv3x3(3->16) + bias + DINL statistics,
-    then the stride-2 convolution reading the raw map and normalising it on the fly.  Returns [b, h/2, w/2, cout2]."""
-    images = as_f32(images, "images")
-    b, h, w, c3 = images.shape
+    then the stride-2 convolution reading the raw map and normalising it on the fly.  Returns [b, h/2, w/2, cout2].
+    ``images``: a dense [b,h,w,3] tensor or a ``FrameStack``."""
+    if isinstance(images, FrameStack):
+        fr = images.frames
+        bsz = fr.shape[0]
+        stride_b, stride_t = fr.stride(0), fr.stride(1)
+        b, h, w, c3 = images.shape
+        img_ptr = ctypes.c_void_p(fr.data_ptr())
+        if not fr.is_cuda:
+            raise RuntimeError("images: m4depth_amd ops run on the MI355X only; there is no CPU fallback")
+        images_dev = fr.device
+    else:
+        images = as_f32(images, "images")
+        b, h, w, c3 = images.shape
+        bsz, stride_b, stride_t = b, h * w * c3, 0
+        img_ptr = dptr(images, "images")
+        images_dev = images.device
     if c3 != 3:
         raise ValueError(f"encoder_head expects RGB images, got {c3} channels")
     C = bias1.numel()
-    ws = _workspace("dinl", 4 * int(lib.m4d_dinl_workspace_floats(b, C)), images.device)
-    raw = torch.empty((b, h, w, C), dtype=torch.float32, device=images.device)
-    check(lib.m4d_enc_head_fwd(dptr(images, "images"), dptr(w_hwio, "w_hwio"), dptr(bias1, "bias"), b, h, w, C, dptr(ws),
-                               dptr(raw), stream_ptr()), "m4d_enc_head_fwd")
+    ws = _workspace("dinl", 4 * int(lib.m4d_dinl_workspace_floats(b, C)), images_dev)
+    raw = torch.empty((b, h, w, C), dtype=torch.float32, device=images_dev)
+    check(lib.m4d_enc_head_fwd(img_ptr, int(bsz), int(stride_b), int(stride_t), dptr(w_hwio, "w_hwio"), dptr(bias1, "bias"),
+                               b, h, w, C, dptr(ws), dptr(raw), stream_ptr()), "m4d_enc_head_fwd")
     total = int(lib.m4d_dinl_workspace_floats(b, C))     # [partials | mean b*C | var b*C]
     mean = ws[total - 2 * b * C: total - b * C]
     var = ws[total - b * C: total]
     oh, ow = -(-h // 2), -(-w // 2)
-    out = torch.empty((b, oh, ow, cout2), dtype=torch.float32, device=images.device)
+    out = torch.empty((b, oh, ow, cout2), dtype=torch.float32, device=images_dev)
     check(lib.m4d_conv3x3s2_dinl_bias_act(dptr(raw), dptr(mean), dptr(var), dptr(dn_scale.reshape(-1), "dn_scale"),
                                           dptr(dn_bias.reshape(-1), "dn_bias"), float(slope), dptr(wp2, "wp"), dptr(bias2, "bias"),
                                           b, h, w, int(cout2), int(cout2_pad), float(slope), dptr(out), stream_ptr()),
@@ -330,3 +376,15 @@ def refiner_tail(x32, w6p, b6, w7p, b7, rot, trans, camera, scale, depth_state=N
                                dptr(para), dptr(depth), dptr(other), dptr(depth_state, "depth_state"), stream_ptr()),
           "m4d_refiner_tail")
     return para, depth, other
+
+
+def camera_pyramid(camera, levels):
+    """Level-local intrinsics of DepthEstimatorPyramid.call (m4depth_network.py:300-302): a list (finest level first) of
+    {"f": [b,2], "c": [b,2]} = camera / 2^(l+1), all levels from one launch."""
+    f = as_f32(camera["f"], "camera['f']")
+    c = as_f32(camera["c"], "camera['c']")
+    b = f.shape[0]
+    out = torch.empty((2, levels, b, 2), dtype=torch.float32, device=f.device)
+    check(lib.m4d_camera_pyramid(dptr(f.reshape(b, 2), "camera['f']"), dptr(c.reshape(b, 2), "camera['c']"), b, int(levels),
+                                 dptr(out[0]), dptr(out[1]), stream_ptr()), "m4d_camera_pyramid")
+    return [{"f": out[0, l], "c": out[1, l]} for l in range(levels)]

@@ -22,10 +22,29 @@ channels are sequential in channel order (c = 0, 1, 2, ...), in float32.
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 
-F32 = np.float32
+F32 = np.float32          # the working precision; ``float64_reference()`` rebinds it to float64
 F16 = np.float16
+
+
+@contextlib.contextmanager
+def float64_reference():
+    """Evaluate every function of this module in float64 instead of float32 -- same operations, same order, same
+    discrete steps (floor / clamp of the bilinear cells, the float16 casts, product and mean rounding of the DSCV,
+    :276-277, which are part of the algorithm, not of the working precision).  This is the higher-precision "truth" the
+    tolerance tests measure BOTH the float32 oracle and the GPU against: |gpu - f64| vs |f32 oracle - f64| says whether
+    a disagreement between the two float32 evaluations is rounding noise or an error.  Not re-entrant, not thread-safe
+    (test infrastructure)."""
+    global F32
+    old = F32
+    F32 = np.float64
+    try:
+        yield
+    finally:
+        F32 = old
 
 __all__ = [
     "get_rot_mat", "get_coords_2d", "motion_factors", "parallax2depth", "depth2parallax",

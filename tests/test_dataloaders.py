@@ -50,6 +50,40 @@ def test_train_plan_cuts_shuffles_and_drops_remainders(tmp_path):
         loader.get_dataset("train", dl.DataloaderParameters({"midair": db}, rec, None, 3, True), device="cpu")
 
 
+def test_sharded_plans_give_every_rank_the_same_number_of_disjoint_batches(tmp_path):
+    """Data-parallel runs (main.py --mode=train under torchrun): 7 chunks, per-rank batch 1, world 2 -> 3 global batches
+    (the odd chunk is dropped on EVERY rank: a rank with one batch more would deadlock the per-step gradient all-reduce),
+    the ranks' sequences are disjoint, their union is what one rank with batch 2 would have drawn, and a fixed seed
+    reproduces the shuffle."""
+    loader, dl, db, rec = _loader("midair", tmp_path, n_traj=1, n_frames=36)
+    settings = dl.DataloaderParameters({"midair": db}, rec, 5, 3, True)
+
+    def plan(batch_size, shard, seed=11):
+        ld = dl.get_loader("midair")
+        ds = ld.get_dataset("train", settings, batch_size=batch_size, out_size=[32, 32], device="cpu", seed=seed, shard=shard)
+        return ds.cardinality(), [[(s[0]["camera_l"], s[0]["id"]) for s in b] for b in ds.plan_fn()]
+
+    n0, p0 = plan(1, (0, 2))
+    n1, p1 = plan(1, (1, 2))
+    ng, pg = plan(2, (0, 1))
+    assert n0 == n1 == ng == 3 and len(p0) == len(p1) == 3
+    assert all(a + b == g for a, b, g in zip(p0, p1, pg))                  # rank r = slice r of the global batch
+    assert not set(sum(p0, [])) & set(sum(p1, []))
+    assert plan(1, (0, 2)) == (n0, p0) and plan(1, (0, 2), seed=12)[1] != p0
+    # eval on subsequences: contiguous chunks, interleaved by global batch
+    ld = dl.get_loader("midair")
+    es = dl.DataloaderParameters({"midair": db}, rec, 4, 4, False)
+    e0 = list(ld.get_dataset("eval", es, batch_size=2, device="cpu", shard=(0, 2)).plan_fn())
+    e1 = list(dl.get_loader("midair").get_dataset("eval", es, batch_size=2, device="cpu", shard=(1, 2)).plan_fn())
+    assert len(e0) == len(e1) == 2                                         # 9 chunks // (2 * 2)
+    assert [b[0][0]["id"] for b in e0] == [0, 16] and [b[0][0]["id"] for b in e1] == [8, 24]
+    with pytest.raises(ValueError):
+        dl.get_loader("midair").get_dataset("eval", dl.DataloaderParameters({"midair": db}, rec, None, 4, False),
+                                            device="cpu", shard=(0, 2))   # streaming cannot be sharded
+    # the plan thread and the augmentation draw from independent generators
+    assert ld.plan_rng is not ld.rng
+
+
 def test_eval_plans(tmp_path):
     loader, dl, db, rec = _loader("kitti-raw", tmp_path, n_traj=2, n_frames=7)
     ds = loader.get_dataset("eval", dl.DataloaderParameters({"kitti-raw": db}, rec, None, 4, False), batch_size=1, device="cpu")

@@ -30,7 +30,8 @@ def _worker(rank, world, port, q):
     gathered = D.all_gather_metric_states(mets, dev)
     res = D.reduce_metric_states(gathered)
     tmax = D.max_over_ranks(float(r + 1), dev)
-    q.put((r, tuple(gathered.shape), res.tolist(), tmax))
+    per_rank = D.all_gather_floats(10.0 * (r + 1), dev)
+    q.put((r, tuple(gathered.shape), res.tolist(), tmax, per_rank))
     torch.distributed.destroy_process_group()
 
 
@@ -57,10 +58,11 @@ def test_two_rank_metric_allgather():
         for m in mets:
             m.update_state(gt[i], est[i])
     ref = np.array([float(m.result()) for m in mets])
-    for r, shape, res, tmax in outs:
+    for r, shape, res, tmax, per_rank in outs:
         assert shape == (2, 7, 2)
         assert np.allclose(res, ref, rtol=1e-6)
         assert tmax == 2.0
+        assert per_rank == [10.0, 20.0]                      # bench.py's per-rank report
 
 
 def _grad_worker(rank, world, port, q):

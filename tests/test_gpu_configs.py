@@ -1,0 +1,302 @@
+"""Configurations and code paths the round-1 suite never executed on the GPU, each against the CPU oracle:
+
+  * every ``M4depthAblationParameters`` flag off (one at a time, and all off): the flags change the ``f_input``
+    offsets / strides, the fused level-front conditions, the padded refiner input and the encoder head
+    (m4depth_network.py:21-22, 79-83, 173-182, 226-240);
+  * BASELINE.json configs[2] (batch 32): at batch >= 8 the Winograd kernels take levels 3+, the 3-workgroup/CU
+    convolution and the tile SNCV / wave DSCV kernels run on levels the batch-1 tests only reach through the small-map
+    kernels -- a reduced-size run against the oracle + the 384x1280 property run;
+  * the float64 evaluation of the oracle as the third party between the GPU and the float32 oracle: how far each float32
+    evaluation is from the higher-precision truth (the tolerance argument of DESIGN.md section 2);
+  * stale packed weights: inference after an in-place parameter update must use the new weights.
+
+Tolerances: as in test_gpu_model.py (parallax 1e-4 relative everywhere, depth 1e-4 of its operands' magnitude everywhere
+and 1e-4 relative on >= 98 % of the pixels); replicas of one sequence inside a batch: bit-identical.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import m4depth_oracle as O
+from m4depth_amd import synthetic as S
+from helpers import F, camera_np, motion_np, to_dev, npy, assert_bits_equal, rel_err
+from test_gpu_model import check_depth_and_parallax
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = ("DINL", "SNCV", "time_recurr", "normalize_features", "subdivide_features", "level_memory")
+ABLATIONS = [{f: False} for f in FLAGS] + [{f: False for f in FLAGS}]
+IDS = ["no_" + f for f in FLAGS] + ["all_off"]
+
+
+def _model(dev, L, weights, ablation=None, rd=4, rs=3):
+    import m4depth_amd as M
+    ab = M.M4depthAblationParameters(**ablation) if ablation else None
+    model = M.M4Depth(nbre_levels=L, ablation_settings=ab, dscv_range=rd, sncv_range=rs)
+    model.load_numpy_weights(weights, dev)
+    return model
+
+
+def _cam_l(cam, l):
+    return {"f": cam["f"] / F(2.0 ** (l + 1)), "c": cam["c"] / F(2.0 ** (l + 1))}
+
+
+# ------------------------------------------------------------------------------- ablations
+@pytest.mark.parametrize("ablation", ABLATIONS, ids=IDS)
+def test_model_ablation_vs_oracle(dev, ablation):
+    """BASELINE config-1 size (128x256, 3 levels), default search ranges, one reset + two full frames, batch 2."""
+    L, H, Wd, T, b = 3, 128, 256, 3, 2
+    W = S.init_weights(L, seed=42, ablation=ablation)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=77)
+    model = _model(dev, L, W, ablation)
+    out = model([to_dev(samples, dev), to_dev(cam, dev)])
+    omodel = O.M4Depth(W, L, ablation=ablation)
+    oout, oseq = omodel(samples, cam)
+    ab = dict(O.DEFAULT_ABLATION, **ablation)
+    for l in range(L):
+        k = 2 ** ((l + 1) // 2) if ab["subdivide_features"] else 1
+        fo, fg = omodel.levels[l].last_f_input, npy(model.d_estimator.levels[l].last_f_input)
+        assert fg.shape == fo.shape and fo.shape[-1] == S.f_input_channels(k, 4, 3, ab["level_memory"], ab["SNCV"], ab["time_recurr"])
+        # the refiner input: cost volumes of features that differ from the oracle's in the last bits (convolution order)
+        assert np.isfinite(fg).all()
+        assert np.percentile(np.abs(fg - fo), 99.9) < 2e-4, f"level {l}: f_input"
+        est = model.last_estimates[-1][l]
+        check_depth_and_parallax(npy(est["depth"]), npy(est["parallax"]), oseq[-1][l]["depth"], oseq[-1][l]["parallax"],
+                                 samples[-1]["rot"], samples[-1]["trans"], _cam_l(cam, l), f"{ablation} level {l}", frac_ok=0.98)
+    re = rel_err(npy(out["depth"]), oout["depth"], 1e-9)
+    assert np.median(re) < 1e-5 and np.mean(re < 1e-4) > 0.98
+
+
+@pytest.mark.parametrize("ablation", ABLATIONS, ids=IDS)
+@pytest.mark.parametrize("depth,h,w", [(2, 16, 24), (4, 8, 12), (6, 6, 10)])
+def test_level_step_ablation_teacher_forced(dev, ablation, depth, h, w):
+    """One DepthEstimatorLevel step with identical inputs on both sides: the assembled refiner input is bit-exact on
+    every channel but the two logs, whatever blocks the flags remove; level 6 without subdivision is one 192-channel cut."""
+    import m4depth_amd as M
+    rng = np.random.default_rng(300 + depth)
+    b = 2
+    C = S.ENCODER_CHANNELS[depth - 1]
+    W = S.init_weights(6, seed=3, ablation=ablation)
+    ol = O.DepthEstimatorLevel(W, depth, ablation=ablation)
+    settings = {"nbre_lvls": 6, "is_training": False, "ablation": M.M4depthAblationParameters(**ablation)}
+    gl = M.DepthEstimatorLevel(settings, depth)
+    convs = list(gl.disp_refiner.prep_conv_layers) + list(gl.disp_refiner.est_d_conv_layers)
+    for i, cv in enumerate(convs):
+        cv.load_hwio(W[f"lvl.{depth}.conv.{i}.kernel"], W[f"lvl.{depth}.conv.{i}.bias"], dev)
+    cam = camera_np(b, h, w)
+    prev = None
+    if depth < 6:
+        prev = {"depth": (1 + 50 * rng.random([b, h // 2, w // 2, 1])).astype(F),
+                "parallax": (0.2 + 2 * rng.random([b, h // 2, w // 2, 1])).astype(F),
+                "other": rng.standard_normal([b, h // 2, w // 2, 4]).astype(F)}
+    ab = dict(O.DEFAULT_ABLATION, **ablation)
+    for step in range(3):
+        rot, trans = motion_np(rng, b, t_scale=(3.0, 3.0, 1.0))
+        f = rng.standard_normal([b, h, w, C]).astype(F)
+        if not ab["normalize_features"]:
+            f = (f / 4).astype(F)                  # keep un-normalised correlations in the float16 range
+        nt = np.full([b], step == 0)
+        eo = ol(f, prev, rot, trans, cam, nt)
+        eg = gl(to_dev(f, dev), to_dev(prev, dev), to_dev(rot, dev), to_dev(trans, dev), to_dev(cam, dev), nt)
+        assert_bits_equal(npy(gl.prev_f_maps), ol.prev_f_maps, "state: (normalised) features")
+        if step == 0:
+            for key in ("depth", "parallax", "other"):
+                assert_bits_equal(npy(eg[key]), eo[key], f"reset branch {key}")
+            assert torch.all(gl.depth_prev_t == 1000.0)
+            continue
+        fo, fg = ol.last_f_input, npy(gl.last_f_input)
+        assert fo.shape == fg.shape
+        k = ol.nbre_cuts()
+        logs = [9 * k] + ([fo.shape[-1] - 1] if ab["time_recurr"] else [])
+        exact = [c for c in range(fo.shape[-1]) if c not in logs]
+        assert_bits_equal(fg[..., exact], fo[..., exact], "f_input (cv | other | sncv)")
+        assert np.max(rel_err(fg[..., logs], fo[..., logs], 1e-3)) < 2e-6
+        check_depth_and_parallax(npy(eg["depth"]), npy(eg["parallax"]), eo["depth"], eo["parallax"], rot, trans, cam,
+                                 f"{ablation} level {depth} step {step}", frac_ok=0.97)
+        gl.depth_prev_t.copy_(to_dev(ol.depth_prev_t, dev))
+
+
+# ------------------------------------------------------------------------------- configs[2]: batch 32
+def _tiled(samples, cam, reps):
+    ts = [{k: np.concatenate([v] * reps, axis=0) for k, v in s.items()} for s in samples]
+    return ts, {k: np.concatenate([v] * reps, axis=0) for k, v in cam.items()}
+
+
+def test_batch32_reduced_size_vs_oracle(dev):
+    """configs[2]'s batch (32 = 2 unique sequences x 16) on a 192x320 / 6-level pyramid: per level the maps have as many
+    pixels as BASELINE's 384x1280 pyramid has at batch 2-8, so the large-grid choices are taken (Winograd kernels 2/4 on
+    levels 1-3, the 3-workgroup/CU direct convolution, tile SNCV, wave DSCV instead of the small-map kernels on levels
+    3-5).  Replicas must be bit-identical to their originals; the two originals are checked against the oracle."""
+    from m4depth_amd import network as net
+    L, H, Wd, T, uniq, reps = 6, 192, 320, 3, 2, 16
+    W = S.init_weights(L, seed=42)
+    samples, cam = S.make_sequence(uniq, T, H, Wd, seed=1236)
+    ts, tcam = _tiled(samples, cam, reps)
+    b = uniq * reps
+    # the dispatch this test is about (guards against the thresholds drifting away from it)
+    assert net._use_winograd(b, H >> 3, Wd >> 3, 128, 128, 1) != 0           # level 3 on Winograd at this batch
+    assert b * (H >> 4) * (Wd >> 4) > 6000                                   # level 4: no small-map / merged cost volumes
+    assert b * (H >> 5) * (Wd >> 5) > net.small_map_conv_pixels              # level 5: not the one-launch small-map conv
+    model = _model(dev, L, W)
+    out = model([to_dev(ts, dev), to_dev(tcam, dev)])["depth"]
+    assert out.shape == (b, H, Wd, 1) and torch.isfinite(out).all()
+    for l in range(L):
+        est = model.last_estimates[-1][l]
+        for key in ("depth", "parallax", "other"):
+            v = est[key]
+            assert torch.equal(v, v[:uniq].repeat(reps, 1, 1, 1)), f"level {l} {key}: replicas differ"
+    oout, oseq = O.M4Depth(W, L)(samples, cam)
+    for l in range(L):
+        est = model.last_estimates[-1][l]
+        check_depth_and_parallax(npy(est["depth"][:uniq]), npy(est["parallax"][:uniq]), oseq[-1][l]["depth"],
+                                 oseq[-1][l]["parallax"], samples[-1]["rot"], samples[-1]["trans"], _cam_l(cam, l),
+                                 f"batch 32 level {l}", frac_ok=0.98)
+    re = rel_err(npy(out[:uniq]), oout["depth"], 1e-9)
+    assert np.median(re) < 1e-5 and np.mean(re < 1e-4) > 0.98
+    # the same two sequences alone (batch 2: other kernels on most levels) agree with their batch-32 run to rounding
+    model2 = _model(dev, L, W)
+    out2 = model2([to_dev(samples, dev), to_dev(cam, dev)])["depth"]
+    rp = rel_err(npy(model2.last_estimates[-1][0]["parallax"]), npy(model.last_estimates[-1][0]["parallax"][:uniq]), 1e-12)
+    assert rp.max() < 1e-4 and np.median(rp) < 2e-6, (rp.max(), np.median(rp))
+    assert torch.isfinite(out2).all()
+
+
+def test_batch32_fullsize_properties(dev):
+    """BASELINE configs[2] itself: 384x1280, 6 levels, batch 32 (2 unique sequences x 16).  No oracle run at this size:
+    size-independent properties -- replicas bit-identical, depth <-> parallax tied by parallax2depth bit for bit, the
+    parallax range of exp(clip), nearest x2 output, determinism, and equality with the batch-2 run of the same sequences
+    on the levels whose kernels do not depend on the batch size."""
+    import m4depth_amd as M
+    L, H, Wd, T, uniq, reps = 6, 384, 1280, 3, 2, 16
+    W = S.init_weights(L, seed=21)
+    samples, cam = S.make_sequence(uniq, T, H, Wd, seed=78)
+    ts, tcam = _tiled(samples, cam, reps)
+    b = uniq * reps
+    model = _model(dev, L, W)
+    ds, dc = to_dev(ts, dev), to_dev(tcam, dev)
+    out = model([ds, dc])["depth"].clone()
+    assert out.shape == (b, H, Wd, 1) and torch.isfinite(out).all()
+    assert torch.equal(out, out[:uniq].repeat(reps, 1, 1, 1))
+    for l in range(L):
+        k = 2 ** ((l + 1) // 2)
+        fin = model.d_estimator.levels[l].last_f_input
+        assert fin.shape == (b, H >> (l + 1), Wd >> (l + 1), 58 * k + 6) and torch.isfinite(fin).all()
+        assert torch.equal(fin, fin[:uniq].repeat(reps, 1, 1, 1)), f"level {l}: refiner input replicas differ"
+        est = model.last_estimates[-1][l]
+        cam_l = {"f": dc["f"] / float(2 ** (l + 1)), "c": dc["c"] / float(2 ** (l + 1))}
+        assert torch.equal(est["depth"], M.parallax2depth(est["parallax"], ds[-1]["rot"], ds[-1]["trans"], cam_l))
+        lo, hi = np.exp(-7.0) / 2.0 ** (l + 1 - 3), np.exp(7.0) / 2.0 ** (l + 1 - 3)
+        assert est["parallax"].min() >= lo * (1 - 1e-5) and est["parallax"].max() <= hi * (1 + 1e-5)
+    fine = model.last_estimates[-1][0]["depth"]
+    assert torch.equal(out[:, ::2, ::2], fine) and torch.equal(out[:, 1::2, 1::2], fine)
+    model.reset_state()
+    assert torch.equal(model([ds, dc])["depth"], out)
+    # the batch-2 run: same pixels, other kernel choices on the coarse levels -> equal to float32 rounding
+    model2 = _model(dev, L, W)
+    model2([to_dev(samples, dev), to_dev(cam, dev)])
+    for l in range(L):
+        a = npy(model2.last_estimates[-1][l]["parallax"])
+        c = npy(model.last_estimates[-1][l]["parallax"][:uniq])
+        rp = rel_err(a, c, 1e-12)
+        assert rp.max() < 1e-4 and np.median(rp) < 2e-6, (l, rp.max(), np.median(rp))
+
+
+# ------------------------------------------------------------------------------- float64 truth
+@pytest.mark.parametrize("winograd", [False, True], ids=["direct_conv", "winograd"])
+def test_error_against_float64_truth(dev, winograd):
+    """Both float32 evaluations -- the numpy oracle and the GPU -- against the float64 evaluation of the same algorithm
+    (oracle.float64_reference(): same operations and order, the float16 steps of the DSCV kept).  The north-star
+    tolerance (1e-4 relative on depth) sits at the rounding-noise floor of ANY float32 evaluation of this network with
+    random weights: the float32 oracle itself is only within 1e-4 of the float64 truth on ~99 % of the pixels.  Asserted:
+    the GPU is as close to the truth as the oracle is (parallax error quantiles within 1.5x of the oracle's with the
+    direct convolution, 2.5x with Winograd F(2x2,3x3), whose transforms add 1.5-1.8x the rounding of a direct sum), and
+    the fraction of depth pixels within 1e-4 of the truth is printed for both, per convolution mode."""
+    from m4depth_amd import network as net
+    L, H, Wd, T, b = 3, 192, 384, 3, 1
+    W = S.init_weights(L, seed=42)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=91)
+    old = net.winograd_conv
+    net.winograd_conv = winograd
+    try:
+        if winograd:
+            assert net._use_winograd(b, H // 2, Wd // 2, 128, 128, 1) != 0, "pick a size at which level 1 runs on Winograd"
+        model = _model(dev, L, W)
+        model([to_dev(samples, dev), to_dev(cam, dev)])
+    finally:
+        net.winograd_conv = old
+    _, seq32 = O.M4Depth(W, L)(samples, cam)
+    with O.float64_reference():
+        _, seq64 = O.M4Depth(W, L)(samples, cam)
+    factor = 2.5 if winograd else 1.5
+    for l in range(L):
+        t_para, t_depth = seq64[-1][l]["parallax"], seq64[-1][l]["depth"]
+        e = {}
+        for name, para, depth in (("oracle_f32", seq32[-1][l]["parallax"], seq32[-1][l]["depth"]),
+                                  ("gpu", npy(model.last_estimates[-1][l]["parallax"]), npy(model.last_estimates[-1][l]["depth"]))):
+            rp = np.abs(para - t_para) / np.abs(t_para)
+            rd = np.abs(depth - t_depth) / np.maximum(np.abs(t_depth), 1e-9)
+            e[name] = dict(med=np.median(rp), p99=np.percentile(rp, 99), p999=np.percentile(rp, 99.9), max=rp.max(),
+                           d_ok=np.mean(rd < 1e-4))
+            print(f"[{'winograd' if winograd else 'direct'}] level {l} {name:10s} vs float64: parallax rel median {e[name]['med']:.2e} "
+                  f"p99 {e[name]['p99']:.2e} p99.9 {e[name]['p999']:.2e} max {e[name]['max']:.2e} | depth within 1e-4: "
+                  f"{100 * e[name]['d_ok']:.3f}%")
+        for q in ("med", "p99", "p999"):
+            assert e["gpu"][q] <= factor * e["oracle_f32"][q] + 1e-7, (l, q, e)
+        assert e["gpu"]["max"] <= max(3 * factor * e["oracle_f32"]["max"], 1e-4), (l, e)     # the max is one pixel: a float16 flip
+        assert e["gpu"]["d_ok"] >= e["oracle_f32"]["d_ok"] - 0.01, (l, e)
+
+
+# ------------------------------------------------------------------------------- helper ops (rows a3, a14)
+def test_helper_ops_vs_oracle(dev):
+    """get_rot_mat, get_coords_2d and tile_in_batch as tensor functions (utils/depth_operations.py:18-68, 217-221)."""
+    import m4depth_amd as M
+    rng = np.random.default_rng(12)
+    b, h, w = 3, 7, 9
+    for quat in (True, False):
+        rot, _ = motion_np(rng, b, quat=quat)
+        assert_bits_equal(npy(M.get_rot_mat(to_dev(rot, dev))), O.get_rot_mat(rot), "get_rot_mat")
+    with pytest.raises(ValueError):
+        M.get_rot_mat(torch.zeros(2, 5, device=dev))
+    cam = camera_np(b, h, w)
+    cam["c"] = (cam["c"] + rng.normal(0, 0.7, cam["c"].shape)).astype(F)
+    cam["f"] = (cam["f"] * rng.uniform(0.8, 1.3, cam["f"].shape)).astype(F)
+    coords, mesh = M.get_coords_2d(torch.zeros(b, h, w, 1, device=dev), to_dev(cam, dev))
+    oc, om = O.get_coords_2d(b, h, w, cam)
+    assert coords.shape == (b, h, w, 3, 1) and mesh.shape == (b, h, w, 2)
+    assert_bits_equal(npy(coords)[..., 0], oc, "coords_2d")
+    assert_bits_equal(npy(mesh), om, "mesh")
+    x = rng.standard_normal([b, 4, 5, 2]).astype(F)
+    t = M.tile_in_batch(to_dev(x, dev), 9)
+    assert t.shape == (9 * b, 4, 5, 2)
+    assert_bits_equal(npy(t), O.tile_in_batch(x, 9), "tile_in_batch")
+    for copy in (0, 4, 8):
+        assert torch.equal(t[copy * b:(copy + 1) * b], to_dev(x, dev))              # out batch index = copy*b + bi
+
+
+# ------------------------------------------------------------------------------- stale packed weights
+def test_inference_follows_parameter_updates(dev):
+    """The packed / Winograd-transformed / tail weight copies are keyed on the parameters' version: after an in-place
+    update (what optimizer.step() or load_state_dict do) eager inference AND a previously captured hipGraph use the new
+    weights -- bit-identical to a fresh model loaded from numpy_weights()."""
+    from m4depth_amd import network as net
+    L, H, Wd, T, b = 3, 64, 96, 2, 2
+    W = S.init_weights(L, seed=8)
+    model = _model(dev, L, W)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=31)
+    d = {k: torch.stack([to_dev(s[k], dev) for s in samples], dim=1) for k in ("depth", "RGB_im", "rot", "trans")}
+    d["new_traj"] = torch.stack([torch.from_numpy(s["new_traj"]) for s in samples], dim=1)
+    d["camera"] = to_dev(cam, dev)
+    ds, dc = to_dev(samples, dev), to_dev(cam, dev)
+    before = model([ds, dc])["depth"].clone()
+    runner = net.GraphedSequence(model, d)
+    assert torch.equal(runner(d), before)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.0 + 0.05 * torch.randn(p.shape, generator=g).to(p.device))
+    model.reset_state()
+    after = model([ds, dc])["depth"].clone()
+    assert not torch.equal(after, before)
+    fresh = _model(dev, L, model.numpy_weights())
+    assert torch.equal(fresh([ds, dc])["depth"], after), "eager inference used stale packed weights"
+    assert torch.equal(runner(d), after), "the captured graph replayed stale packed weights"

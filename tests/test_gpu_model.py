@@ -4,7 +4,7 @@ Tolerances:
   * teacher-forced level step (identical inputs, convolutions excluded): the
     refiner input ``f_input`` matches the oracle bit-exactly on the cost-volume /
     memory channels and to 2e-6 relative on the two log channels;
-  * full model (MIOpen fp32 convolutions vs the oracle's BLAS convolutions --
+  * full model (hand-written fp32-MFMA / Winograd convolutions vs the oracle's BLAS convolutions --
     different summation orders): depth within 1e-4 relative of the oracle
     (north_star tolerance) on >= 99.5 % of pixels, median below 1e-5, AbsRel metric
     within 1e-4 relative.  The few outliers come from float16 rounding flips of
@@ -136,10 +136,8 @@ def test_model_config1_vs_oracle_and_golden(dev, golden):
 def test_model_streaming_equals_sequence(dev):
     """Feeding frames one at a time (main.py eval on a stream, test_step 4-D branch)
     must give the same depth as feeding the whole sequence: state is carried by the
-    levels, not by the call.  Not asserted bitwise: several MIOpen fp32 convolution
-    solvers on gfx950 are run-to-run nondeterministic (atomic split-K; measured with
-    tools/debug_determinism3.py), so two executions of the SAME call already differ in
-    the last bits.  The hand-written kernels are deterministic (bitwise tests above)."""
+    levels, not by the call.  Bitwise: every kernel of the forward is deterministic, and the
+    sequence call's batched encoder has the same per-sample arithmetic."""
     L, H, Wd, T, b = 4, 64, 128, 2, 2
     W = S.init_weights(L, seed=5)
     samples, cam = S.make_sequence(b, T, H, Wd, seed=99)
@@ -152,9 +150,8 @@ def test_model_streaming_equals_sequence(dev):
         last = model([[s], dc])
     last_para = npy(model.last_estimates[-1][0]["parallax"])
     assert torch.isfinite(full["depth"]).all()
-    rp = rel_err(last_para, full_para, 1e-12)
-    print(f"stream vs sequence: parallax rel median {np.median(rp):.2e} max {rp.max():.2e}")
-    assert rp.max() < 1e-4 and np.median(rp) < 1e-6
+    assert_bits_equal(last_para, full_para, "stream vs sequence parallax")
+    assert torch.equal(last["depth"], full["depth"])
 
 
 def test_test_step_semantics(dev):
@@ -187,8 +184,8 @@ def test_test_step_semantics(dev):
 
 def test_graphed_sequence_matches_eager(dev):
     """hipGraph replay of the sequence forward (the bench's launch path) against the
-    eager forward of the same batch (not bitwise: MIOpen nondeterminism, see above), and
-    replay on a second batch copied into the static buffers."""
+    eager forward of the same batch, bit for bit, and replay on a second batch copied into the
+    static buffers; a batch with another shape or new_traj pattern is refused."""
     import m4depth_amd as M
     from m4depth_amd import network as net
     L, H, Wd, T, b = 3, 64, 96, 2, 2
@@ -214,35 +211,35 @@ def test_graphed_sequence_matches_eager(dev):
     for d, ref in ((d1, eager1), (d2, eager2), (d1, eager1)):
         res = model.graphed_test_step(d, runner)
         torch.cuda.synchronize()
-        rp = rel_err(npy(model.last_estimates[-1][0]["parallax"]), ref, 1e-12)
-        assert rp.max() < 1e-4 and np.median(rp) < 1e-6, (rp.max(), np.median(rp))
+        assert_bits_equal(npy(model.last_estimates[-1][0]["parallax"]), ref, "graph replay vs eager")
     assert model.compiled_metrics[0].count == 3 and np.isfinite(float(res["AbsRel"]))
+    bad = dict(d1)
+    bad["new_traj"] = torch.zeros_like(d1["new_traj"])
+    with pytest.raises(ValueError):
+        runner(bad)
+    bad = dict(d1)
+    bad["RGB_im"] = d1["RGB_im"][:1]
+    with pytest.raises(ValueError):
+        runner(bad)
 
 
-def test_fully_deterministic_mode_is_bitwise(dev):
-    """With the encoder on the hand-written convolution as well (no MIOpen kernel left in the
-    model) every kernel is deterministic: the same sequence twice, and frame-by-frame streaming
-    vs one sequence call, are bit-identical."""
-    from m4depth_amd import network as net
-    old = (net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels)
-    net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels = True, 1, 1
-    try:
-        L, H, Wd, T, b = 4, 64, 128, 3, 2
-        W = S.init_weights(L, seed=5)
-        samples, cam = S.make_sequence(b, T, H, Wd, seed=99)
-        model = _build(dev, L, 4, 3, W)
-        ds, dc = to_dev(samples, dev), to_dev(cam, dev)
-        first = model([ds, dc])["depth"].clone()
-        model.reset_state()
-        again = model([ds, dc])["depth"].clone()
-        assert torch.equal(first, again)
-        model.reset_state()
-        for s in ds:
-            last = model([[s], dc])["depth"]
-        # the sequence call batches the encoder over the frames; per-sample arithmetic is identical
-        assert torch.equal(first, last)
-    finally:
-        net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels = old
+def test_forward_is_deterministic_bitwise(dev):
+    """No MIOpen / framework kernel is in the model and every hand-written kernel is deterministic: the same
+    sequence twice, and frame-by-frame streaming vs one sequence call, are bit-identical."""
+    L, H, Wd, T, b = 4, 64, 128, 3, 2
+    W = S.init_weights(L, seed=5)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=99)
+    model = _build(dev, L, 4, 3, W)
+    ds, dc = to_dev(samples, dev), to_dev(cam, dev)
+    first = model([ds, dc])["depth"].clone()
+    model.reset_state()
+    again = model([ds, dc])["depth"].clone()
+    assert torch.equal(first, again)
+    model.reset_state()
+    for s in ds:
+        last = model([[s], dc])["depth"]
+    # the sequence call batches the encoder over the frames; per-sample arithmetic is identical
+    assert torch.equal(first, last)
 
 
 def test_model_large_search_windows(dev):
@@ -275,10 +272,9 @@ def test_model_large_search_windows(dev):
 def test_frame_pipeline_is_bitwise_neutral(dev):
     """The (frame, level) wavefront on one stream per frame -- eager, round-robin over 8 streams for a
     10-frame sequence, and captured in the hipGraph for 4 frames -- gives bit-identical depth to the
-    single-stream loop (deterministic mode: no MIOpen kernel in the model)."""
+    single-stream loop."""
     from m4depth_amd import network as net
-    old = (net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels, net.level_pipeline_streams)
-    net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels = True, 1, 1
+    old = net.level_pipeline_streams
     try:
         L, H, Wd, b = 3, 64, 96, 2
         W = S.init_weights(L, seed=6)
@@ -304,7 +300,7 @@ def test_frame_pipeline_is_bitwise_neutral(dev):
                     torch.cuda.synchronize()
                     assert torch.equal(ref, out), "captured pipeline differs"
     finally:
-        net.mfma_conv_encoder, net.mfma_conv_min_cin, net.mfma_conv_min_pixels, net.level_pipeline_streams = old
+        net.level_pipeline_streams = old
 
 
 @pytest.mark.parametrize("H,Wd,rd,rs,name", [(384, 1280, 4, 3, "configs[1]"), (768, 2560, 6, 6, "configs[4]")])

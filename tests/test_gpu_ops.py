@@ -504,6 +504,13 @@ def test_winograd_kernel_4_is_bitwise_kernel_2(dev, tmp_path):
     res = subprocess.run([sys.executable, tool, "--compare", *outs], check=True, timeout=600, capture_output=True, text=True).stdout
     lines = [l for l in res.strip().splitlines() if l]
     assert len(lines) >= 5 and all(l.endswith("bit-identical") for l in lines), res
+    # ... and both against the oracle's direct convolution at these geometries (Winograd differs by float32 rounding only)
+    saved = torch.load(outs[1])
+    for key, (x, k, bias) in saved["in"].items():
+        ref = O.leaky_relu(O.conv2d_same(x.numpy(), k.numpy(), bias.numpy(), 1), 0.1)
+        err = np.abs(saved["out"][key].numpy() - ref).max() / np.abs(ref).max()
+        print(f"winograd kernel 4 vs oracle, {key}: max error / output range = {err:.2e}")
+        assert err < 2e-5, (key, err)
 
 
 def test_sncv_variants_are_bitwise_identical(dev, tmp_path):
@@ -523,6 +530,12 @@ def test_sncv_variants_are_bitwise_identical(dev, tmp_path):
     res = subprocess.run([sys.executable, tool, "--compare", *outs], check=True, timeout=600, capture_output=True, text=True).stdout
     lines = [l for l in res.strip().splitlines() if l]
     assert len(lines) == 4 * 5 and all(l.endswith("bit-identical") for l in lines), res
+    # ... and the tile kernel (ys1: small-map kernel disabled) against the oracle itself at these (C, k) geometries:
+    # C = 96 / k = 4 and C = 192 / k = 8 otherwise only meet the oracle through the small-map kernel
+    saved = torch.load(outs[0])
+    for key, x in saved["in"].items():
+        ref = O.cost_volume(x.numpy(), x.numpy(), 3, nbre_cuts=int(key.split("/")[1]))
+        assert_bits_equal(saved["out"][key].numpy(), ref, f"SNCV tile kernel vs oracle, {key}")
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,slope", [

@@ -106,3 +106,50 @@ def test_shard_range():
     assert [D.shard_range(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
     with pytest.raises(ValueError):
         D.shard_range(10, 0, 4)
+
+
+def test_tensor_helpers_match_oracle_on_cpu():
+    """get_rot_mat / get_coords_2d / tile_in_batch are plain tensor plumbing (no kernel): the product functions themselves
+    (utils/depth_operations.py:18-68, 217-221) against the oracle, bit for bit, without a GPU."""
+    import m4depth_amd as M
+    rng = np.random.default_rng(4)
+    b, h, w = 2, 5, 6
+    q = rng.standard_normal([b, 4]).astype(F)                      # NOT renormalised by the reference
+    assert np.array_equal(M.get_rot_mat(torch.from_numpy(q)).numpy(), O.get_rot_mat(q))
+    e = (0.02 * rng.standard_normal([b, 3])).astype(F)
+    assert np.array_equal(M.get_rot_mat(torch.from_numpy(e)).numpy(), O.get_rot_mat(e))
+    assert np.array_equal(M.get_rot_mat(torch.tensor([[1., 0., 0., 0.]])).numpy()[0], np.eye(3, dtype=F))   # Appendix B inv. 1
+    with pytest.raises(ValueError):
+        M.get_rot_mat(torch.zeros(2, 2))
+    cam = {"f": np.array([[3.1, 2.2], [2.9, 2.4]], F), "c": np.array([[3.0, 2.5], [2.7, 2.6]], F)}
+    coords, mesh = M.get_coords_2d(torch.zeros(b, h, w, 1), {k: torch.from_numpy(v) for k, v in cam.items()})
+    oc, om = O.get_coords_2d(b, h, w, cam)
+    assert coords.shape == (b, h, w, 3, 1)
+    assert np.array_equal(coords.numpy()[..., 0], oc) and np.array_equal(mesh.numpy(), om)
+    x = rng.standard_normal([b, 3, 2]).astype(F)
+    t = M.tile_in_batch(torch.from_numpy(x), 4).numpy()
+    assert t.shape == (4 * b, 3, 2) and np.array_equal(t, O.tile_in_batch(x, 4))
+    assert np.array_equal(t[2 * b + 1], x[1])                       # out batch index = copy*b + bi
+
+
+def test_float64_reference_mode_of_the_oracle():
+    """oracle.float64_reference(): same algorithm in float64 (float16 DSCV steps kept); restores float32 afterwards."""
+    rng = np.random.default_rng(8)
+    b, h, w, C = 1, 6, 8, 16
+    c1 = O.normalize_cuts(rng.standard_normal([b, h, w, C]).astype(F), 1)
+    c2 = O.normalize_cuts(rng.standard_normal([b, h, w, C]).astype(F), 1)
+    cam = {"f": np.array([[4.0, 3.0]], F), "c": np.array([[4.0, 3.0]], F)}
+    rot = np.array([[1.0, 0.001, -0.002, 0.0015]], F)
+    trans = np.array([[0.05, -0.02, 0.3]], F)
+    disp = (0.5 + rng.random([b, h, w, 1])).astype(F)
+    cv32, _ = O.get_parallax_sweeping_cv(c1, c2, disp, disp, rot, trans, cam, 2)
+    with O.float64_reference():
+        assert O.F32 is np.float64
+        cv64, _ = O.get_parallax_sweeping_cv(c1, c2, disp, disp, rot, trans, cam, 2)
+        d64 = O.parallax2depth(disp, rot, trans, cam)
+    assert O.F32 is np.float32
+    assert cv32.dtype == np.float32 and cv64.dtype == np.float64 and d64.dtype == np.float64
+    assert np.array_equal(cv64, cv64.astype(np.float16).astype(np.float64))        # still float16-valued
+    assert np.mean(cv32 == cv64) > 0.9 and np.max(np.abs(cv32 - cv64)) < 2e-3       # same up to a few float16 flips
+    d32 = O.parallax2depth(disp, rot, trans, cam)
+    assert d32.dtype == np.float32 and np.max(np.abs(d32 - d64) / np.abs(d64)) < 1e-5

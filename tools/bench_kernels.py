@@ -71,7 +71,7 @@ def main():
                 ("sncv", run_sncv, None)]
     bytes_["dscv[wave]"] = bytes_["dscv[lds-window]"] = bytes_["dscv[lds-hyp]"] = bytes_["dscv[lds-hyp9]"] = bytes_["dscv"]
     for name, fn, variant in variants:
-        if name.split("[")[0] not in args.which.split(","):
+        if name.split("[")[0] not in args.which.split(",") and name not in args.which.split(","):
             continue
         if variant is not None:
             lib.m4d_dscv_set_variant(variant)

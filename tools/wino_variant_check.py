@@ -1,6 +1,7 @@
 """Winograd kernel 2 (M4D_WINO_VARIANT=2) vs kernel 4 (default where the grid is large enough; M4D_WINO4_MIN_WG=0 forces
 it wherever it applies): run once per variant with --save, then --compare: the outputs must be bit-identical (same
-arithmetic, same order).  Used by tests/test_gpu_ops.py::test_winograd_kernel_4_is_bitwise_kernel_2."""
+arithmetic, same order).  The inputs are saved next to the outputs, so the test can also compare both with the CPU oracle.
+Used by tests/test_gpu_ops.py::test_winograd_kernel_4_is_bitwise_kernel_2."""
 import argparse, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,13 +10,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--save"); ap.add_argument("--compare", nargs=2)
 a = ap.parse_args()
 if a.compare:
-    x, y = torch.load(a.compare[0]), torch.load(a.compare[1])
+    x, y = torch.load(a.compare[0])["out"], torch.load(a.compare[1])["out"]
     for k in x:
         same = torch.equal(x[k].view(torch.int32), y[k].view(torch.int32))
         print(k, "bit-identical" if same else f"DIFFERENT max {(x[k] - y[k]).abs().max().item():.3e}")
     sys.exit(0)
 dev = torch.device("cuda:0")
-out = {}
+out = {"in": {}, "out": {}}
 g = torch.Generator().manual_seed(3)
 for (b, h, w, cin, cout) in [(1, 192, 640, 128, 128), (2, 96, 320, 124, 64), (1, 37, 53, 36, 40), (1, 50, 70, 44, 128), (3, 16, 16, 32, 64),
                              (1, 100, 130, 64, 120)]:
@@ -32,5 +33,6 @@ for (b, h, w, cin, cout) in [(1, 192, 640, 128, 128), (2, 96, 320, 124, 64), (1,
     for _ in range(10): nops.conv3x3_wino2_bias_act(x, wud, bias, cout, cpad, 0.1)
     e1.record(); torch.cuda.synchronize()
     print(f"b={b} {h}x{w} {cin}->{cout}: {e0.elapsed_time(e1) * 100:.1f} us", flush=True)
-    out[f"{b}x{h}x{w}x{cin}->{cout}"] = y.cpu()
+    out["in"][f"{b}x{h}x{w}x{cin}->{cout}"] = (x.cpu(), k, bias.cpu())
+    out["out"][f"{b}x{h}x{w}x{cin}->{cout}"] = y.cpu()
 torch.save(out, a.save)
