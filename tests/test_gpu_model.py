@@ -21,7 +21,7 @@ from helpers import F, camera_np, motion_np, to_dev, npy, assert_bits_equal, rel
 pytestmark = pytest.mark.gpu
 
 
-def check_depth_and_parallax(depth, para, o_depth, o_para, rot, trans, cam, what, frac_ok=0.99):
+def check_depth_and_parallax(depth, para, o_depth, o_para, rot, trans, cam, what, frac_ok=0.99, max_tol=1e-4):
     """The north-star tolerance is 1e-4 relative on depth.  depth = (s/para - tz)/alpha
     cancels when s/para ~ tz (only reachable with random weights: a trained net keeps
     depth in [0.1, 1000]), so relative depth error is unbounded there however accurate
@@ -36,8 +36,8 @@ def check_depth_and_parallax(depth, para, o_depth, o_para, rot, trans, cam, what
     rd = rel_err(depth, o_depth, 1e-9)
     print(f"{what}: parallax rel max {rp.max():.2e} | depth rel median {np.median(rd):.2e} p99 {np.percentile(rd, 99):.2e} "
           f"max {rd.max():.2e} within1e-4 {100 * np.mean(rd < 1e-4):.3f}% | cond-scaled max {np.max(ed / scale):.2e}")
-    assert rp.max() < 1e-4, what
-    assert np.max(ed / scale) < 1e-4, what
+    assert rp.max() < max_tol, what
+    assert np.max(ed / scale) < max_tol, what
     assert np.mean(rd < 1e-4) >= frac_ok and np.median(rd) < 1e-5, what
 
 
