@@ -272,6 +272,22 @@ int m4d_level_pre_normalize(const float* prev_l_depth, const float* prev_l_paral
                             float* depth_state_reset,
                             const float* norm_x, int C, int nbre_cuts, float* norm_out, void* stream);
 
+/* The fused level front (m4depth_network.py:179-242 in one launch, default settings: all ablation blocks on, DSCV range 4,
+ * SNCV range 3): per-cut normalisation of raw_f [b,h,w,C] -> norm_out (the buffer that becomes prev_f_maps, :211/:259);
+ * x2 upsampling of the coarser level's parallax / other maps ([b,ph,pw,1] / [b,ph,pw,4]; both NULL at the coarsest level),
+ * prev_d2para of depth_prev_t, DSCV against prev_f, SNCV of the normalised features, both log features -- assembled into
+ * whole rows of f_input [b,h,w,f_stride] (channel order cv | log para_l | other(4) | sncv | log para_t, padding channels
+ * zeroed), written as contiguous runs.  Bit-identical to m4d_level_pre_normalize + m4d_dscv_fwd + m4d_sncv_fwd.
+ * m4d_level_front_supported: 1 if the (C, cuts, ranges, row stride) combination has a kernel (f_stride must be 58*cuts+6
+ * rounded up to a multiple of 8), else 0 -- the caller then uses the three separate entry points. */
+int m4d_level_front_supported(int C, int nbre_cuts, int dscv_range, int sncv_range, int f_stride);
+void m4d_front_set_stamps(unsigned long long* device_buffer);   /* profiling: 8 x u64 per workgroup, phase cycle stamps */
+int m4d_level_front(const float* raw_f, float* norm_out, const float* prev_f, const float* depth_prev_t,
+                    const float* prev_l_parallax, const float* prev_l_other, int ph, int pw,
+                    const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
+                    int b, int h, int w, int C, int nbre_cuts, int cv_accum,
+                    float* f_input, int f_stride, float log_scale, void* stream);
+
 /* Level-local intrinsics of DepthEstimatorPyramid.call (m4depth_network.py:300-302) for all levels in one launch:
  * f_out / c_out [levels,b,2], level l (0 = finest) = cam / 2^(l+1). */
 int m4d_camera_pyramid(const float* cam_f, const float* cam_c, int b, int levels, float* f_out, float* c_out,

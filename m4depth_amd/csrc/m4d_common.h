@@ -96,3 +96,36 @@ __device__ __forceinline__ float m4d_lerp2(float tl, float tr, float bl, float b
 
 // float -> half -> float (round-to-nearest-even), the cast at depth_operations.py:276.
 __device__ __forceinline__ float m4d_round_half(float v) { return __half2float(__float2half_rn(v)); }
+
+// tf.compat.v1.image.resize_bilinear with legacy coordinates (m4depth_network.py:202-204): src = dst * (in / out),
+// lower = floor, upper = min(ceil, in - 1), top + (bottom - top) * ylerp with top = tl + (tr - tl) * xlerp.
+struct ResizeAxis { int lo, hi; float lerp; };
+__device__ __forceinline__ ResizeAxis resize_axis(int o, float scale, int in_n) {
+  const float src = (float)o * scale;
+  const float fl = floorf(src);
+  ResizeAxis a;
+  a.lo = max((int)fl, 0);
+  a.hi = min((int)ceilf(src), in_n - 1);
+  a.lerp = src - fl;
+  return a;
+}
+__device__ __forceinline__ float resize_sample(const float* __restrict__ img, int iw, int c, int cc,
+                                               const ResizeAxis& ya, const ResizeAxis& xa) {
+  const float tl = img[((long long)ya.lo * iw + xa.lo) * c + cc];
+  const float tr = img[((long long)ya.lo * iw + xa.hi) * c + cc];
+  const float bl = img[((long long)ya.hi * iw + xa.lo) * c + cc];
+  const float br = img[((long long)ya.hi * iw + xa.hi) * c + cc];
+  const float top = tl + (tr - tl) * xa.lerp;
+  const float bot = bl + (br - bl) * xa.lerp;
+  return top + (bot - top) * ya.lerp;
+}
+
+
+// prev_d2para (utils/depth_operations.py:197-215) of one pixel: delta = (t*f - tz*((mesh/f)*f)) / (depth - tz), |delta|.
+__device__ __forceinline__ float m4d_prev_d2para_px(const M4dMotion& m, float depth, int i, int j) {
+  const float mx = ((float)i + 0.5f) - m.cx, my = ((float)j + 0.5f) - m.cy;
+  const float ccx = (mx / m.fx) * m.fx, ccy = (my / m.fy) * m.fy;
+  const float den = depth - m.tz;
+  const float dx = (m.stx - m.tz * ccx) / den, dy = (m.sty - m.tz * ccy) / den;
+  return sqrtf(dx * dx + dy * dy);
+}

@@ -83,28 +83,8 @@ void launch_normalize_group(const float* x, long long items, float* out, hipStre
   hipLaunchKernelGGL(normalize_cuts_group_kernel<LPG>, dim3((unsigned)blocks), dim3(256), 0, s, x, items, out);
 }
 
-// ---- tf.compat.v1.image.resize_bilinear, legacy coordinates (:202-204) ----------
-struct ResizeAxis { int lo, hi; float lerp; };
-__device__ __forceinline__ ResizeAxis resize_axis(int o, float scale, int in_n) {
-  const float src = (float)o * scale;
-  const float fl = floorf(src);
-  ResizeAxis a;
-  a.lo = max((int)fl, 0);
-  a.hi = min((int)ceilf(src), in_n - 1);
-  a.lerp = src - fl;
-  return a;
-}
-__device__ __forceinline__ float resize_sample(const float* __restrict__ img, int iw, int c, int cc,
-                                               const ResizeAxis& ya, const ResizeAxis& xa) {
-  const float tl = img[((long long)ya.lo * iw + xa.lo) * c + cc];
-  const float tr = img[((long long)ya.lo * iw + xa.hi) * c + cc];
-  const float bl = img[((long long)ya.hi * iw + xa.lo) * c + cc];
-  const float br = img[((long long)ya.hi * iw + xa.hi) * c + cc];
-  const float top = tl + (tr - tl) * xa.lerp;
-  const float bot = bl + (br - bl) * xa.lerp;
-  return top + (bot - top) * ya.lerp;
-}
-
+// ---- tf.compat.v1.image.resize_bilinear, legacy coordinates (:202-204): ResizeAxis / resize_axis / resize_sample live in
+// m4d_common.h (shared with the fused level front, m4d_front.hip)
 __global__ void __launch_bounds__(256)
 resize_bilinear_v1_kernel(const float* __restrict__ x, int ih, int iw, int c, int oh, int ow,
                           float mul, long long total, float* __restrict__ out) {

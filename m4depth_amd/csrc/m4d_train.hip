@@ -16,17 +16,7 @@ namespace {
 
 inline int grid1d(long long n) { long long g = (n + 255) / 256; return (int)(g > 65535 ? 65535 : (g < 1 ? 1 : g)); }
 
-// ---- adjoint of tf.compat.v1.image.resize_bilinear ---------------------------------
-struct ResizeAxis { int lo, hi; float lerp; };
-__device__ __forceinline__ ResizeAxis resize_axis(int o, float scale, int in_n) {
-  const float src = (float)o * scale;
-  const float fl = floorf(src);
-  ResizeAxis a;
-  a.lo = max((int)fl, 0);
-  a.hi = min((int)ceilf(src), in_n - 1);
-  a.lerp = src - fl;
-  return a;
-}
+// ---- adjoint of tf.compat.v1.image.resize_bilinear (ResizeAxis / resize_axis: m4d_common.h) ----------
 // weight of input index `in` in output index `o` along one axis
 __device__ __forceinline__ float axis_weight(int o, float scale, int in_n, int in) {
   const ResizeAxis a = resize_axis(o, scale, in_n);

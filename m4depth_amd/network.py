@@ -77,6 +77,13 @@ fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
 # level_pre and the per-cut normalisation of a level in one launch (m4d_level_pre_normalize).  0 = two launches.
 fused_level_front = _os.environ.get("M4D_FUSED_LEVEL_FRONT", "1") == "1"
 
+# The whole level front (normalise + level_pre + DSCV + SNCV -> complete refiner-input rows) as ONE kernel
+# (csrc/m4d_front.hip) wherever it has an instantiation: the default settings and 16 channels x 1-2 cuts or 32 x 2 (levels 1-3
+# of the 6-level pyramid); maps of at most fused_front_min_pixels pixels (batch included) and every other configuration keep
+# the separate kernels.  M4D_FUSED_FRONT=0 = the separate kernels everywhere (same bits).
+fused_front = _os.environ.get("M4D_FUSED_FRONT", "1") == "1"
+fused_front_min_pixels = int(_os.environ.get("M4D_FUSED_FRONT_MIN_PX", "0"))
+
 # Encoder level 0 as two fused kernels (direct 3->16 convolution + bias + DINL statistics; DINL apply fused into the
 # stride-2 convolution's input staging) instead of MIOpen conv + bias pass + 3 DINL passes + conv: no MIOpen kernel is
 # left in the inference path.  0 = the unfused sequence.
@@ -444,12 +451,27 @@ class DepthEstimatorLevel(torch.nn.Module):
         use_state = (not self.is_training) and prev_f_maps is None and prev_t_depth is None    # :192
         if not self.is_training:
             self._ensure_state((b, h, w, c), dev)
+        nt = new_traj
+        if isinstance(nt, torch.Tensor):
+            nt = bool(nt.reshape(-1)[0].item())       # "sequences are synchronized over the batch" (:207)
+        elif not isinstance(nt, bool):
+            nt = bool(np.asarray(nt).reshape(-1)[0])
+        ab = self.ablation
+        F_in = self.f_in
+        F_st = (F_in + 7) // 8 * 8 if (pad_refiner_input and dev.type == "cuda" and not self.is_training) else F_in
+        # the fused level front: normalisation, upsampling, both cost volumes and the log features in one launch
+        use_front = (fused_front and use_state and not nt and dev.type == "cuda" and self._spare_f is not None
+                     and ab.SNCV and ab.time_recurr and ab.normalize_features and ab.level_memory
+                     and b * h * w > fused_front_min_pixels and self.dscv_range == 4 and self.sncv_range == 3
+                     and bool(lib.m4d_level_front_supported(c, k, 4, 3, F_st)))
         # normalised current features land in the spare state buffer: after the level
         # ran they ARE the new prev_f_maps (:211, :259) -- a pointer swap, not a copy.
         # (inference, state mode) the normalisation shares a launch with level_pre below: both open the level, neither
         # depends on the other
         norm_job = None
-        if (fused_level_front and self.ablation.normalize_features and dev.type == "cuda" and not self.is_training
+        if use_front:
+            curr_f = self._spare_f
+        elif (fused_level_front and self.ablation.normalize_features and dev.type == "cuda" and not self.is_training
                 and prev_f_maps is None and self._spare_f is not None and c % self.nbre_cuts == 0):
             curr_f = self._spare_f
             norm_job = (curr_f_maps, self.nbre_cuts, curr_f)
@@ -461,12 +483,6 @@ class DepthEstimatorLevel(torch.nn.Module):
             prev_t_depth = self.depth_prev_t
             prev_f_maps = self.prev_f_maps
 
-        nt = new_traj
-        if isinstance(nt, torch.Tensor):
-            nt = bool(nt.reshape(-1)[0].item())       # "sequences are synchronized over the batch" (:207)
-        elif not isinstance(nt, bool):
-            nt = bool(np.asarray(nt).reshape(-1)[0])
-
         if prev_t_depth is None or nt:                                                 # :208-214
             para_prev_l, depth_prev_l, other_prev_l, _ = _timed("pre", "reset", lambda: nops.level_pre(
                 prev_l_est, None, None, None, b, h, w, dev, normalize=norm_job,
@@ -477,10 +493,7 @@ class DepthEstimatorLevel(torch.nn.Module):
 
         r = self.dscv_range
         ncp = 2 * r + 1
-        F_in = self.f_in
-        F_st = F_in                                   # channel stride of the refiner input buffer
-        if pad_refiner_input and dev.type == "cuda" and not self.is_training and F_in % 8 != 0:
-            F_st = (F_in + 7) // 8 * 8
+        if F_st != F_in:                              # channel stride of the refiner input buffer > its width: zero padding
             f_buf = nops.zeroed_workspace(("f_input", self.lvl_depth), (b, h, w, F_st), dev)
         else:
             f_buf = torch.empty((b, h, w, F_in), dtype=torch.float32, device=dev)
@@ -490,9 +503,10 @@ class DepthEstimatorLevel(torch.nn.Module):
         sncv_off = log_off + 1 + (4 if self.ablation.level_memory else 0)
         scale = float(2.0 ** self.lvl_mul)
         # "preprocessor" (:216-242): upsample coarser estimate, prev_d2para, log / memory features
-        para_prev_l, depth_prev_l, other_prev_l, para_prev_t = _timed("pre", self.lvl_depth, lambda: nops.level_pre(
-            prev_l_est, as_f32(prev_t_depth, "prev_t_depth"), trans, camera, b, h, w, dev,
-            f_input=f_input, log_off=log_off, other_off=other_off, log_scale=scale, normalize=norm_job))
+        if not use_front:
+            para_prev_l, depth_prev_l, other_prev_l, para_prev_t = _timed("pre", self.lvl_depth, lambda: nops.level_pre(
+                prev_l_est, as_f32(prev_t_depth, "prev_t_depth"), trans, camera, b, h, w, dev,
+                f_input=f_input, log_off=log_off, other_off=other_off, log_scale=scale, normalize=norm_job))
         rot_t = as_f32(rot, "rot")
         tr = as_f32(trans, "trans").reshape(b, 3)
         cf = as_f32(camera["f"], "camera['f']").reshape(b, 2)
@@ -505,7 +519,19 @@ class DepthEstimatorLevel(torch.nn.Module):
         # DSCV (:220-221) -> f_input[..., 0:9k]; time-recurrence feature (:238) -> f_input[..., -1]
         prev_f = as_f32(prev_f_maps, "prev_f_maps")
         kt_on = kernel_timer is not None and getattr(kernel_timer, "enabled", True)
-        if fused_cost_volumes and self.ablation.SNCV and dev.type == "cuda" and not kt_on and b * h * w <= 6000:
+        if use_front:
+            pp = po = None
+            ph = pw = 0
+            if prev_l_est is not None:
+                pp = as_f32(prev_l_est["parallax"], "prev_l_est['parallax']")
+                po = as_f32(prev_l_est["other"], "prev_l_est['other']")
+                ph, pw = pp.shape[1:3]
+            check(_timed("front", self.lvl_depth, lambda: lib.m4d_level_front(
+                dptr(curr_f_maps, "curr_f_maps"), dptr(curr_f), dptr(prev_f), dptr(as_f32(prev_t_depth, "prev_t_depth")),
+                dptr(pp), dptr(po), ph, pw, dptr(rot_t), rot_t.shape[1], dptr(tr), dptr(cf), dptr(cc),
+                b, h, w, c, k, _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr), F_st, scale, stream_ptr())), "m4d_level_front")
+            para_prev_t = para_prev_l = None
+        elif fused_cost_volumes and self.ablation.SNCV and dev.type == "cuda" and not kt_on and b * h * w <= 6000:
             # small maps: both (independent) cost volumes in one launch
             check(lib.m4d_dscv_sncv_fwd(
                 dptr(curr_f), dptr(prev_f), dptr(para_prev_t), dptr(para_prev_l), dptr(rot_t), rot_t.shape[1],
@@ -523,6 +549,7 @@ class DepthEstimatorLevel(torch.nn.Module):
                     ctypes.c_void_p(fin_ptr + 4 * sncv_off), F_st, stream_ptr())), "m4d_sncv_fwd")
         self.last_f_input = f_input if F_st == F_in else f_input[..., :F_in]      # the reference-width view (inspection / tests)
         self.last_cv_inputs = (curr_f, prev_f, para_prev_t, para_prev_l, rot_t, tr, cf, cc)   # for tools/bench_kernels.py
+        self.last_front_inputs = (curr_f_maps, prev_l_est, prev_t_depth)
         # "depth_estimator" (:244-260)
         convs = list(self.disp_refiner.prep_conv_layers) + list(self.disp_refiner.est_d_conv_layers)
         if (fused_refiner_tail and dev.type == "cuda" and len(convs) == 7 and convs[5].weight is not None

@@ -597,3 +597,59 @@ def test_merged_cost_volume_launch(M, dev, b, h, w, C, k):
     ocv, _ = O.get_parallax_sweeping_cv(c1, c2, dpt, disp, rot, trans, cam, 4, k)
     assert_bits_equal(npy(outs[0][..., :9 * k]), ocv, "dscv through the merged entry")
     assert_bits_equal(npy(outs[0][..., 9 * k + 1:9 * k + 1 + 49 * k]), O.cost_volume(c1, c1, 3, nbre_cuts=k), "sncv through the merged entry")
+
+
+@pytest.mark.parametrize("depth,b,h,w,quat,cv_accum", [
+    (1, 2, 37, 45, True, "fp32_round"),      # C = 16, 1 cut: ragged tiles in both directions
+    (1, 1, 8, 32, False, "fp16_seq"),        # exactly one tile; small-angle rotation; sequential float16 mean
+    (2, 2, 20, 27, True, "fp32_round"),      # C = 32, 2 cuts, padded row stride 122 -> 128
+    (3, 1, 19, 33, True, "fp32_round"),      # C = 64, 2 cuts
+    (3, 2, 16, 16, False, "fp16_seq"),
+])
+def test_fused_level_front_is_bitwise_the_separate_kernels(M, dev, depth, b, h, w, quat, cv_accum):
+    """m4d_level_front (normalise + level_pre + DSCV + SNCV in one launch, whole refiner-input rows) against the three
+    separate launches it replaces: refiner input (incl. the zero padding channels), feature state and outputs bit for bit,
+    over three consecutive frames (the second and third see a depth memory and a coarser estimate that vary per pixel)."""
+    from m4depth_amd import network as net
+    rng = np.random.default_rng(500 + depth * 10 + h)
+    C = S_ENC[depth - 1]
+    from m4depth_amd import synthetic as S
+    W = S.init_weights(6, seed=4)
+    settings = {"nbre_lvls": 6, "is_training": False, "ablation": M.M4depthAblationParameters(), "cv_accum": cv_accum}
+    levels = []
+    for _ in range(2):
+        gl = M.DepthEstimatorLevel(settings, depth)
+        convs = list(gl.disp_refiner.prep_conv_layers) + list(gl.disp_refiner.est_d_conv_layers)
+        for i, cv in enumerate(convs):
+            cv.load_hwio(W[f"lvl.{depth}.conv.{i}.kernel"], W[f"lvl.{depth}.conv.{i}.bias"], dev)
+        levels.append(gl)
+    cam = to_dev(camera_np(b, h, w), dev)
+    old = (net.fused_front, net.fused_front_min_pixels)
+    try:
+        for step in range(4):
+            rot, trans = motion_np(rng, b, quat=quat, t_scale=(3.0, 3.0, 1.0))
+            f = to_dev(rng.standard_normal([b, h, w, C]).astype(F), dev)
+            prev = {"depth": to_dev((1 + 50 * rng.random([b, (h + 1) // 2, (w + 1) // 2, 1])).astype(F), dev),
+                    "parallax": to_dev((0.2 + 2 * rng.random([b, (h + 1) // 2, (w + 1) // 2, 1])).astype(F), dev),
+                    "other": to_dev(rng.standard_normal([b, (h + 1) // 2, (w + 1) // 2, 4]).astype(F), dev)}
+            if step == 3:
+                prev = None                      # the coarsest-level form of the call (no coarser estimate)
+            nt = np.full([b], step == 0)
+            outs, fins = [], []
+            for fused, gl in zip((True, False), levels):
+                net.fused_front, net.fused_front_min_pixels = fused, 0
+                outs.append(gl(f, prev, to_dev(rot, dev), to_dev(trans, dev), cam, nt))
+                fins.append(gl.last_f_input.clone() if step > 0 else None)     # both levels share the persistent padded buffer
+            assert torch.equal(levels[0].prev_f_maps, levels[1].prev_f_maps), f"step {step}: feature state"
+            assert torch.equal(levels[0].depth_prev_t, levels[1].depth_prev_t), f"step {step}: depth state"
+            for key in ("depth", "parallax", "other"):
+                assert torch.equal(outs[0][key], outs[1][key]), f"step {step}: {key}"
+            if step > 0:
+                fa, fb = fins
+                assert_bits_equal(npy(fa), npy(fb), f"step {step}: refiner input")
+                assert torch.isfinite(fa).all()
+    finally:
+        net.fused_front, net.fused_front_min_pixels = old
+
+
+S_ENC = [16, 32, 64, 96, 128, 192]

@@ -11,6 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["M4D_FUSED_FRONT"] = "0"                          # the model step below must leave the separate kernels' inputs behind
 import m4depth_amd as M                                     # noqa: E402
 from m4depth_amd import synthetic as S                      # noqa: E402
 from m4depth_amd._lib import lib, dptr, stream_ptr          # noqa: E402
@@ -65,10 +66,24 @@ def main():
         return lib.m4d_sncv_fwd(dptr(c1), dptr(c1), b, h, w, C, 3, 1, k, ctypes.c_void_p(fin + 4 * (9 * k + 5)), F_in,
                                 stream_ptr())
 
+    raw_f, prev_l, depth_t = lvl.last_front_inputs
+    F_st = (F_in + 7) // 8 * 8
+    f_front = torch.zeros((b, h, w, F_st), device=dev)
+    norm_out = torch.empty_like(c1)
+    bytes_["front"] = int(px * (4 * (3 * C + 1 + F_in + 6) + 6))
+
+    def run_front():
+        pp = prev_l["parallax"] if prev_l is not None else None
+        po = prev_l["other"] if prev_l is not None else None
+        ph, pw = (pp.shape[1], pp.shape[2]) if pp is not None else (0, 0)
+        return lib.m4d_level_front(dptr(raw_f), dptr(norm_out), dptr(c2), dptr(depth_t), dptr(pp), dptr(po), ph, pw,
+                                   dptr(rot), rot.shape[1], dptr(tr), dptr(cf), dptr(cc), b, h, w, C, k, 0,
+                                   dptr(f_front), F_st, 0.25, stream_ptr())
+
     lib.m4d_dscv_set_ablation(args.ablate)
     counter = torch.zeros(1, dtype=torch.int32, device=dev)
     variants = [("dscv[wave]", run_dscv, 1), ("dscv[lds-window]", run_dscv, 2), ("dscv[lds-hyp]", run_dscv, 3), ("dscv[lds-hyp9]", run_dscv, 4),
-                ("sncv", run_sncv, None)]
+                ("sncv", run_sncv, None), ("front", run_front, None)]
     bytes_["dscv[wave]"] = bytes_["dscv[lds-window]"] = bytes_["dscv[lds-hyp]"] = bytes_["dscv[lds-hyp9]"] = bytes_["dscv"]
     for name, fn, variant in variants:
         if name.split("[")[0] not in args.which.split(",") and name not in args.which.split(","):
@@ -94,6 +109,19 @@ def main():
                     print(f"  {name}: cycles/workgroup box {d[0]:.0f}  stage {d[1]:.0f}  gather+compute {d[2]:.0f}  | window px mean "
                           f"{float(st[:, 4].mean()):.0f} max {float(st[:, 4].max()):.0f}, width mean {float(st[:, 5].mean()):.1f}; "
                           f"kernel span {(float(st[:, 3].max()) - float(st[:, 0].min())) / 1e3:.0f} kcycles over {len(st)} workgroups", flush=True)
+        if name == "front":
+            tiles = 4096
+            stamps = torch.zeros((tiles, 8), dtype=torch.int64, device=dev)
+            lib.m4d_front_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+            fn()
+            torch.cuda.synchronize()
+            lib.m4d_front_set_stamps(None)
+            st = stamps[stamps[:, 0] != 0].double()
+            if len(st):
+                names = ["stage+upsample", "normalise", "state store+SNCV", "c1+stage writes", "DSCV", "row stores"]
+                d = [float((st[:, i + 1] - st[:, i]).mean()) for i in range(6)]
+                print("  front phases (cycles/workgroup, mean over %d): " % len(st) + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, d))
+                      + f" | total {float((st[:, 6] - st[:, 0]).mean()):.0f}; kernel span {(float(st[:, 6].max()) - float(st[:, 0].min())) / 1e3:.1f} kcycles", flush=True)
         for _ in range(3):
             assert fn() == 0
         torch.cuda.synchronize()
