@@ -380,6 +380,20 @@ long long m4d_metrics_workspace_bytes(void);
 int m4d_depth_metrics(const float* gt, const float* est, long long n, float max_d, void* workspace,
                       float* out7, float* total7, float count, float* mean7, void* stream);
 
+/* ---- training without MIOpen (train_step, m4depth_network.py:371-399: tf.GradientTape through every Conv2D) ---------- */
+
+/* Weight gradient of the 3x3 TF-'SAME' convolution y = conv(x [b,h,w,cin], W), stride 1 or 2, given g = dL/dy
+ * [b,ceil(h/s),ceil(w/s),cout]: dw [cout][3][3][cin] floats (the memory layout of an OIHW parameter with channels-last
+ * strides).  fp32 MFMA, two-stage fixed-order reduction over the pixels (deterministic).  cin < 8 is the 3-channel image
+ * layer (stride 1, cout <= 32).  workspace: m4d_conv3x3_wgrad_workspace_floats(...) floats. */
+long long m4d_conv3x3_wgrad_workspace_floats(int b, int h, int w, int cin, int cout, int stride);
+int m4d_conv3x3_wgrad(const float* x, const float* g, int b, int h, int w, int cin, int cout, int stride,
+                      float* workspace, long long workspace_floats, float* dw, void* stream);
+/* g [b,ceil(h/2),ceil(w/2),C] spread onto the [b,h,w,C] grid of a stride-2 layer's input (zeros elsewhere), placed so that
+ * the layer's data gradient is the stride-1 'SAME' convolution of the result with the rotated, transposed kernel
+ * (m4d_pack_conv_weights(transpose = 1) + m4d_conv3x3s_bias_act_ws). */
+int m4d_dilate2(const float* g, int b, int oh, int ow, int C, int h, int w, float* out, void* stream);
+
 /* ---- dataloaders (midair / kitti / tartanair .py): _decode_samples after decompression ----------------------- */
 
 /* RGB frames as the JPEG decoder leaves them, [n,ih,iw,3] uint8 -> [n,oh,ow,3] float32 =

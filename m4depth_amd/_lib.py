@@ -85,6 +85,8 @@ _SIGNATURES = {
     "m4d_level_front_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "m4d_level_front": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
                         _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_f, _c_fp],
+    "m4d_conv3x3_wgrad": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, ctypes.c_longlong, _c_fp, _c_fp],
+    "m4d_dilate2": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_camera_pyramid": [_c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
     "m4d_level_post": [_c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
                        _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
@@ -92,7 +94,8 @@ _SIGNATURES = {
 
 _LL_SIGNATURES = {"m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
                   "m4d_dinl_workspace_floats": [_c_int, _c_int], "m4d_metrics_workspace_bytes": [],
-                  "m4d_bias_act_bwd_workspace_floats": [ctypes.c_longlong, _c_int], "m4d_loss_workspace_floats": []}
+                  "m4d_bias_act_bwd_workspace_floats": [ctypes.c_longlong, _c_int], "m4d_loss_workspace_floats": [],
+                  "m4d_conv3x3_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]}
 _VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
                     "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp], "m4d_wino_set_stamps": [_c_fp],
                     "m4d_front_set_stamps": [_c_fp]}

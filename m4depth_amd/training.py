@@ -6,17 +6,20 @@ Here torch autograd records the graph, and the nodes that carry the work are HIP
 
   * cost volumes: ``get_parallax_sweeping_cv`` / ``cost_volume`` forward and backward kernels
     (m4d_dscv_fwd/bwd, m4d_sncv_fwd/bwd);
-  * convolutions: forward = the fp32-MFMA implicit GEMM with fused bias + leaky_relu, data
-    gradient of the stride-1 layers = the SAME kernel run on the 180-degree-rotated, transposed
-    weights (a 3x3 'SAME' stride-1 correlation is its own adjoint up to that re-packing);
-    weight gradients and the stride-2 / 3-channel layers go through MIOpen
-    (aten.convolution_backward);
+  * convolutions: forward = the fp32-MFMA implicit GEMM with fused bias + leaky_relu (every layer, the 3-channel
+    image layer included); data gradient = the SAME kernel run on the 180-degree-rotated, transposed
+    weights (a 3x3 'SAME' stride-1 correlation is its own adjoint up to that re-packing; for a stride-2
+    layer the incoming gradient is first spread onto the input grid, m4d_dilate2); weight gradient = the
+    fp32-MFMA kernel of csrc/m4d_wgrad.hip (K = pixels, fixed-order two-stage reduction).  No MIOpen /
+    framework convolution is left in the training step;
   * the per-pixel glue (upsampling, log/exp, parallax<->depth) is a handful of elementwise
     torch ops on the device -- they are < 1 % of a training step.
 
 There is no CPU path: every tensor must live on the MI355X.
 """
 from __future__ import annotations
+
+import ctypes
 
 import numpy as np
 import torch
@@ -50,20 +53,13 @@ def _packed(cache, weight, transpose):
 
 
 class _ConvBiasAct(torch.autograd.Function):
-    """leaky_relu(conv3x3_same_tf(x, w) + bias, slope) on NHWC activations, OIHW weights."""
+    """leaky_relu(conv3x3_same_tf(x, w) + bias, slope) on NHWC activations, OIHW weights (channels-last strides)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, slope, cache):
-        b, h, w, cin = x.shape
         cout = weight.shape[0]
-        if cin >= 8:
-            wp, n_pad = _packed(cache, weight, False)
-            out = nops.conv3x3_bias_act(x, wp, bias.detach(), cout, n_pad, slope, stride=stride)
-        else:
-            pt, pb, pl, pr = _same_pads(h, w, stride)
-            xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
-            y = F.conv2d(xn, weight, None, stride, 0).permute(0, 2, 3, 1).contiguous()
-            out = nops.bias_act_(y, bias.detach(), slope)
+        wp, n_pad = _packed(cache, weight, False)
+        out = nops.conv3x3_bias_act(x, wp, bias.detach(), cout, n_pad, slope, stride=stride)
         ctx.save_for_backward(x, weight, out)
         ctx.cfg = (stride, slope, cache)
         return out
@@ -74,6 +70,7 @@ class _ConvBiasAct(torch.autograd.Function):
         stride, slope, cache = ctx.cfg
         b, h, w, cin = x.shape
         cout = weight.shape[0]
+        oh, ow = out.shape[1:3]
         g = as_f32(g, "grad")
         rows = g.numel() // cout
         # epilogue backward: leaky_relu mask (tf.nn.leaky_relu: features > 0 ? g : alpha*g) + bias gradient, one pass
@@ -83,28 +80,28 @@ class _ConvBiasAct(torch.autograd.Function):
         check(lib.m4d_bias_act_bwd(dptr(g, "grad"), dptr(out), rows, cout, float(slope), dptr(gp), dptr(g_bias), dptr(ws),
                                    stream_ptr()), "m4d_bias_act_bwd")
         g = gp
-        need_x = ctx.needs_input_grad[0]
         g_x = None
-        mfma_dgrad = need_x and stride == 1 and cout >= 8
-        if mfma_dgrad:
-            # adjoint of a stride-1 'SAME' 3x3 correlation = the same correlation with k'[ky,kx,o,i] = k[2-ky,2-kx,i,o]
+        if ctx.needs_input_grad[0]:
+            # adjoint of a 'SAME' 3x3 correlation = the stride-1 correlation with k'[ky,kx,o,i] = k[2-ky,2-kx,i,o] of the
+            # gradient (stride 2: of the gradient spread onto the input grid with zeros in between)
             wp, n_pad = _packed(cache, weight, True)
             zero = cache.get(("zero", cin))
             if zero is None:
                 zero = torch.zeros(cin, dtype=torch.float32, device=x.device)
                 cache[("zero", cin)] = zero
-            g_x = nops.conv3x3_bias_act(g, wp, zero, cin, n_pad, 1.0, stride=1)
-        pt, pb, pl, pr = _same_pads(h, w, stride)
-        xn = x.permute(0, 3, 1, 2)
-        if pt or pb or pl or pr:
-            xn = F.pad(xn, (pl, pr, pt, pb))
-        mask = [bool(need_x and not mfma_dgrad), bool(ctx.needs_input_grad[1]), False]
+            gd = g
+            if stride == 2:
+                gd = torch.empty((b, h, w, cout), dtype=torch.float32, device=g.device)
+                check(lib.m4d_dilate2(dptr(g), b, oh, ow, cout, h, w, dptr(gd), stream_ptr()), "m4d_dilate2")
+            g_x = nops.conv3x3_bias_act(gd, wp, zero, cin, n_pad, 1.0, stride=1)
         g_w = None
-        if mask[0] or mask[1]:
-            gi, g_w, _ = torch.ops.aten.convolution_backward(
-                g.permute(0, 3, 1, 2), xn, weight, None, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1, mask)
-            if mask[0]:
-                g_x = gi[:, :, pt:pt + h, pl:pl + w].permute(0, 2, 3, 1).contiguous()
+        if ctx.needs_input_grad[1]:
+            # gradient in the parameter's own memory layout: OIHW tensor with channels-last strides = [O][ky][kx][I]
+            g_w = torch.empty_strided(tuple(weight.shape), (9 * cin, 1, 3 * cin, cin), dtype=torch.float32, device=x.device)
+            n_ws = int(lib.m4d_conv3x3_wgrad_workspace_floats(b, h, w, cin, cout, stride))
+            wsg = nops._workspace("wgrad", 4 * n_ws, x.device)
+            check(lib.m4d_conv3x3_wgrad(dptr(x), dptr(g), b, h, w, cin, cout, stride, dptr(wsg), n_ws,
+                                        ctypes.c_void_p(g_w.data_ptr()), stream_ptr()), "m4d_conv3x3_wgrad")
         return g_x, g_w, g_bias, None, None, None
 
 

@@ -175,3 +175,57 @@ def test_bias_act_backward_kernel(M, dev):
         want = g * np.where(out > 0, F(1.0), F(0.1))
         assert np.array_equal(npy(gp), want)
         np.testing.assert_allclose(npy(gb), want.sum(axis=0, dtype=np.float64), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,stride", [
+    (2, 16, 24, 32, 64, 1),       # whole 32-blocks
+    (1, 9, 21, 122, 96, 1),       # ragged tiles, Cin not a multiple of 4 (the training graph's exact-width refiner input)
+    (3, 12, 16, 16, 16, 2),       # stride 2, even size: TF pads bottom / right only
+    (1, 11, 13, 64, 64, 2),       # stride 2, odd sizes: one before, one after
+    (2, 20, 28, 3, 16, 1),        # the 3-channel image layer
+    (1, 6, 10, 470, 128, 1),      # the widest refiner input
+])
+def test_conv_backward_kernels_match_float64_autodiff(M, dev, b, h, w, cin, cout, stride):
+    """training._ConvBiasAct (forward MFMA convolution; backward = bias/activation kernel, data gradient through the MFMA
+    convolution on rotated weights (+ m4d_dilate2 for stride 2), weight gradient through m4d_conv3x3_wgrad) against
+    float64 autodiff of the same TF-'SAME' convolution on the CPU.  Tolerance: 2e-5 of the largest gradient entry (float32
+    sums over up to b*h*w pixels / 9*Cout products)."""
+    import torch.nn.functional as TF
+    from m4depth_amd import training as TR
+    rng = np.random.default_rng(cin * 3 + cout + stride)
+    x = rng.standard_normal([b, h, w, cin]).astype(F)
+    k = (rng.standard_normal([cout, cin, 3, 3]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = (0.1 * rng.standard_normal([cout])).astype(F)
+    oh, ow = -(-h // stride), -(-w // stride)
+    gout = rng.standard_normal([b, oh, ow, cout]).astype(F)
+    # float64 reference
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    kr = torch.from_numpy(k).double().requires_grad_(True)
+    br = torch.from_numpy(bias).double().requires_grad_(True)
+    ph = max((oh - 1) * stride + 3 - h, 0)
+    pw = max((ow - 1) * stride + 3 - w, 0)
+    xp = TF.pad(xr.permute(0, 3, 1, 2), (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    yr = TF.leaky_relu(TF.conv2d(xp, kr, br, stride, 0), 0.1).permute(0, 2, 3, 1)
+    (yr * torch.from_numpy(gout).double()).sum().backward()
+    # the product's autograd node
+    xd = to_dev(x, dev).requires_grad_(True)
+    wd = torch.nn.Parameter(to_dev(k, dev).contiguous(memory_format=torch.channels_last))
+    bd = torch.nn.Parameter(to_dev(bias, dev))
+    yd = TR._ConvBiasAct.apply(xd, wd, bd, stride, 0.1, {})
+    np.testing.assert_allclose(npy(yd), yr.detach().numpy(), atol=2e-5 * float(yr.abs().max()))
+    (yd * to_dev(gout, dev)).sum().backward()
+    assert wd.grad.shape == wd.shape
+    _close(npy(wd.grad), kr.grad.numpy(), 2e-5, "weight gradient")
+    _close(npy(bd.grad), br.grad.numpy(), 2e-5, "bias gradient")
+    _close(npy(xd.grad), xr.grad.numpy(), 2e-5, "data gradient")
+    # deterministic: a second backward gives the same bits
+    wd.grad = None
+    xd.grad = None
+    yd2 = TR._ConvBiasAct.apply(xd, wd, bd, stride, 0.1, {})
+    (yd2 * to_dev(gout, dev)).sum().backward()
+    assert torch.equal(yd2, yd)
+    g1 = wd.grad.clone()
+    wd.grad = None
+    yd3 = TR._ConvBiasAct.apply(xd, wd, bd, stride, 0.1, {})
+    (yd3 * to_dev(gout, dev)).sum().backward()
+    assert torch.equal(wd.grad, g1)
