@@ -1017,6 +1017,12 @@ class GraphedSequence:
     def _run(self):
         return self.model([self._samples(), self.camera])["depth"]
 
+    def input_buffers(self):
+        """The graph's static input tensors ({"RGB_im", "rot", "trans", "camera": {"f", "c"}}): a producer (data loader,
+        host-to-device copy) that writes the next batch straight into them and passes them back to ``__call__`` skips the
+        device-to-device hand-over copies (``__call__`` only copies tensors that live elsewhere)."""
+        return dict(self.static, camera=self.camera)
+
     def _check(self, name, got, want):
         if tuple(got.shape) != tuple(want.shape):
             raise ValueError(f"GraphedSequence: {name} has shape {tuple(got.shape)}, the graph was captured for {tuple(want.shape)}")

@@ -70,7 +70,7 @@ def main():
     F_st = (F_in + 7) // 8 * 8
     f_front = torch.zeros((b, h, w, F_st), device=dev)
     norm_out = torch.empty_like(c1)
-    bytes_["front"] = int(px * (4 * (3 * C + 1 + F_in + 6) + 6))
+    bytes_["front"] = int(px * (4 * (3 * C + 1 + F_in) + 5))
 
     def run_front():
         pp = prev_l["parallax"] if prev_l is not None else None
