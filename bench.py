@@ -313,11 +313,16 @@ def main():
 
     # Per-kernel timing: the SAME workload, eager launches bracketed by HIP events on the
     # launch stream (events cannot bracket nodes of a replayed graph), right after the timed region.
+    # Every timed eager step is queued behind a GPU-side spin (torch.cuda._sleep): the host enqueues the step's launches and
+    # event records while the GPU spins, so an event pair brackets the kernel's execution, not the host's launch latency
+    # (without it the small kernels of the coarse levels read 3-10x too long: the GPU runs ahead of the eager host loop).
     if not args.no_kernel_timing:
         timer.enabled = True
+        spin_cycles = int(60e6 * max(1, args.batch) ** 0.5)
         for _ in range(min(args.steps, 5)):
+            torch.cuda._sleep(spin_cycles)
             model.test_step(data)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         timer.enabled = False
 
     if rank != 0:
@@ -413,6 +418,8 @@ def main():
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_frame": hp_bytes, "us_per_frame": round(t_all * 1e6, 1),
                 "us_per_frame_by_kernel": {k: round(v * 1e6, 1) for k, v in sorted(per_kernel.items())},
+                "us_per_launch_by_kernel_and_level": {f"{k[0]}.{k[1]}": round(v[1] * 1e6, 1) for k, v in sorted(summ.items(), key=lambda kv: str(kv[0]))
+                                                      if k[0] in HOT_KERNELS},
                 "frac_excluding_tail": round(hp_bytes / t_no_tail / 1e9 / HBM_PEAK_GBS, 4) if t_no_tail > 0 else None,
                 "note": "SURVEY 8(d) bytes of one full frame (all levels; x batch) / the summed HIP-event time of the hand-written "
                         "level kernels of that frame (level_pre + normalise, DSCV, SNCV, refiner tail) / 8 TB/s.  The tail kernel "
