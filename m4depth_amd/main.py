@@ -49,6 +49,9 @@ def build_parser():
                         "file, e.g. pretrained_weights/midair): used instead of <ckpt_dir>/train for the initial weights")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--graph", action="store_true", help="replay the sequence forward from a hipGraph")
+    p.add_argument("--host_input", action="store_true",
+                   help="synthetic eval: hand every batch over from pinned HOST memory (the PCIe copy is part of the step) and "
+                        "print the frames/s of the loop -- the PCIe-inclusive rate, next to bench.py's HBM-resident one")
     p.add_argument("--learning_rate", type=float, default=1e-4, help="Adam step size (main.py:88)")
     p.add_argument("--save_every", type=int, default=0, help="train: checkpoint every N steps (0 = at the end)")
     # ablation flags, spelled as in m4depth_options.py:67-84
@@ -63,16 +66,26 @@ def ablation_from_args(args):
                                      not args.no_level_memory)                  # m4depth_options.py:96-98
 
 
-def synthetic_batches(args, rank, world, dev):
+def synthetic_batches(args, rank, world, dev, on_host=False):
+    """``on_host``: the batch stays in pinned host memory (the consumer uploads it: PCIe inside the step)."""
     lo, hi = D.shard_range(args.batch_size, rank, world)
     h, w = args.height or 384, args.width or 1280
+    put = (lambda t: t.pin_memory()) if on_host else (lambda t: t.to(dev))
     for i in range(args.n_batches):
         samples, cam = S.make_sequence(args.batch_size, args.seq_len, h, w, seed=args.seed + i)
-        data = {k: torch.from_numpy(np.stack([s[k][lo:hi] for s in samples], axis=1)).to(dev)
+        data = {k: put(torch.from_numpy(np.stack([s[k][lo:hi] for s in samples], axis=1)))
                 for k in ("depth", "RGB_im", "rot", "trans")}
         data["new_traj"] = torch.from_numpy(np.stack([s["new_traj"][lo:hi] for s in samples], axis=1))
-        data["camera"] = {k: torch.from_numpy(v[lo:hi]).to(dev) for k, v in cam.items()}
+        data["camera"] = {k: put(torch.from_numpy(v[lo:hi])) for k, v in cam.items()}
         yield data
+
+
+def _upload(data, dev):
+    """Host-resident batch -> device (non-blocking copies on the current stream); new_traj stays on the host."""
+    out = {k: (v.to(dev, non_blocking=True) if isinstance(v, torch.Tensor) and k != "new_traj" else v) for k, v in data.items()
+           if k != "camera"}
+    out["camera"] = {k: v.to(dev, non_blocking=True) for k, v in data["camera"].items()}
+    return out
 
 
 def dataset_batches(args, usecase, rank, world, dev):
@@ -194,11 +207,22 @@ def main(argv=None):
     model.compile(metrics=default_metrics())
     runner = None
     preds = []
+    host_input = args.host_input and args.dataset == "synthetic" and args.mode != "predict"
     if args.dataset == "synthetic":
-        batches = synthetic_batches(args, rank, world, dev)
+        batches = synthetic_batches(args, rank, world, dev, on_host=host_input)
+        if host_input:
+            batches = list(batches)                # generation is not part of the measured loop
     else:
         batches, _ = dataset_batches(args, "predict" if args.mode == "predict" else "eval", rank, world, dev)
-    for data in batches:
+    import time
+    n_frames, t_loop = 0, None
+    for batch_idx, data in enumerate(batches):
+        if host_input:
+            if batch_idx == 1:                                 # the first batch is the warm-up (allocations, graph capture)
+                torch.cuda.synchronize()
+                t_loop, n_frames = time.perf_counter(), 0
+            data = _upload(data, dev)
+            n_frames += data["RGB_im"].shape[0] * data["RGB_im"].shape[1]
         if data["RGB_im"].dim() == 4:            # streaming frame of a real dataset (db_seq_len None)
             if args.mode == "predict":
                 preds.append(model.predict_step(data)["depth"].cpu().numpy())
@@ -225,6 +249,12 @@ def main(argv=None):
             os.makedirs(args.ckpt_dir, exist_ok=True)
             np.save(os.path.join(args.ckpt_dir, "predictions.npy"), np.concatenate(preds, axis=0))
         return 0
+    if host_input and t_loop is not None:
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t_loop
+        if rank == 0 and n_frames:
+            print(f"host-resident input (pinned memory, PCIe copy inside the step): {n_frames / dt:.1f} frames/s per rank "
+                  f"over {n_frames} frames")
     gathered = D.all_gather_metric_states(model.compiled_metrics, dev)
     metrics = D.reduce_metric_states(gathered).cpu().numpy()
     if rank == 0:

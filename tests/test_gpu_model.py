@@ -343,3 +343,18 @@ def test_fullsize_configs_properties(dev, H, Wd, rd, rs, name):
     # deterministic: a second run from the same state gives the same bits
     model.reset_state()
     assert torch.equal(model([ds, dc])["depth"], out)
+
+
+def test_main_eval_with_host_resident_input(dev, tmp_path, capsys):
+    """python -m m4depth_amd.main --mode=eval --host_input: the batch is handed over from pinned host memory every step
+    (PCIe inside the loop); same metrics file as the HBM-resident run, bit for bit, plus the PCIe-inclusive rate."""
+    from m4depth_amd import main as MAIN
+    common = ["--mode", "eval", "--arch_depth", "3", "--seq_len", "3", "--batch_size", "2", "--n_batches", "3",
+              "--height", "64", "--width", "96"]
+    assert MAIN.main(common + ["--ckpt_dir", str(tmp_path / "a")]) == 0
+    assert MAIN.main(common + ["--ckpt_dir", str(tmp_path / "b"), "--host_input", "--graph"]) == 0
+    out = capsys.readouterr().out
+    assert "host-resident input" in out and "frames/s" in out
+    a = np.loadtxt(tmp_path / "a" / "perfs-synthetic.txt")
+    b = np.loadtxt(tmp_path / "b" / "perfs-synthetic.txt")
+    assert a.shape == (7,) and np.array_equal(a, b)
