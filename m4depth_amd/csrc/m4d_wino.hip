@@ -846,12 +846,13 @@ extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, cons
   }
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 32)), (unsigned)b);
   // Kernel 4 (512 threads, 64 couts, one workgroup per CU) where its grid still fills the chip and the K loop is long
-  // enough to pay for its prologue (tools/bench_wino_variants.py: 3-13 % faster from 240 workgroups up, slower at 120 and
-  // for 2-chunk layers); otherwise kernel 2 (twice as many, smaller workgroups).  Same results bit for bit.
+  // enough to pay for its prologue (tools/bench_wino_variants.py: 3-13 % faster from 240 workgroups up; in isolation slower at 120 and
+  // for 2-chunk layers; inside the pipelined step, where other frames' kernels share the chip, it pays from ~100 workgroups:
+  // +0.5 % frames/s at batch 1, round 2); otherwise kernel 2 (twice as many, smaller workgroups).  Same results bit for bit.
   // M4D_WINO_VARIANT=2 forces kernel 2, M4D_WINO4_MIN_WG moves the threshold.
   static int variant = -1, min_wg4 = -1;
   if (variant < 0) { const char* e = getenv("M4D_WINO_VARIANT"); variant = e ? atoi(e) : 4; }
-  if (min_wg4 < 0) { const char* e = getenv("M4D_WINO4_MIN_WG"); min_wg4 = e ? atoi(e) : 200; }
+  if (min_wg4 < 0) { const char* e = getenv("M4D_WINO4_MIN_WG"); min_wg4 = e ? atoi(e) : 100; }
   if (variant == 4 && CoutPad % 64 == 0 && Cin >= 32 && Cin % 8 == 0 && (long long)a.tiles_x * a.tiles_y * (CoutPad / 64) * b >= min_wg4) {
     constexpr size_t lds4 = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);              // epilogue staging 147 KB (K loop: 126 KB)
     static_assert(lds4 >= (size_t)(2 * kRawF + 2 * kVF) * sizeof(float), "epilogue staging must cover the K-loop buffers");

@@ -42,6 +42,13 @@ kernel_timer = None
 winograd_conv = _os.environ.get("M4D_WINOGRAD", "1") == "1"
 
 
+# Smallest grid (workgroups of Winograd kernel 2) for which a layer leaves the direct convolution.  Round 1 used 200 (a
+# launch that fills the chip on its own); inside the frame pipeline the chip is shared with other frames' kernels anyway and
+# the 2.25x fewer MFMA flops win from 60 workgroups on: level 3 of the 384x1280 pyramid (30 tiles x 2-4 N-tiles) moves to
+# Winograd, +2 % frames/s at batch 1 (1050 -> 1074; 30: 1047).
+winograd2_min_workgroups = int(_os.environ.get("M4D_WINO2_MIN_WG", "60"))
+
+
 def _use_winograd(b, h, w, cin, cout, stride):
     """0 = direct convolution; 1 = Winograd kernel 1 (16x8 tile, 16-channel chunks, 2 N-tiles per workgroup);
     2 = kernel 2 (16x16 tile, 8-channel chunks: half the weight traffic per flop -- ahead on the large maps).
@@ -51,7 +58,7 @@ def _use_winograd(b, h, w, cin, cout, stride):
     if not winograd_conv or stride != 1 or cin < 16 or cin % 2 != 0:
         return 0
     n32 = -(-cout // 32)
-    if cin % 4 == 0 and b * (-(-h // 16)) * (-(-w // 16)) * n32 >= 200:
+    if cin % 4 == 0 and b * (-(-h // 16)) * (-(-w // 16)) * n32 >= winograd2_min_workgroups:
         return 2
     t8 = b * (-(-h // 8)) * (-(-w // 16))
     if cout % 64 == 0 and t8 * (cout // 64) >= 400:
@@ -194,6 +201,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self._cache = _PackCache()
         self.tag = None                  # e.g. "lvl1.conv1": lets bench.py bracket one layer with HIP events
         self.small_maps_ok = False       # DispRefiner layers: may take the one-launch small-map kernel
+        self.per_image_dispatch = False  # encoder layers: kernel choice from the per-image grid (see forward)
         if in_channels is not None:
             self._build(in_channels, None)
 
@@ -260,7 +268,10 @@ class _Conv3x3SameTF(torch.nn.Module):
                 raise ValueError(f"stride {self.stride} is not supported by the HIP convolution")
             b_, h_, w_, cin_ = x_nhwc.shape
             act = 1.0 if slope is None else slope
-            wino = _use_winograd(b_, h_, w_, cin_, self.out_channels, self.stride)
+            # The encoder is run on frames stacked along the batch axis, and how many are stacked depends on the launch mode
+            # (all T frames, two batches in the pipelined forward, one frame when streaming): its kernel choice must not
+            # depend on that, or the modes stop being bit-identical -- decide from the per-image grid.
+            wino = _use_winograd(1 if self.per_image_dispatch else b_, h_, w_, cin_, self.out_channels, self.stride)
             if wino:
                 wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8, cin_)     # cin_ > Cin: zero-padded input
                 fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
@@ -325,6 +336,8 @@ class FeaturePyramid(torch.nn.Module):
         self.conv_layers_s1 = torch.nn.ModuleList([_Conv3x3SameTF(n, 1, ci) for n, ci in zip(self.out_sizes, cin)])
         self.conv_layers_s2 = torch.nn.ModuleList([_Conv3x3SameTF(n, 2, n) for n in self.out_sizes])
         self.dn_layers = torch.nn.ModuleList([DomainNormalization(regularizer_weight) for _ in self.out_sizes])
+        for conv in list(self.conv_layers_s1) + list(self.conv_layers_s2):
+            conv.per_image_dispatch = True
 
     def forward(self, images):
         """``images``: [b,H,W,3], or a ``network_ops.FrameStack`` (the frames of a sequence batch, encoded in one pass)."""
