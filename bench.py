@@ -15,10 +15,10 @@ batch 1); N > 1 GPUs -> configs[3] (global batch 32 N: 32 sequences per rank, 25
 ``value`` = all frames processed by all ranks / max-over-ranks time.
 
 The JSON line also carries
-  roofline          -- the dominant kernel of the step, the level-1 refiner 128->128 convolution (Winograd F(2x2,3x3) on
-                       fp32 MFMA): the MFMA flops the kernel EXECUTES / HIP-event time on the launch stream, against the
-                       157.3 TFLOP/s fp32-MFMA peak (frac <= 1); the layer's algorithmic (direct-convolution) rate is a
-                       side field;
+  roofline          -- the dominant kernel of the step, the level-1 refiner 128->128 convolution (Winograd F(2x2,3x3),
+                       float32 operands split into three bf16 terms on the bf16 matrix cores): the MFMA flops the kernel
+                       EXECUTES / HIP-event time on the launch stream, against the dense peak of the MFMA type it issues
+                       (frac <= 1); the float32-equivalent and algorithmic (direct-convolution) rates are side fields;
   roofline_hotpath  -- SURVEY 8(d): the hot path's algorithmic bytes per full frame (106.72 MB at the default config) /
                        the summed time of the hand-written level kernels of one full frame / 8 TB/s;
   roofline_<kernel> -- the level-1 cost-volume kernels alone, algorithmic bytes / time against the 8 TB/s HBM3E peak;
@@ -45,6 +45,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= fp32 vector peak), MI355X_MICROARCH.md
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity), MI355X_MICROARCH.md
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 HOT_KERNELS = ("pre", "front", "dscv", "sncv", "dscv_sncv", "tail", "post", "resize")     # network._timed names of the hot path
 
@@ -336,6 +337,12 @@ def main():
         "metric": "frames/s", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "dtype_note": "every tensor, operand and accumulator is float32 (the reference's float16 DSCV products excepted, as in "
+                      "the reference).  The wide Winograd convolutions feed the bf16 matrix cores with float32 operands split "
+                      "EXACTLY into three bf16 terms (6 of the 9 term products, float32 accumulation): float32 accuracy -- "
+                      "measured error against float64 0.8x that of the fp32-MFMA kernels (profiles/r02_bf16_split_probe.txt, "
+                      "tools/bench_wino6.py; parity.vs_float64_oracle below) -- not a reduced-precision path; "
+                      "M4D_CONV_ARITH=f32 runs the fp32-MFMA kernels instead",
         "data": "synthetic", "per_gpu": round(value / world, 2),
         "full_frames_per_s": round(value * (args.seq_len - 1) / args.seq_len, 2),
         "metric_note": "value counts every frame of the sequence the reference's test_step processes, including frame 0, "
@@ -345,8 +352,9 @@ def main():
                                f"dscv_range={args.dscv_range} sncv_range={args.sncv_range} batch {args.batch}/GPU = {cfg_name}",
                    "global_batch": world * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
                    "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",
-                   "kernels": "every kernel of the captured forward is hand-written HIP (libm4depth_hip.so, gfx950): fp32-MFMA "
-                              "convolutions with fused bias+leaky-relu (Winograd F(2x2,3x3) on the wide stride-1 layers, direct "
+                   "kernels": "every kernel of the captured forward is hand-written HIP (libm4depth_hip.so, gfx950): MFMA "
+                              "convolutions with fused bias+leaky-relu (Winograd F(2x2,3x3) on the wide stride-1 layers -- float32 "
+                              "operands as exact 3 x bf16 splits on the bf16 matrix cores, or fp32 MFMA --, direct fp32-MFMA "
                               "implicit GEMM elsewhere), fused encoder head / refiner tail, the level kernels; no MIOpen, rocBLAS "
                               "or PyTorch kernel in the graph (torch only launches the 7-metric kernel's host wrapper eagerly)",
                    "hot_path": "libm4depth_hip.so (HIP, gfx950)"},
@@ -372,19 +380,32 @@ def main():
             n, sec = conv
             wino = net._use_winograd(args.batch, h1, w1, 128, 128, 1)
             flops_direct = 2.0 * 9 * 128 * 128 * h1 * w1 * args.batch
-            flops_exec = 2.0 * 16 * 128 * 128 * ((h1 + 1) // 2) * ((w1 + 1) // 2) * args.batch if wino else flops_direct
+            flops_wino = 2.0 * 16 * 128 * 128 * ((h1 + 1) // 2) * ((w1 + 1) // 2) * args.batch      # one multiply-add per (position, cin, cout)
+            if wino == 6:           # float32 operands as 3 bf16 terms each: 6 bf16 MFMA products per float32 multiply
+                flops_exec, peak, key = 6.0 * flops_wino, BF16_MFMA_PEAK_TFLOPS, "wino6_l1_128_128"
+                kname = ("conv3x3_wino6_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3), float32 operands split into 3 bf16 "
+                         "terms, 6 bf16 MFMA products each, float32 accumulate; bias+leaky-relu fused)")
+            elif wino:
+                flops_exec, peak, key = flops_wino, FP32_MFMA_PEAK_TFLOPS, "wino_l1_128_128"
+                kname = "conv3x3_wino4_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3) on fp32 MFMA, bias+leaky-relu fused)"
+            else:
+                flops_exec, peak, key = flops_direct, FP32_MFMA_PEAK_TFLOPS, "conv_l1_128_128"
+                kname = "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)"
             tf_exec = flops_exec / sec / 1e12
-            key = "wino_l1_128_128" if wino else "conv_l1_128_128"
             out["roofline"] = {
-                "kernel": ("conv3x3_wino4_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3) on fp32 MFMA, bias+leaky-relu fused)"
-                           if wino else "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)"),
-                "bound": "mfma", "achieved": round(tf_exec, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf_exec / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": tr(key),
+                "kernel": kname, "bound": "mfma", "achieved": round(tf_exec, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(tf_exec / peak, 4), "traffic": tr(key),
                 "traffic_kernel": None if key not in traffic else traffic[key].get("kernel"),
                 "executed_mfma_flops_per_launch": flops_exec,
-                "note": "achieved / frac = MFMA flops the kernel executes (2*16*Cin*Cout per 2x2 output tile for Winograd; the "
-                        "direct kernel executes the algorithmic 2*9*Cin*Cout per pixel) / time; algorithmic_* prices the layer's "
-                        "direct-convolution flops over the same time (> peak is possible for Winograd: 2.25x fewer multiplies)",
+                "note": "achieved / frac = MFMA flops the kernel executes / time against the dense peak of the MFMA type it issues "
+                        "(bf16 2500 TFLOP/s for the split kernel: 6 bf16 products per float32 multiply-add of the Winograd form, "
+                        "2*16*Cin*Cout per 2x2 output tile; fp32 MFMA 157.3 otherwise).  The split kernel is balanced between the "
+                        "matrix core and the VALU work of the exact 3-way operand split (7.5 instructions per transformed input "
+                        "element), so its MFMA fraction is low by design; float32_equivalent_tflops = the float32 multiply-adds of "
+                        "the Winograd form it replaces / time (fp32-MFMA peak 157.3), algorithmic_* = the layer's "
+                        "direct-convolution flops / time",
+                "float32_equivalent_tflops": round(flops_wino / sec / 1e12, 2) if wino else round(tf_exec, 2),
+                "float32_equivalent_frac_of_fp32_mfma_peak": round((flops_wino if wino else flops_direct) / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 "algorithmic_flops_per_launch": flops_direct,
                 "algorithmic_tflops": round(flops_direct / sec / 1e12, 2),
                 "algorithmic_bytes_per_launch": 4 * (2 * 128 * h1 * w1 * args.batch + 9 * 128 * 128),

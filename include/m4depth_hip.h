@@ -162,6 +162,14 @@ int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, const float* bi
  * per K chunk (first 40), at chunk start / after the first barrier / after the input transform / after the second barrier /
  * after the MFMA loop.  NULL switches it off. */
 void m4d_wino_set_stamps(unsigned long long* device_buffer);
+/* The same convolution with float32 operands on the BF16 matrix cores: every float32 operand is the exact sum of three
+ * bf16 terms, six of the nine term products are accumulated in float32 (the dropped ones are below float32's product
+ * rounding): float32 accuracy at 2.67x less matrix-core time.  wu6 = the transformed filter split and packed on the host
+ * (network_ops.pack_conv_weights_wino6: [Cin/16][CoutPad/64][16][2][3][64][8] bf16); Cin % 16 == 0, CoutPad % 64 == 0.
+ * Replaces the same tf.keras Conv2D + leaky_relu pairs as m4d_conv3x3_wino2_bias_act (m4depth_network.py:101-131). */
+int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
+                               int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
+void m4d_wino6_set_stamps(unsigned long long* device_buffer);
 
 /* The tail of a level in one kernel: the last two DispRefiner convolutions (32 -> 16 + leaky_relu(0.1), 16 -> 5;
  * m4depth_network.py:109-135) and m4d_level_post (:247-260).  x32 [b,h,w,32]; w6p [9][16][32] = kernel[ky][kx][k][n] as

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "m4d_conv3x3_small_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino2_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
+    "m4d_conv3x3_wino6_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_enc_head_fwd": [_c_fp, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int,
                          _c_fp, _c_fp, _c_fp],
     "m4d_conv3x3s2_dinl_bias_act": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_f, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -98,7 +99,7 @@ _LL_SIGNATURES = {"m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_in
                   "m4d_conv3x3_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]}
 _VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
                     "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp], "m4d_wino_set_stamps": [_c_fp],
-                    "m4d_front_set_stamps": [_c_fp]}
+                    "m4d_front_set_stamps": [_c_fp], "m4d_wino6_set_stamps": [_c_fp]}
 
 EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES) + list(_VOID_SIGNATURES) + list(_LL_SIGNATURES)
 

@@ -1,0 +1,427 @@
+// 3x3 stride-1 'SAME' convolution + bias + leaky_relu: Winograd F(2x2,3x3) with FLOAT32 operands on the BF16 matrix cores.
+//
+// fp32 MFMA (m4d_wino.hip) runs at the float32 vector rate, 1/16 of the bf16 MFMA rate.  Every float32 number is EXACTLY the
+// sum of three bf16 numbers (8 + 8 + 8 significand bits: p1 = bf16(v), p2 = bf16(v - p1), p3 = (v - p1) - p2, round to
+// nearest), and a bf16 x bf16 product is exact in the matrix core's float32 accumulator, so
+//     a * b = sum_{i,j} a_i b_j     (9 terms);   dropping a2 b3, a3 b2, a3 b3 (each <= 2^-26 |a b|, below float32's own
+//                                                product rounding) leaves 6 bf16 MFMAs per 16 k
+// -- 6 x 32 cycles against 8 x 64 for v_mfma_f32_32x32x2_f32: 2.67x less matrix-core time at float32 accuracy (measured:
+// error against float64 0.8x that of the fp32 MFMA chain, no bias: tools/micro/bf16_split_probe.hip,
+// profiles/r02_bf16_split_probe.txt).  The filter transform U = G g G^T is split on the host (pack_conv_weights_wino6);
+// the input transform V = B^T d B is computed and split in registers by the wave that multiplies it.
+//
+// Workgroup = 4 waves, ONE PER SIMD (512 registers each), = a 16x16-pixel output tile (64 Winograd tiles = two MFMA M-tiles)
+// x 64 output channels (two N-tiles).  Wave r owns row r of the 4x4 Winograd positions: 4 positions x 2 M x 2 N = 16
+// accumulators (256 AGPRs).  Its A operands need no exchange: V[r][c] of a tile depends on two raw rows of that tile only,
+// so lane (tile m, k-half) reads those 2 x 4 pixels x 8 channels from the raw halo in LDS, forms t_c = d[ra][c] +- d[rb][c]
+// once per 16-channel chunk (64 registers), and per position V = t_c +- t_c', the 3-way split and the packing (7.5 VALU
+// operations per element -- the kernel is balanced between the VALU and the matrix core, not MFMA-bound any more).  B
+// operands (the split U) come straight from L2 in fragment order (1 KB per (position, N-tile, part), 16 bytes per lane).
+// LDS holds only the raw halo (double buffered, 23 KB each), laid out [channel quad][row][column parity][column / 2] so that
+// the 16-byte reads of a wave are conflict-free; one barrier per chunk.  Epilogue as in kernel 4 of m4d_wino.hip: rows of
+// A^T (M A) through LDS, bias + leaky_relu, 16-byte stores.  Deterministic: fixed summation order, no atomics.
+#include <cstdlib>
+#include "m4d_common.h"
+#include "../../include/m4depth_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Wino6Args {
+  const float* x; const unsigned char* wu; const float* bias; float* out;
+  int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
+  float slope;
+  unsigned long long* stamps;   // profiling only (m4d_wino_set_stamps): per workgroup: start, end of K loop, end
+};
+
+constexpr int kT = 16, kH = kT + 2;              // output tile, halo (pixels)
+constexpr int kJ = 10;                           // 16-byte slots per (row, column parity): 9 used; 2 * kJ = 20 = 4 mod 8 makes
+constexpr int kRow = 2 * kJ;                     //   two rows = 8 slots mod 16: every 16-lane read group covers 16 distinct slots
+constexpr int kQuad = kH * kRow;                 // slots per channel quad (360)
+constexpr int kRawSlots = 4 * kQuad;             // per chunk of 16 channels: 1440 slots = 23040 B
+constexpr int kRawF4 = kH * kH * 4;              // float4 loads per chunk (1296) over 256 threads: 5 full rounds + 16
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  bf16x2 v; v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float lo_f32(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float hi_f32(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// v[0..7] -> three bf16x8 operands (hi, mid, lo): v = hi + mid + lo exactly
+__device__ __forceinline__ void split8(const float* v, bf16x8& a0, bf16x8& a1, bf16x8& a2) {
+  u32x4 p0, p1, p2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x0 = v[2 * e], x1 = v[2 * e + 1];
+    const unsigned q0 = pk_bf16(x0, x1);
+    const float r0 = x0 - lo_f32(q0), r1 = x1 - hi_f32(q0);
+    const unsigned q1 = pk_bf16(r0, r1);
+    const float s0 = r0 - lo_f32(q1), s1 = r1 - hi_f32(q1);
+    p0[e] = q0; p1[e] = q1; p2[e] = pk_bf16(s0, s1);
+  }
+  a0 = __builtin_bit_cast(bf16x8, p0); a1 = __builtin_bit_cast(bf16x8, p1); a2 = __builtin_bit_cast(bf16x8, p2);
+}
+
+template <bool STAMPS, int ABL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+conv3x3_wino6_kernel(const Wino6Args a) {
+  extern __shared__ __align__(16) float lds[];
+  float4* raw = reinterpret_cast<float4*>(lds);                      // [2][kRawSlots]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int pr = __builtin_amdgcn_readfirstlane(t >> 6);             // position row of this wave (scalar)
+  const int m = lane & 31, kh = lane >> 5;
+  const int n_tiles = a.tiles_x * a.tiles_y, n_groups = a.CoutPad / 64;
+  int tile, ng;
+  {
+    const int L = blockIdx.x;
+    if ((n_tiles & 7) == 0) {                                        // consecutive workgroups go to different XCDs: keep the
+      const int xcd = L & 7, idx = L >> 3;                           // N-groups of one pixel tile on one XCD (its L2 holds the halo)
+      tile = xcd * (n_tiles >> 3) + idx / n_groups;
+      ng = idx % n_groups;
+    } else {
+      tile = L / n_groups;
+      ng = L % n_groups;
+    }
+  }
+  const int tile_y = (tile / a.tiles_x) * kT, tile_x = (tile % a.tiles_x) * kT;
+  const int bi = blockIdx.y;
+  const int n = a.n_chunks;
+  const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
+
+  // ---- raw staging: item = (halo pixel, channel quad); 6 slots per thread (the last one new for t < 16 only)
+  unsigned voff[6];
+  int dst[6];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int idx = min(s * 256 + t, kRawF4 - 1);
+    const int hp = idx >> 2, q = idx & 3;
+    const int hy = hp / kH, hx = hp - hy * kH;
+    const int gy = tile_y - 1 + hy, gx = tile_x - 1 + hx;
+    const bool ok = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    okmask |= (ok ? 1u : 0u) << s;
+    voff[s] = (unsigned)(((min(max(gy, 0), a.h - 1) * a.w + min(max(gx, 0), a.w - 1)) * a.Cin + q * 4) * 4);
+    dst[s] = q * kQuad + hy * kRow + (hx & 1) * kJ + (hx >> 1);
+  }
+  // (slot 5 of threads 16.. is the clamped last item again: same address, same value, same LDS slot -- no branch needed)
+  float4 rg[6];
+  auto load_raw_to = [&](int chunk, float4 (&r)[6]) {
+    const char* base = reinterpret_cast<const char*>(ximg) + (size_t)chunk * 64;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) r[s] = *reinterpret_cast<const float4*>(base + voff[s]);
+  };
+  auto commit_raw_from = [&](float4* rb, const float4 (&r)[6]) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const bool ok = (okmask >> s) & 1u;
+      rb[dst[s]] = ok ? r[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto load_raw = [&](int chunk, bool force = false) {
+    if ((ABL & 16) && !force) return;              // ablation 16: no raw staging in the loop
+    load_raw_to(chunk, rg);
+  };
+  auto commit_raw = [&](float4* rb, bool force = false) {
+    if ((ABL & 16) && !force) return;
+    commit_raw_from(rb, rg);
+  };
+
+  // ---- this lane's tiles: M-tile mt holds tile rows 4 mt .. 4 mt + 3; lane m = (row m >> 3, column m & 7)
+  // position row pr of B^T d uses raw rows (ra, rb) of the 4x4 input tile: d0 - d2, d1 + d2, d2 - d1, d1 - d3
+  const int ra = pr == 0 ? 0 : (pr == 2 ? 2 : 1);
+  const int rb_ = pr == 0 ? 2 : (pr == 1 ? 2 : (pr == 2 ? 1 : 3));
+  const float sgn = pr == 1 ? 1.f : -1.f;
+  const int ty0 = m >> 3, tx = m & 7;
+  // slot of (M-tile 0, raw row 0, column 0, quad 2 kh); + mt * 8 rows, + row * kRow, + (c & 1) * kJ + (c >> 1), + quad
+  const int src0 = (2 * kh) * kQuad + (2 * ty0) * kRow + tx;
+
+  float tv[2][4][8];                               // t_c of the current chunk: [M-tile][column c][channel]
+  // columns c0, c0 + 2 of t for the chunk in rbuf (two calls per chunk: the registers of columns 0, 2 are free one
+  // position earlier than those of columns 1, 3)
+  auto read_t = [&](const float4* rbuf, int c0, bool force = false) {
+    if ((ABL & 8) && !force) return;               // ablation 8: no LDS reads / t in the loop
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int c = c0 + 2 * cc;
+          const int s = src0 + qq * kQuad + (8 * mt) * kRow + (c & 1) * kJ + (c >> 1);
+          const float4 da = rbuf[s + ra * kRow], db = rbuf[s + rb_ * kRow];
+          tv[mt][c][4 * qq + 0] = __builtin_fmaf(sgn, db.x, da.x);     // exact product: one rounding, = da +- db
+          tv[mt][c][4 * qq + 1] = __builtin_fmaf(sgn, db.y, da.y);
+          tv[mt][c][4 * qq + 2] = __builtin_fmaf(sgn, db.z, da.z);
+          tv[mt][c][4 * qq + 3] = __builtin_fmaf(sgn, db.w, da.w);
+        }
+  };
+  // A operands of position (pr, c): V = (t B)_c = t0 - t2, t1 + t2, t2 - t1, t1 - t3
+  auto gen_a = [&](int c, bf16x8 (&A)[2][3], bool force = false) {
+    if ((ABL & 4) && !force) return;               // ablation 4: no input transform / split in the loop
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = c == 0 ? tv[mt][0][e] - tv[mt][2][e] : c == 1 ? tv[mt][1][e] + tv[mt][2][e]
+             : c == 2 ? tv[mt][2][e] - tv[mt][1][e] : tv[mt][1][e] - tv[mt][3][e];
+      split8(v, A[mt][0], A[mt][1], A[mt][2]);
+    }
+  };
+
+  // ---- B operands: wu[chunk][N-group][16 positions][2 N-tiles][3 parts][64 lanes][8 bf16]; this wave walks the 4
+  // positions of its row chunk after chunk: 6 KB per position, contiguous
+  const long long w_pos = 6 * 1024;
+  const long long w_chunk = (long long)n_groups * 16 * w_pos;
+  const unsigned char* wptr = a.wu + ((long long)ng * 16 + 4 * pr) * w_pos;      // uniform; position q = chunk * 4 + c
+  const unsigned wlane = (unsigned)lane * 16u;
+  bf16x8 B[2][2][3];                               // [ring][N-tile][part]
+  auto load_b = [&](const unsigned char* p, int ring, bool force = false) {
+    if ((ABL & 1) && !force) return;               // ablation 1: the B operands of the prologue only
+#pragma unroll
+    for (int f = 0; f < 6; ++f) B[ring][f / 3][f % 3] = *reinterpret_cast<const bf16x8*>(p + wlane + f * 1024);
+  };
+
+  f32x16 acc[4][2][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][mt][nt][r] = 0.f;
+
+  unsigned long long* st = (STAMPS && a.stamps != nullptr && t == 0 && blockIdx.y == 0 && blockIdx.x < 512)
+                               ? a.stamps + (long long)blockIdx.x * 4 : nullptr;
+  if (STAMPS && st) st[0] = __builtin_readcyclecounter();
+
+  // ---- prologue: raw(0), raw(1) in LDS, raw(2) in registers, t(0), A(0, 0), B(0)
+  const int last = n - 1;
+  {
+    float4 rg1[6];                                 // both first chunks in flight together
+    load_raw_to(0, rg);
+    load_raw_to(min(1, last), rg1);
+    load_b(wptr, 0, true);
+    if (ABL & 1) load_b(wptr, 1, true);
+    commit_raw_from(raw, rg);
+    commit_raw_from(raw + kRawSlots, rg1);
+  }
+  __syncthreads();
+  read_t(raw, 0, true);
+  read_t(raw, 1, true);
+  bf16x8 A[2][2][3];                               // [ring][M-tile][part]
+  gen_a(0, A[0], true);
+  if (ABL & 4) gen_a(1, A[1], true);
+  load_raw(min(2, last), true);
+
+  // epilogue operands fetched now (their latency disappears under the K loop): this thread's two output-channel quads
+  float bs[2][4];
+#pragma unroll
+  for (int ont = 0; ont < 2; ++ont)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = ng * 64 + ont * 32 + 4 * (t & 7) + e;
+      bs[ont][e] = a.bias[min(co, a.Cout - 1)];
+    }
+
+  // the 6 products of one accumulator, small terms first: (A part, B part)
+  constexpr int kTA[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int kTB[6] = {2, 0, 1, 1, 0, 0};
+#define M4D_W6_MFMAS(c, ring)                                                                                          \
+  if (!(ABL & 2))                                                                                                      \
+  _Pragma("unroll") for (int term = 0; term < 6; ++term)                                                               \
+  _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                     \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                     \
+    acc[c][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ring][mt][kTA[term]], B[ring][nt][kTB[term]],          \
+                                                              acc[c][mt][nt], 0, 0, 0);
+  // one MFMA, then `valu` vector instructions (the matrix core needs 32 cycles per MFMA: ~5 other issues fit in its shadow)
+#define M4D_W6_PIPE(n_mfma, valu, ds_first, every_dsw, every_vm)                                                       \
+  if (ds_first) __builtin_amdgcn_sched_group_barrier(0x100, ds_first, 0);                                              \
+  _Pragma("unroll") for (int i_ = 0; i_ < n_mfma; ++i_) {                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);                                                              \
+    if (every_dsw && i_ % every_dsw == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                           \
+    if (every_vm && i_ % every_vm == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                             \
+  }
+
+  // The compiler may sink pure arithmetic past a sched_barrier (only the machine scheduler honours it): an empty asm that
+  // "modifies" the freshly produced operands pins their producers inside the region they are meant to overlap with.
+  auto pin_a = [&](bf16x8 (&X)[2][3]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int part = 0; part < 3; ++part) asm volatile("" : "+v"(X[mt][part]));
+  };
+  auto pin_t = [&](int c0) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(tv[mt][c0 + 2 * cc][e]));
+  };
+
+  // Uniform loop body (no branches: one scheduling region per position).  Work past the last chunk is harmless: the
+  // surplus t / A come from a buffer nobody needs any more and are never multiplied.
+  for (int chunk = 0; chunk < n; ++chunk) {
+    const unsigned char* wnext = chunk < last ? wptr + w_chunk : wptr;            // scalar select
+    // position 0: A(1) from t1, t2
+    load_b(wptr + w_pos, 1);
+    gen_a(1, A[1]);
+    M4D_W6_MFMAS(0, 0)
+    pin_a(A[1]);
+    M4D_W6_PIPE(24, 5, 0, 0, 4)
+    __builtin_amdgcn_sched_barrier(0);
+    // position 1: A(2) from t2, t1
+    load_b(wptr + 2 * w_pos, 0);
+    gen_a(2, A[0]);
+    M4D_W6_MFMAS(1, 1)
+    pin_a(A[0]);
+    M4D_W6_PIPE(24, 5, 0, 0, 4)
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                               // raw(chunk + 1) committed by every wave; raw(chunk) no longer read
+    const float4* rnext = raw + ((chunk + 1) & 1) * kRawSlots;
+    // position 2: A(3) from t1, t3; columns 0, 2 of t(chunk + 1)
+    load_b(wptr + 3 * w_pos, 1);
+    gen_a(3, A[1]);
+    read_t(rnext, 0);
+    M4D_W6_MFMAS(2, 0)
+    pin_a(A[1]);
+    pin_t(0);
+    M4D_W6_PIPE(24, 6, 0, 0, 4)
+    __builtin_amdgcn_sched_barrier(0);
+    // position 3: columns 1, 3 of t(chunk + 1), A(chunk + 1, 0); raw(chunk + 2) -> LDS, raw(chunk + 3) -> registers
+    load_b(wnext, 0);
+    read_t(rnext, 1);
+    gen_a(0, A[0]);
+    commit_raw(raw + (chunk & 1) * kRawSlots);
+    load_raw(min(chunk + 3, last));
+    M4D_W6_MFMAS(3, 1)
+    pin_a(A[0]);
+    pin_t(1);
+    M4D_W6_PIPE(24, 7, 0, 6, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    wptr = wnext;
+  }
+#undef M4D_W6_MFMAS
+#undef M4D_W6_PIPE
+  if (STAMPS && st) st[1] = __builtin_readcyclecounter();
+  __syncthreads();                                 // every wave is done with raw: the epilogue buffer aliases it
+
+  // ---- output transform: rows of A^T (M A) through LDS per (N-tile, M-tile), then one 2x2-output item x 4 couts per thread
+  constexpr int kMS = 36;                          // row stride (floats): 32 couts + 4 pad (16-byte aligned rows)
+  constexpr int kRbMT = 4 * 2 * 32 * kMS;          // floats per (N-tile, M-tile): [4 rows i][2 k][32 tiles][kMS] = 36.9 KB
+  float* Rb = lds;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float* rbuf = Rb + (nt * 2 + mt) * kRbMT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0][mt][nt][r], m1 = acc[1][mt][nt][r], m2 = acc[2][mt][nt][r], m3 = acc[3][mt][nt][r];
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        rbuf[((pr * 2 + 0) * 32 + trow) * kMS + m] = (m0 + m1) + m2;
+        rbuf[((pr * 2 + 1) * 32 + trow) * kMS + m] = (m1 - m2) - m3;
+      }
+    }
+  __syncthreads();
+  float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+  const bool vec_ok = (a.Cout & 3) == 0;
+  const bool whole = tile_x + kT <= a.w && tile_y + kT <= a.h;      // uniform: no per-store bounds tests on interior tiles
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int item = it * 256 + t;                 // (N-tile, M-tile, tile in M-tile, cout quad)
+    const int cq = item & 7, tl = (item >> 3) & 31, mt = (item >> 8) & 1, ont = it >> 1;
+    const float* rbuf = Rb + (ont * 2 + mt) * kRbMT;
+    const int tg = mt * 32 + tl;                   // Winograd tile 0..63 of the workgroup (8 x 8)
+    const int ty2 = tg >> 3, tx2 = tg & 7;
+    const int co = ng * 64 + ont * 32 + 4 * cq;
+    float4 rv[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) rv[i][k] = *reinterpret_cast<const float4*>(rbuf + ((i * 2 + k) * 32 + tl) * kMS + 4 * cq);
+    float y[2][2][4];                              // [column k][row l][cout]
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float* r0 = reinterpret_cast<const float*>(&rv[0][k]); const float* r1 = reinterpret_cast<const float*>(&rv[1][k]);
+      const float* r2 = reinterpret_cast<const float*>(&rv[2][k]); const float* r3 = reinterpret_cast<const float*>(&rv[3][k]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v0 = ((r0[e] + r1[e]) + r2[e]) + bs[ont][e];
+        const float v1 = ((r1[e] - r2[e]) - r3[e]) + bs[ont][e];
+        y[k][0][e] = v0 > 0.f ? v0 : v0 * a.slope;
+        y[k][1][e] = v1 > 0.f ? v1 : v1 * a.slope;
+      }
+    }
+    const int ox = tile_x + 2 * tx2, oy = tile_y + 2 * ty2;
+    float* op = oimg + ((long long)oy * a.w + ox) * a.Cout + co;
+    if (whole && vec_ok && co + 3 < a.Cout) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          *reinterpret_cast<float4*>(op + ((long long)l * a.w + k) * a.Cout) = make_float4(y[k][l][0], y[k][l][1], y[k][l][2], y[k][l][3]);
+    } else if (co < a.Cout) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (ox + k < a.w && oy + l < a.h) {
+            float* o2 = op + ((long long)l * a.w + k) * a.Cout;
+            if (vec_ok && co + 3 < a.Cout) *reinterpret_cast<float4*>(o2) = make_float4(y[k][l][0], y[k][l][1], y[k][l][2], y[k][l][3]);
+            else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) o2[e] = y[k][l][e]; }
+          }
+    }
+  }
+  if (STAMPS && st) st[2] = __builtin_readcyclecounter();
+}
+
+unsigned long long* g_wino6_stamps = nullptr;
+
+}  // namespace
+
+extern "C" void m4d_wino6_set_stamps(unsigned long long* device_buffer) { g_wino6_stamps = device_buffer; }
+
+extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
+                                          int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  M4D_CHECK_ARG(x && wu6 && bias && out && b > 0 && h > 0 && w > 0 && Cin >= 16 && Cout > 0);
+  M4D_CHECK_ARG(CoutPad % 64 == 0 && CoutPad >= Cout && Cin % 16 == 0);
+  M4D_CHECK_ARG(((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu6) & 15u) == 0));
+  Wino6Args a;
+  a.x = x; a.wu = reinterpret_cast<const unsigned char*>(wu6); a.bias = bias; a.out = out;
+  a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.n_chunks = Cin / 16; a.slope = slope;
+  a.tiles_x = (w + kT - 1) / kT; a.tiles_y = (h + kT - 1) / kT;
+  a.stamps = g_wino6_stamps;
+  constexpr size_t lds = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);                 // epilogue staging 147 KB (K loop: 46 KB)
+  static_assert(lds >= (size_t)2 * kRawSlots * 16, "epilogue staging must cover the K-loop buffers");
+  static int abl = -1;                             // profiling only: M4D_WINO6_ABLATE (see the kernel)
+  if (abl < 0) { const char* e = getenv("M4D_WINO6_ABLATE"); abl = e ? atoi(e) : 0; }
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
+  auto launch = [&](auto kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  };
+  if (a.stamps) launch(&conv3x3_wino6_kernel<true, 0>);
+  else if (abl == 0) launch(&conv3x3_wino6_kernel<false, 0>);
+#ifdef M4D_W6_ABLATIONS
+  else if (abl == 1) launch(&conv3x3_wino6_kernel<false, 1>);
+  else if (abl == 2) launch(&conv3x3_wino6_kernel<false, 2>);
+  else if (abl == 3) launch(&conv3x3_wino6_kernel<false, 3>);
+  else if (abl == 4) launch(&conv3x3_wino6_kernel<false, 4>);
+  else if (abl == 12) launch(&conv3x3_wino6_kernel<false, 12>);
+  else if (abl == 28) launch(&conv3x3_wino6_kernel<false, 28>);
+  else if (abl == 29) launch(&conv3x3_wino6_kernel<false, 29>);
+  else if (abl == 31) launch(&conv3x3_wino6_kernel<false, 31>);
+#endif
+  else return (int)hipErrorInvalidValue;
+  return M4D_LAUNCH_RESULT();
+}

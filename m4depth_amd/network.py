@@ -49,16 +49,26 @@ winograd_conv = _os.environ.get("M4D_WINOGRAD", "1") == "1"
 winograd2_min_workgroups = int(_os.environ.get("M4D_WINO2_MIN_WG", "60"))
 
 
+# Arithmetic of the wide Winograd layers: "bf16x3" = float32 operands split exactly into three bf16 terms, six bf16 MFMA
+# products, float32 accumulation (csrc/m4d_wino6.hip: float32 accuracy -- error against float64 0.8x that of the fp32
+# MFMA kernels, tools/bench_wino6.py -- at 2.67x less matrix-core time); "f32" = the fp32-MFMA kernels everywhere.
+conv_arith = _os.environ.get("M4D_CONV_ARITH", "bf16x3")
+wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
+
+
 def _use_winograd(b, h, w, cin, cout, stride):
-    """0 = direct convolution; 1 = Winograd kernel 1 (16x8 tile, 16-channel chunks, 2 N-tiles per workgroup);
-    2 = kernel 2 (16x16 tile, 8-channel chunks: half the weight traffic per flop -- ahead on the large maps).
+    """0 = direct convolution; 6 = the bf16-split Winograd kernel (m4d_wino6.hip); 1 = Winograd kernel 1 (16x8 tile,
+    16-channel chunks, 2 N-tiles per workgroup); 2 = kernel 2 (16x16 tile, 8-channel chunks: half the weight traffic per flop -- ahead on the large maps).
     Winograd only pays when the launch fills the chip: the thresholds are workgroup counts (measured per layer of the
     384x1280 pyramid, profiles/r01_step_launches_b1_wino.txt: level 3 and coarser stay on the direct kernel, which can
     split N and K further)."""
     if not winograd_conv or stride != 1 or cin < 16 or cin % 2 != 0:
         return 0
     n32 = -(-cout // 32)
-    if cin % 4 == 0 and b * (-(-h // 16)) * (-(-w // 16)) * n32 >= winograd2_min_workgroups:
+    t16 = b * (-(-h // 16)) * (-(-w // 16))
+    if conv_arith == "bf16x3" and cin % 16 == 0 and cin >= 32 and cout >= 64 and t16 * (-(-cout // 64)) >= wino6_min_workgroups:
+        return 6                                                # 64-cout workgroups: 96 runs as 128 and is still ahead
+    if cin % 4 == 0 and t16 * n32 >= winograd2_min_workgroups:
         return 2
     t8 = b * (-(-h // 8)) * (-(-w // 16))
     if cout % 64 == 0 and t8 * (cout // 64) >= 400:
@@ -246,6 +256,16 @@ class _Conv3x3SameTF(torch.nn.Module):
             return torch.from_numpy(wu).to(self.weight.device), cpad
         return self._cache.get(("wino", chunk, cin_pad), _stamp(self.weight), build)
 
+    def _packed_weights_wino6(self, cin_pad=None):
+        """(wu6 int16 bits, CoutPad) for m4d_conv3x3_wino6_bias_act: U = G g G^T split into three bf16 terms on the host."""
+        if cin_pad is not None and cin_pad == self.weight.shape[1]:
+            cin_pad = None
+
+        def build():
+            wu, cpad = nops.pack_conv_weights_wino6(self._hwio_numpy(cin_pad))
+            return torch.from_numpy(wu.view("int16")).to(self.weight.device), cpad
+        return self._cache.get(("wino6", cin_pad), _stamp(self.weight), build)
+
     def _hwio_device(self):
         """The TF-layout [3,3,Cin,Cout] kernel as a contiguous device tensor (the encoder-head kernel reads it directly)."""
         return self._cache.get(("hwio",), _stamp(self.weight), lambda: self.weight.detach().permute(2, 3, 1, 0).contiguous())
@@ -272,6 +292,9 @@ class _Conv3x3SameTF(torch.nn.Module):
             # (all T frames, two batches in the pipelined forward, one frame when streaming): its kernel choice must not
             # depend on that, or the modes stop being bit-identical -- decide from the per-image grid.
             wino = _use_winograd(1 if self.per_image_dispatch else b_, h_, w_, cin_, self.out_channels, self.stride)
+            if wino == 6:
+                wu, cpad = self._packed_weights_wino6(cin_)
+                return _timed("conv", self.tag, lambda: nops.conv3x3_wino6_bias_act(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
             if wino:
                 wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8, cin_)     # cin_ > Cin: zero-padded input
                 fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
@@ -775,6 +798,8 @@ class M4Depth(torch.nn.Module):
                     conv._packed_weights_winograd(16)
                     if cin % 4 == 0:
                         conv._packed_weights_winograd(8)
+                    if cin % 16 == 0 and cin >= 32 and conv.out_channels >= 64:
+                        conv._packed_weights_wino6()
         for lvl in self.d_estimator.levels:
             convs = list(lvl.disp_refiner.prep_conv_layers) + list(lvl.disp_refiner.est_d_conv_layers)
             c0 = convs[0] if convs else None
@@ -783,6 +808,8 @@ class M4Depth(torch.nn.Module):
                 c0._packed_weights(cin_pad)
                 c0._packed_weights_winograd(16, cin_pad)
                 c0._packed_weights_winograd(8, cin_pad)
+                if cin_pad % 16 == 0 and c0.out_channels >= 64:
+                    c0._packed_weights_wino6(cin_pad)
             if len(convs) == 7 and convs[5].weight is not None and convs[5].weight.is_cuda \
                     and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16):
                 lvl._tail_weights(convs)

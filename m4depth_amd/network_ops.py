@@ -279,6 +279,61 @@ def conv3x3_wino2_bias_act(x, wu8, bias, cout, cout_pad, slope=0.1):
     return out
 
 
+def split_bf16x3(v):
+    """float32 array -> uint16 [3, ...]: three bf16 bit patterns p1, p2, p3 (round to nearest even) with
+    v == p1 + p2 + p3 EXACTLY (8 + 8 + 8 significand bits; the residuals of a rounding are exact in float32)."""
+    import numpy as np
+
+    def bf16_rn(x):
+        u = x.view(np.uint32).astype(np.uint64)
+        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+    def widen(b):
+        return (b.astype(np.uint32) << 16).view(np.float32)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    p1 = bf16_rn(v)
+    r1 = v - widen(p1)
+    p2 = bf16_rn(r1)
+    r2 = r1 - widen(p2)
+    p3 = bf16_rn(r2)
+    assert np.array_equal(widen(p3), r2), "float32 value not representable as three bf16 terms (denormal range?)"
+    return np.stack([p1, p2, p3])
+
+
+def pack_conv_weights_wino6(kernel_hwio):
+    """Winograd F(2x2,3x3) filter transform U = G g G^T (float64, rounded once to float32 -- the same U as
+    pack_conv_weights_winograd), every value split exactly into three bf16 terms, in the MFMA B-fragment order of
+    m4d_conv3x3_wino6_bias_act: [Cin/16][CoutPad/64][16 positions][2 N-tiles][3 parts][64 lanes][8] bf16 (uint16 bits),
+    lane = k_half * 32 + cout % 32, element e = channel 8 k_half + e of the chunk.  Cin is zero-padded to a multiple of
+    16, Cout to a multiple of 64.  numpy in, (numpy uint16, CoutPad) out."""
+    import numpy as np
+    k = np.asarray(kernel_hwio, dtype=np.float64)
+    assert k.shape[:2] == (3, 3)
+    cin, cout = k.shape[2], k.shape[3]
+    G = np.array(_WINO_G, np.float64)
+    U = np.einsum('ij,jkco,lk->ilco', G, k, G)                   # [4,4,Cin,Cout]
+    nch, ng = -(-cin // 16), -(-cout // 64)
+    cpad = ng * 64
+    full = np.zeros((16, nch * 16, cpad), np.float32)
+    full[:, :cin, :cout] = U.reshape(16, cin, cout).astype(np.float32)
+    parts = split_bf16x3(full)                                   # [3][pos][cin][cout]
+    parts = parts.reshape(3, 16, nch, 2, 8, ng, 2, 32)           # part, pos, chunk, k_half, e, n-group, n-tile, j
+    w = np.ascontiguousarray(parts.transpose(2, 5, 1, 6, 0, 3, 7, 4))   # chunk, group, pos, n-tile, part, k_half, j, e
+    return w.reshape(nch, ng, 16, 2, 3, 64, 8), cpad
+
+
+def conv3x3_wino6_bias_act(x, wu6, bias, cout, cout_pad, slope=0.1):
+    """3x3 stride-1 TF-'SAME' convolution + bias + leaky_relu(slope): Winograd F(2x2,3x3), float32 operands split into
+    three bf16 terms, six bf16 MFMA products per term pair, float32 accumulation (csrc/m4d_wino6.hip)."""
+    x = as_f32(x, "x")
+    b, h, w, cin = x.shape
+    out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    check(lib.m4d_conv3x3_wino6_bias_act(dptr(x, "x"), dptr(wu6, "wu6", torch.int16), dptr(bias, "bias"), b, h, w, cin,
+                                         int(cout), int(cout_pad), float(slope), dptr(out), stream_ptr()),
+          "m4d_conv3x3_wino6_bias_act")
+    return out
+
+
 class FrameStack:
     """``frames`` [bsz,T',H,W,3]-shaped VIEW into a sequence batch [bsz,T,H,W,3] (frames t0..t1 of every sequence): what
     M4Depth.call hands the encoder so that all frames are encoded in one launch, frame-major (image t*bsz + i), read in

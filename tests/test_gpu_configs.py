@@ -243,14 +243,15 @@ def test_batch32_fullsize_properties(dev):
 
 
 # ------------------------------------------------------------------------------- float64 truth
-@pytest.mark.parametrize("winograd", [False, True], ids=["direct_conv", "winograd"])
+@pytest.mark.parametrize("winograd", [False, "f32", "bf16x3"], ids=["direct_conv", "winograd_fp32_mfma", "winograd_bf16_split"])
 def test_error_against_float64_truth(dev, winograd):
     """Both float32 evaluations -- the numpy oracle and the GPU -- against the float64 evaluation of the same algorithm
     (oracle.float64_reference(): same operations and order, the float16 steps of the DSCV kept).  The north-star
     tolerance (1e-4 relative on depth) sits at the rounding-noise floor of ANY float32 evaluation of this network with
     random weights: the float32 oracle itself is only within 1e-4 of the float64 truth on ~99 % of the pixels.  Asserted:
     the GPU is as close to the truth as the oracle is (parallax error quantiles within 1.5x of the oracle's with the
-    direct convolution, 2.5x with Winograd F(2x2,3x3), whose transforms add 1.5-1.8x the rounding of a direct sum), and
+    direct convolution, 2.5x with Winograd F(2x2,3x3), whose transforms add 1.5-1.8x the rounding of a direct sum --
+    in both arithmetics: fp32 MFMA, and float32 operands as exact 3 x bf16 splits on the bf16 matrix cores), and
     the fraction of depth pixels within 1e-4 of the truth is printed for both, per convolution mode.  (Measured, MI355X:
     the GPU's median parallax error to the truth is 3-4x SMALLER than the numpy oracle's at every level of the default
     model -- 5.7e-7 vs 2.0e-6 at level 1 -- and the same fraction of depth pixels, 99.5-99.9 %, is within 1e-4.)"""
@@ -258,15 +259,18 @@ def test_error_against_float64_truth(dev, winograd):
     L, H, Wd, T, b = 3, 192, 384, 3, 1
     W = S.init_weights(L, seed=42)
     samples, cam = S.make_sequence(b, T, H, Wd, seed=91)
-    old = net.winograd_conv
-    net.winograd_conv = winograd
+    old, old_arith = net.winograd_conv, net.conv_arith
+    net.winograd_conv = bool(winograd)
+    net.conv_arith = winograd if winograd else old_arith
     try:
         if winograd:
-            assert net._use_winograd(b, H // 2, Wd // 2, 128, 128, 1) != 0, "pick a size at which level 1 runs on Winograd"
+            kind = net._use_winograd(b, H // 2, Wd // 2, 128, 128, 1)
+            assert kind != 0, "pick a size at which level 1 runs on Winograd"
+            assert (kind == 6) == (winograd == "bf16x3"), "the bf16-split kernel must be the one under test (or not)"
         model = _model(dev, L, W)
         model([to_dev(samples, dev), to_dev(cam, dev)])
     finally:
-        net.winograd_conv = old
+        net.winograd_conv, net.conv_arith = old, old_arith
     _, seq32 = O.M4Depth(W, L)(samples, cam)
     with O.float64_reference():
         _, seq64 = O.M4Depth(W, L)(samples, cam)
@@ -274,7 +278,7 @@ def test_error_against_float64_truth(dev, winograd):
     for l in range(L):
         est = model.last_estimates[-1][l]
         check_against_float64_truth({"parallax": npy(est["parallax"]), "depth": npy(est["depth"])}, seq32[-1][l], seq64[-1][l],
-                                    f"[{'winograd' if winograd else 'direct'}] level {l}", factor=factor)
+                                    f"[{'winograd ' + winograd if winograd else 'direct'}] level {l}", factor=factor)
 
 
 # ------------------------------------------------------------------------------- helper ops (rows a3, a14)

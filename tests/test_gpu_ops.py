@@ -405,6 +405,41 @@ def test_winograd_conv_kernel2(M, dev, b, h, w, cin, cout, slope):
     assert torch.equal(got, nops.conv3x3_wino2_bias_act(xd, wd, bd, cout, cpad, slope))
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,slope", [
+    (2, 32, 48, 64, 128, 0.1),
+    (1, 37, 53, 112, 96, 0.1),        # ragged tiles; 96 output channels run as two 64-wide workgroups
+    (1, 19, 21, 32, 40, 1.0),         # N padding (40 -> 64), no activation, a map smaller than two tiles
+    (2, 16, 16, 16, 64, 0.1),         # a single 16-channel chunk
+    (1, 50, 90, 96, 64, 0.1),
+    (2, 100, 130, 48, 120, 0.1),      # Cout % 4 == 0 but not a multiple of 64: the guarded store path on the last quad
+    (1, 192, 320, 64, 66, 1.0),       # Cout % 4 != 0: scalar stores
+])
+def test_winograd_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
+    """m4d_conv3x3_wino6_bias_act (Winograd F(2x2,3x3), float32 operands split exactly into three bf16 terms, six bf16 MFMA
+    products, float32 accumulation) vs the oracle's convolution: the float32 tolerance of the fp32-MFMA Winograd kernels,
+    AND no further from the float64 result than the float32 oracle itself (the claim that lets it stand in for them)."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(cin * 17 + cout)
+    x = rng.standard_normal([b, h, w, cin]).astype(F)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = (0.1 * rng.standard_normal([cout])).astype(F)
+    wu, cpad = nops.pack_conv_weights_wino6(k)
+    assert cpad % 64 == 0 and wu.dtype == np.uint16
+    xd, wd, bd = to_dev(x, dev), torch.from_numpy(wu.view(np.int16)).to(dev), to_dev(bias, dev)
+    got = nops.conv3x3_wino6_bias_act(xd, wd, bd, cout, cpad, slope)
+    act = lambda r: np.where(r > 0, r, r * r.dtype.type(slope))
+    ref32 = act(O.conv2d_same(x, k, bias, 1)).astype(F)
+    with O.float64_reference():
+        ref64 = act(O.conv2d_same(x.astype(np.float64), k.astype(np.float64), bias.astype(np.float64), 1))
+    assert ref64.dtype == np.float64
+    scale = max(1.0, np.abs(ref32).max())
+    assert np.max(np.abs(npy(got) - ref32)) < 1e-5 * scale
+    e_gpu, e_oracle = np.abs(npy(got).astype(np.float64) - ref64), np.abs(ref32.astype(np.float64) - ref64)
+    print(f"bf16-split Winograd {cin}->{cout}: mean |error| to float64: GPU {e_gpu.mean():.3e}, float32 oracle {e_oracle.mean():.3e}")
+    assert e_gpu.mean() <= 1.5 * e_oracle.mean() and e_gpu.max() <= 3.0 * e_oracle.max()
+    assert torch.equal(got, nops.conv3x3_wino6_bias_act(xd, wd, bd, cout, cpad, slope))          # deterministic
+
+
 @pytest.mark.parametrize("b,h,w,quat", [(2, 24, 40, True), (1, 37, 53, False), (1, 6, 20, True)])
 def test_fused_refiner_tail(M, dev, b, h, w, quat):
     """conv(32->16)+lrelu, conv(16->5) and the level tail in one kernel vs the oracle's two convolutions + the oracle's

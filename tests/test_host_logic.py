@@ -153,3 +153,27 @@ def test_float64_reference_mode_of_the_oracle():
     assert np.mean(cv32 == cv64) > 0.9 and np.max(np.abs(cv32 - cv64)) < 2e-3       # same up to a few float16 flips
     d32 = O.parallax2depth(disp, rot, trans, cam)
     assert d32.dtype == np.float32 and np.max(np.abs(d32 - d64) / np.abs(d64)) < 1e-5
+
+
+def test_bf16_three_way_split_and_wino6_pack():
+    """network_ops.split_bf16x3: every float32 value is exactly the sum of its three bf16 terms; pack_conv_weights_wino6 holds
+    the same transformed filter U as the fp32 Winograd pack, in MFMA B-fragment order."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(21)
+    v = np.concatenate([rng.standard_normal(4096), rng.standard_normal(512) * 1e-6, rng.standard_normal(512) * 1e6,
+                        np.array([0.0, -0.0, 1.0, -1.0, 1.0 + 2.0 ** -23, 255.99998, 2.0 ** -100, 3.0e38])]).astype(F)
+    parts = nops.split_bf16x3(v)
+    assert parts.shape == (3,) + v.shape and parts.dtype == np.uint16
+    wide = (parts.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    assert np.array_equal(wide.sum(0), v.astype(np.float64))                         # exact, not approximately
+    assert np.all(np.abs(wide[1]) <= np.abs(wide[0]) * 2.0 ** -8 + 1e-300) and np.all(np.abs(wide[2]) <= np.abs(wide[0]) * 2.0 ** -16 + 1e-300)
+    cin, cout = 40, 70                                                                # padded to 48 / 128
+    k = rng.standard_normal([3, 3, cin, cout]).astype(F)
+    w6, cpad = nops.pack_conv_weights_wino6(k)
+    assert cpad == 128 and w6.shape == (3, 2, 16, 2, 3, 64, 8)
+    u = (w6.astype(np.uint32) << 16).view(np.float32).astype(np.float64).sum(4)       # [chunk, group, pos, n-tile, lane, e]
+    u = u.reshape(3, 2, 16, 2, 2, 32, 8)                                              # lane = k_half * 32 + j
+    full = u.transpose(2, 0, 4, 6, 1, 3, 5).reshape(16, 48, 128)                      # [pos][cin][cout]
+    w8, cpad8 = nops.pack_conv_weights_winograd(k, chunk=16)                          # [chunk][pos][n][channels], same U
+    ref = w8.transpose(1, 0, 3, 2).reshape(16, 48, cpad8)
+    assert np.array_equal(full[:, :, :cpad8], ref.astype(np.float64)) and not full[:, :, cout:].any() and not full[:, cin:].any()

@@ -8,13 +8,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1); ap.add_argument("--cin", type=int, default=128)
 ap.add_argument("--cout", type=int, default=128); ap.add_argument("--h", type=int, default=192)
 ap.add_argument("--w", type=int, default=640); ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--winograd", type=int, default=0, help="0 = direct MFMA kernel, 1 / 2 = Winograd kernel 1 / 2")
+ap.add_argument("--winograd", type=int, default=0, help="0 = direct MFMA kernel, 1 / 2 = fp32-MFMA Winograd kernel 1 / 2(4), 6 = the bf16-split Winograd kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 x = torch.randn(a.batch, a.h, a.w, a.cin, device=dev)
 k = torch.randn(3, 3, a.cin, a.cout) * (2.0 / (9 * a.cin)) ** 0.5
 bias = torch.randn(a.cout, device=dev) * 0.1
-if a.winograd:
+if a.winograd == 6:
+    wp, cpad = nops.pack_conv_weights_wino6(k.numpy()); wp = wp.view("int16")
+    fn = nops.conv3x3_wino6_bias_act
+elif a.winograd:
     wp, cpad = nops.pack_conv_weights_winograd(k.numpy(), chunk=8 if a.winograd == 2 else 16)
     fn = nops.conv3x3_wino2_bias_act if a.winograd == 2 else nops.conv3x3_wino_bias_act
 else:

@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python tools/pmc_traffic.py --batch 1 > $OUT/pmc.log 2>&1
-python tools/pmc_traffic.py --batch 32 --only front,wino_l1_128_128 >> $OUT/pmc.log 2>&1
+python tools/pmc_traffic.py --batch 32 --only front,wino6_l1_128_128 >> $OUT/pmc.log 2>&1
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 cp gpurun_out/pmc_traffic_rows.txt $OUT/pmc_traffic_rows.txt
 python bench.py --steps 20 --host-input > $OUT/bench_b1.json 2> $OUT/bench_b1.err

@@ -1,0 +1,27 @@
+"""Cycle stamps of the bf16-split Winograd kernel (m4d_wino6_set_stamps): per workgroup start / end of the K loop / end of the
+epilogue, for the level-1 and level-2 128->128 layers.  The stamped kernel is the product kernel + three s_memtime reads."""
+import os, sys, ctypes, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from m4depth_amd import network_ops as nops
+from m4depth_amd._lib import lib
+dev = torch.device("cuda:0")
+for (h, w, cin, cout) in [(192, 640, 128, 128), (96, 320, 128, 128), (192, 640, 64, 128)]:
+    x = torch.randn(1, h, w, cin, device=dev)
+    k = torch.randn(3, 3, cin, cout) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.zeros(cout, device=dev)
+    wu6, cpad = nops.pack_conv_weights_wino6(k.numpy()); wud = torch.from_numpy(wu6.view("int16")).to(dev)
+    for _ in range(3): nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
+    st = torch.zeros(512 * 4, dtype=torch.int64, device=dev)
+    lib.m4d_wino6_set_stamps(ctypes.c_void_p(st.data_ptr()))
+    nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
+    torch.cuda.synchronize()
+    lib.m4d_wino6_set_stamps(None)
+    s = st.view(512, 4).cpu().double()
+    nwg = min(512, -(-h // 16) * -(-w // 16) * (cpad // 64))
+    s = s[:nwg]
+    t0 = s[:, 0].min()
+    kl, ep = (s[:, 1] - s[:, 0]), (s[:, 2] - s[:, 1])
+    print(f"{h}x{w} {cin}->{cout}: {nwg} stamped workgroups; start spread {(s[:,0]-t0).max():.0f} ticks; "
+          f"prologue+K loop mean {kl.mean():.0f} (min {kl.min():.0f}, max {kl.max():.0f}) = {kl.mean() / (cin // 16):.0f} per 16-channel chunk; "
+          f"epilogue mean {ep.mean():.0f} (min {ep.min():.0f} max {ep.max():.0f}); kernel span {(s[:,2].max()-t0):.0f} ticks")
