@@ -16,9 +16,13 @@
 // so lane (tile m, k-half) reads those 2 x 4 pixels x 8 channels from the raw halo in LDS, forms t_c = d[ra][c] +- d[rb][c]
 // once per 16-channel chunk (64 registers), and per position V = t_c +- t_c', the 3-way split and the packing (7.5 VALU
 // operations per element -- the kernel is balanced between the VALU and the matrix core, not MFMA-bound any more).  B
-// operands (the split U) come straight from L2 in fragment order (1 KB per (position, N-tile, part), 16 bytes per lane).
-// LDS holds only the raw halo (double buffered, 23 KB each), laid out [channel quad][row][column parity][column / 2] so that
-// the 16-byte reads of a wave are conflict-free; one barrier per chunk.  Epilogue as in kernel 4 of m4d_wino.hip: rows of
+// operands (the split U, fragment order: 1 KB per (position, N-tile, part)) and the raw halo both reach LDS by LDS-DMA
+// (global_load_lds / buffer_load ... lds: no staging registers, no ds_write pass): each wave keeps a private 4-position ring
+// of its B fragments (3 positions in flight ahead of the one being read into registers), the four waves share the
+// double-buffered raw halo (23 KB each, [channel quad][row][column parity][column / 2]: conflict-free 16-byte reads; pixels
+// outside the image come back as zeros from the buffer descriptor's range check).  The DMAs are inline asm with hand-counted
+// s_waitcnt vmcnt(N) -- the compiler would drain every DMA in flight (vmcnt(0)) before any LDS read it cannot prove
+// independent; one raw s_barrier per chunk.  Epilogue as in kernel 4 of m4d_wino.hip: rows of
 // A^T (M A) through LDS, bias + leaky_relu, 16-byte stores.  Deterministic: fixed summation order, no atomics.
 #include <cstdlib>
 #include "m4d_common.h"
@@ -42,8 +46,12 @@ constexpr int kT = 16, kH = kT + 2;              // output tile, halo (pixels)
 constexpr int kJ = 10;                           // 16-byte slots per (row, column parity): 9 used; 2 * kJ = 20 = 4 mod 8 makes
 constexpr int kRow = 2 * kJ;                     //   two rows = 8 slots mod 16: every 16-lane read group covers 16 distinct slots
 constexpr int kQuad = kH * kRow;                 // slots per channel quad (360)
-constexpr int kRawSlots = 4 * kQuad;             // per chunk of 16 channels: 1440 slots = 23040 B
-constexpr int kRawF4 = kH * kH * 4;              // float4 loads per chunk (1296) over 256 threads: 5 full rounds + 16
+constexpr int kRawUsed = 4 * kQuad;              // per chunk of 16 channels: 1440 slots
+constexpr int kRawDma = 23;                      // LDS-DMA instructions per chunk: 64 slots each (the last one half used)
+constexpr int kRawSlots = kRawDma * 64;          // 1472 slots = 23552 B per buffer
+constexpr int kBRingBytes = 4 * 6 * 1024;        // per wave: 4 positions x 6 fragments of 1 KB
+constexpr int kBRingOff = 2 * kRawSlots * 16;    // byte offset of the B rings in LDS (47104)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   bf16x2 v; v[0] = (__bf16)a; v[1] = (__bf16)b;
@@ -67,11 +75,12 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& a0, bf16x8& a1, b
   a0 = __builtin_bit_cast(bf16x8, p0); a1 = __builtin_bit_cast(bf16x8, p1); a2 = __builtin_bit_cast(bf16x8, p2);
 }
 
-template <bool STAMPS, int ABL>
+template <bool STAMPS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv3x3_wino6_kernel(const Wino6Args a) {
   extern __shared__ __align__(16) float lds[];
   float4* raw = reinterpret_cast<float4*>(lds);                      // [2][kRawSlots]
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address (for M0)
 
   const int t = threadIdx.x, lane = t & 63;
   const int pr = __builtin_amdgcn_readfirstlane(t >> 6);             // position row of this wave (scalar)
@@ -91,45 +100,47 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   }
   const int tile_y = (tile / a.tiles_x) * kT, tile_x = (tile % a.tiles_x) * kT;
   const int bi = blockIdx.y;
-  const int n = a.n_chunks;
+  const int n = a.n_chunks, last = n - 1;
   const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
 
-  // ---- raw staging: item = (halo pixel, channel quad); 6 slots per thread (the last one new for t < 16 only)
-  unsigned voff[6];
-  int dst[6];
-  unsigned okmask = 0;
-#pragma unroll
-  for (int s = 0; s < 6; ++s) {
-    const int idx = min(s * 256 + t, kRawF4 - 1);
-    const int hp = idx >> 2, q = idx & 3;
-    const int hy = hp / kH, hx = hp - hy * kH;
-    const int gy = tile_y - 1 + hy, gx = tile_x - 1 + hx;
-    const bool ok = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-    okmask |= (ok ? 1u : 0u) << s;
-    voff[s] = (unsigned)(((min(max(gy, 0), a.h - 1) * a.w + min(max(gx, 0), a.w - 1)) * a.Cin + q * 4) * 4);
-    dst[s] = q * kQuad + hy * kRow + (hx & 1) * kJ + (hx >> 1);
+  // ---- raw halo by LDS-DMA: instruction i fills slots 64 i .. 64 i + 63 (lane = slot); wave pr issues i = pr, pr + 4, ...
+  // (6 per wave; the 24th repeats the 23rd).  Per lane: the byte offset of its slot's (pixel, channel quad) in the image, or
+  // an offset past the buffer's num_records for pixels outside the image and pad slots: the range check returns zeros.
+  i32x4 rsrc;
+  {
+    const unsigned long long xa = (unsigned long long)ximg;
+    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(xa & 0xffffffffull));
+    rsrc[1] = __builtin_amdgcn_readfirstlane((int)((xa >> 32) & 0xffffull));            // stride 0: raw buffer
+    rsrc[2] = a.h * a.w * a.Cin * 4;                                                     // num_records (bytes)
+    rsrc[3] = 0x00020000;
   }
-  // (slot 5 of threads 16.. is the clamped last item again: same address, same value, same LDS slot -- no branch needed)
-  float4 rg[6];
-  auto load_raw_to = [&](int chunk, float4 (&r)[6]) {
-    const char* base = reinterpret_cast<const char*>(ximg) + (size_t)chunk * 64;
+  unsigned rvoff[6];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) r[s] = *reinterpret_cast<const float4*>(base + voff[s]);
+  for (int k = 0; k < 6; ++k) {
+    const int i = min(pr + 4 * k, kRawDma - 1);
+    const int s = i * 64 + lane;
+    const int q = s / kQuad, rem = s - q * kQuad;
+    const int hy = rem / kRow, r2 = rem - hy * kRow;
+    const int e = r2 / kJ, j = r2 - e * kJ;
+    const int hx = 2 * j + e;
+    const int gy = tile_y - 1 + hy, gx = tile_x - 1 + hx;
+    const bool ok = s < kRawUsed && j < 9 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    rvoff[k] = ok ? (unsigned)(((gy * a.w + gx) * a.Cin + q * 4) * 4) : 0x80000000u;
+  }
+  // one raw DMA: LDS destination (wave-uniform byte address) in M0, + lane * 16
+  auto raw_dma = [&](unsigned lds_dst, unsigned voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
   };
-  auto commit_raw_from = [&](float4* rb, const float4 (&r)[6]) {
+  // this wave's DMAs k0 .. k0 + 2 of raw(chunk) into buffer `buf`
+  auto raw_dma3 = [&](int chunk, int buf, int k0) {
+    const int soff = chunk * 64;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      const bool ok = (okmask >> s) & 1u;
-      rb[dst[s]] = ok ? r[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = k0; k < k0 + 3; ++k) {
+      const int i = min(pr + 4 * k, kRawDma - 1);
+      raw_dma(lds_base + (unsigned)((buf * kRawSlots + i * 64) * 16), rvoff[k], soff);
     }
-  };
-  auto load_raw = [&](int chunk, bool force = false) {
-    if ((ABL & 16) && !force) return;              // ablation 16: no raw staging in the loop
-    load_raw_to(chunk, rg);
-  };
-  auto commit_raw = [&](float4* rb, bool force = false) {
-    if ((ABL & 16) && !force) return;
-    commit_raw_from(rb, rg);
   };
 
   // ---- this lane's tiles: M-tile mt holds tile rows 4 mt .. 4 mt + 3; lane m = (row m >> 3, column m & 7)
@@ -144,8 +155,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   float tv[2][4][8];                               // t_c of the current chunk: [M-tile][column c][channel]
   // columns c0, c0 + 2 of t for the chunk in rbuf (two calls per chunk: the registers of columns 0, 2 are free one
   // position earlier than those of columns 1, 3)
-  auto read_t = [&](const float4* rbuf, int c0, bool force = false) {
-    if ((ABL & 8) && !force) return;               // ablation 8: no LDS reads / t in the loop
+  auto read_t = [&](const float4* rbuf, int c0) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -162,8 +172,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
         }
   };
   // A operands of position (pr, c): V = (t B)_c = t0 - t2, t1 + t2, t2 - t1, t1 - t3
-  auto gen_a = [&](int c, bf16x8 (&A)[2][3], bool force = false) {
-    if ((ABL & 4) && !force) return;               // ablation 4: no input transform / split in the loop
+  auto gen_a = [&](int c, bf16x8 (&A)[2][3]) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       float v[8];
@@ -176,17 +185,31 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   };
 
   // ---- B operands: wu[chunk][N-group][16 positions][2 N-tiles][3 parts][64 lanes][8 bf16]; this wave walks the 4
-  // positions of its row chunk after chunk: 6 KB per position, contiguous
+  // positions of its row chunk after chunk (6 KB per position, contiguous) into its LDS ring: position q -> slot q & 3 = its
+  // column (static), three positions ahead of the multiply; one position ahead the fragments move to registers.
   const long long w_pos = 6 * 1024;
   const long long w_chunk = (long long)n_groups * 16 * w_pos;
-  const unsigned char* wptr = a.wu + ((long long)ng * 16 + 4 * pr) * w_pos;      // uniform; position q = chunk * 4 + c
-  const unsigned wlane = (unsigned)lane * 16u;
-  bf16x8 B[2][2][3];                               // [ring][N-tile][part]
-  auto load_b = [&](const unsigned char* p, int ring, bool force = false) {
-    if ((ABL & 1) && !force) return;               // ablation 1: the B operands of the prologue only
-#pragma unroll
-    for (int f = 0; f < 6; ++f) B[ring][f / 3][f % 3] = *reinterpret_cast<const bf16x8*>(p + wlane + f * 1024);
+  const unsigned char* wc = a.wu + ((long long)ng * 16 + 4 * pr) * w_pos;        // uniform: this wave's row, chunk 0
+  const unsigned bring = lds_base + (unsigned)(kBRingOff + pr * kBRingBytes);    // LDS byte address of this wave's ring
+  const unsigned char* bring_p = reinterpret_cast<const unsigned char*>(lds) + kBRingOff + pr * kBRingBytes;
+  const unsigned bl0 = (unsigned)lane * 16u, bl1 = bl0 + 4096u;
+  // (the instruction offset of an LDS-DMA load moves BOTH the global address and the LDS address)
+  auto b_dma = [&](const unsigned char* gsrc, int slot) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %4 offset:2048\n\tglobal_load_lds_dwordx4 %1, %4 offset:3072\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(bl0), "v"(bl1), "s"(bring + (unsigned)(slot * 6144)), "s"(gsrc) : "memory");
   };
+  bf16x8 B[2][2][3];                               // [ring][N-tile][part]
+  auto read_b = [&](int slot, int ring) {
+#pragma unroll
+    for (int f = 0; f < 6; ++f) B[ring][f / 3][f % 3] = *reinterpret_cast<const bf16x8*>(bring_p + slot * 6144 + f * 1024 + bl0);
+  };
+#define M4D_W6_VMCNT(nn) asm volatile("s_waitcnt vmcnt(" #nn ")" ::: "memory")
 
   f32x16 acc[4][2][2];
 #pragma unroll
@@ -202,27 +225,17 @@ conv3x3_wino6_kernel(const Wino6Args a) {
                                ? a.stamps + (long long)blockIdx.x * 4 : nullptr;
   if (STAMPS && st) st[0] = __builtin_readcyclecounter();
 
-  // ---- prologue: raw(0), raw(1) in LDS, raw(2) in registers, t(0), A(0, 0), B(0)
-  const int last = n - 1;
+  // ---- prologue: raw(0), raw(1), B(0..2) by DMA; epilogue operands; then t(0), A(0, 0), B(0) in registers
+  raw_dma3(0, 0, 0); raw_dma3(0, 0, 3);
+  raw_dma3(min(1, last), 1, 0); raw_dma3(min(1, last), 1, 3);
   {
-    float4 rg1[6];                                 // both first chunks in flight together
-    load_raw_to(0, rg);
-    load_raw_to(min(1, last), rg1);
-    load_b(wptr, 0, true);
-    if (ABL & 1) load_b(wptr, 1, true);
-    commit_raw_from(raw, rg);
-    commit_raw_from(raw + kRawSlots, rg1);
+    const unsigned char* wc1 = n > 1 ? wc + w_chunk : wc;
+    b_dma(wc, 0);
+    b_dma(wc + w_pos, 1);
+    b_dma(wc + 2 * w_pos, 2);
+    (void)wc1;
   }
-  __syncthreads();
-  read_t(raw, 0, true);
-  read_t(raw, 1, true);
-  bf16x8 A[2][2][3];                               // [ring][M-tile][part]
-  gen_a(0, A[0], true);
-  if (ABL & 4) gen_a(1, A[1], true);
-  load_raw(min(2, last), true);
-
-  // epilogue operands fetched now (their latency disappears under the K loop): this thread's two output-channel quads
-  float bs[2][4];
+  float bs[2][4];                                  // this thread's two output-channel quads of the bias
 #pragma unroll
   for (int ont = 0; ont < 2; ++ont)
 #pragma unroll
@@ -230,25 +243,28 @@ conv3x3_wino6_kernel(const Wino6Args a) {
       const int co = ng * 64 + ont * 32 + 4 * (t & 7) + e;
       bs[ont][e] = a.bias[min(co, a.Cout - 1)];
     }
+  M4D_W6_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+  read_t(raw, 0);
+  read_t(raw, 1);
+  read_b(0, 0);
+  bf16x8 A[2][2][3];                               // [ring][M-tile][part]
+  gen_a(0, A[0]);
 
   // the 6 products of one accumulator, small terms first: (A part, B part)
   constexpr int kTA[6] = {0, 2, 1, 0, 1, 0};
   constexpr int kTB[6] = {2, 0, 1, 1, 0, 0};
 #define M4D_W6_MFMAS(c, ring)                                                                                          \
-  if (!(ABL & 2))                                                                                                      \
   _Pragma("unroll") for (int term = 0; term < 6; ++term)                                                               \
   _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                     \
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                     \
     acc[c][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ring][mt][kTA[term]], B[ring][nt][kTB[term]],          \
                                                               acc[c][mt][nt], 0, 0, 0);
-  // one MFMA, then `valu` vector instructions (the matrix core needs 32 cycles per MFMA: ~5 other issues fit in its shadow)
-#define M4D_W6_PIPE(n_mfma, valu, ds_first, every_dsw, every_vm)                                                       \
-  if (ds_first) __builtin_amdgcn_sched_group_barrier(0x100, ds_first, 0);                                              \
+  // one MFMA, then `valu` vector instructions (the matrix core needs 32 cycles per MFMA: ~6 other issues fit in its shadow)
+#define M4D_W6_PIPE(n_mfma, valu)                                                                                      \
   _Pragma("unroll") for (int i_ = 0; i_ < n_mfma; ++i_) {                                                              \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);                                                              \
-    if (every_dsw && i_ % every_dsw == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                           \
-    if (every_vm && i_ % every_vm == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                             \
   }
 
   // The compiler may sink pure arithmetic past a sched_barrier (only the machine scheduler honours it): an empty asm that
@@ -269,49 +285,62 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   };
 
   // Uniform loop body (no branches: one scheduling region per position).  Work past the last chunk is harmless: the
-  // surplus t / A come from a buffer nobody needs any more and are never multiplied.
+  // surplus DMAs re-fetch the last chunk / position into buffers nobody reads any more, the surplus t / A are never multiplied.
+  // DMA order per wave and chunk: [p0: B] [p1: B] [p2: B, wait, barrier, raw x3] [p3: B, raw x3]; the vmcnt(N) of position p
+  // leaves exactly the DMAs issued after B(q + 1) in flight (N = 18, 15, 12, 18), which at p2 also covers raw(chunk + 1).
   for (int chunk = 0; chunk < n; ++chunk) {
-    const unsigned char* wnext = chunk < last ? wptr + w_chunk : wptr;            // scalar select
+    const unsigned char* wn = chunk < last ? wc + w_chunk : wc;                   // scalar select: B of the next chunk
+    const int rnext_c = min(chunk + 2, last);
     // position 0: A(1) from t1, t2
-    load_b(wptr + w_pos, 1);
+    b_dma(wc + 3 * w_pos, 3);
+    M4D_W6_VMCNT(18);
+    read_b(1, 1);
     gen_a(1, A[1]);
     M4D_W6_MFMAS(0, 0)
     pin_a(A[1]);
-    M4D_W6_PIPE(24, 5, 0, 0, 4)
+    M4D_W6_PIPE(24, 5)
     __builtin_amdgcn_sched_barrier(0);
     // position 1: A(2) from t2, t1
-    load_b(wptr + 2 * w_pos, 0);
+    b_dma(wn, 0);
+    M4D_W6_VMCNT(15);
+    read_b(2, 0);
     gen_a(2, A[0]);
     M4D_W6_MFMAS(1, 1)
     pin_a(A[0]);
-    M4D_W6_PIPE(24, 5, 0, 0, 4)
+    M4D_W6_PIPE(24, 5)
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();                               // raw(chunk + 1) committed by every wave; raw(chunk) no longer read
+    // position 2: A(3) from t1, t3; columns 0, 2 of t(chunk + 1); first half of raw(chunk + 2)
+    b_dma(wn + w_pos, 1);
+    M4D_W6_VMCNT(12);
+    __builtin_amdgcn_s_barrier();                  // raw(chunk + 1) landed for every wave; raw(chunk) no longer read
     const float4* rnext = raw + ((chunk + 1) & 1) * kRawSlots;
-    // position 2: A(3) from t1, t3; columns 0, 2 of t(chunk + 1)
-    load_b(wptr + 3 * w_pos, 1);
+    raw_dma3(rnext_c, chunk & 1, 0);
+    read_b(3, 1);
     gen_a(3, A[1]);
     read_t(rnext, 0);
     M4D_W6_MFMAS(2, 0)
     pin_a(A[1]);
     pin_t(0);
-    M4D_W6_PIPE(24, 6, 0, 0, 4)
+    M4D_W6_PIPE(24, 6)
     __builtin_amdgcn_sched_barrier(0);
-    // position 3: columns 1, 3 of t(chunk + 1), A(chunk + 1, 0); raw(chunk + 2) -> LDS, raw(chunk + 3) -> registers
-    load_b(wnext, 0);
+    // position 3: columns 1, 3 of t(chunk + 1), A(chunk + 1, 0); second half of raw(chunk + 2)
+    b_dma(wn + 2 * w_pos, 2);
+    raw_dma3(rnext_c, chunk & 1, 3);
+    M4D_W6_VMCNT(18);
+    read_b(0, 0);
     read_t(rnext, 1);
     gen_a(0, A[0]);
-    commit_raw(raw + (chunk & 1) * kRawSlots);
-    load_raw(min(chunk + 3, last));
     M4D_W6_MFMAS(3, 1)
     pin_a(A[0]);
     pin_t(1);
-    M4D_W6_PIPE(24, 7, 0, 6, 2)
+    M4D_W6_PIPE(24, 7)
     __builtin_amdgcn_sched_barrier(0);
-    wptr = wnext;
+    wc = wn;
   }
 #undef M4D_W6_MFMAS
 #undef M4D_W6_PIPE
+  M4D_W6_VMCNT(0);                                 // no DMA may land in LDS once the epilogue reuses it
+#undef M4D_W6_VMCNT
   if (STAMPS && st) st[1] = __builtin_readcyclecounter();
   __syncthreads();                                 // every wave is done with raw: the epilogue buffer aliases it
 
@@ -396,32 +425,24 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
   M4D_CHECK_ARG(x && wu6 && bias && out && b > 0 && h > 0 && w > 0 && Cin >= 16 && Cout > 0);
   M4D_CHECK_ARG(CoutPad % 64 == 0 && CoutPad >= Cout && Cin % 16 == 0);
   M4D_CHECK_ARG(((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu6) & 15u) == 0));
+  M4D_CHECK_ARG((long long)h * w * Cin * 4 < (1ll << 31));                              // one image = one buffer descriptor
   Wino6Args a;
   a.x = x; a.wu = reinterpret_cast<const unsigned char*>(wu6); a.bias = bias; a.out = out;
   a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.n_chunks = Cin / 16; a.slope = slope;
   a.tiles_x = (w + kT - 1) / kT; a.tiles_y = (h + kT - 1) / kT;
   a.stamps = g_wino6_stamps;
-  constexpr size_t lds = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);                 // epilogue staging 147 KB (K loop: 46 KB)
-  static_assert(lds >= (size_t)2 * kRawSlots * 16, "epilogue staging must cover the K-loop buffers");
-  static int abl = -1;                             // profiling only: M4D_WINO6_ABLATE (see the kernel)
-  if (abl < 0) { const char* e = getenv("M4D_WINO6_ABLATE"); abl = e ? atoi(e) : 0; }
+  constexpr size_t lds = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);                 // epilogue staging 147 KB (K loop: 142 KB)
+  static_assert(lds >= (size_t)kBRingOff + 4 * kBRingBytes, "epilogue staging must cover the K-loop buffers");
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
   auto launch = [&](auto kernel) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static bool attr_set = false;                  // more than 64 KB of dynamic LDS needs the opt-in (once per instantiation)
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
   };
-  if (a.stamps) launch(&conv3x3_wino6_kernel<true, 0>);
-  else if (abl == 0) launch(&conv3x3_wino6_kernel<false, 0>);
-#ifdef M4D_W6_ABLATIONS
-  else if (abl == 1) launch(&conv3x3_wino6_kernel<false, 1>);
-  else if (abl == 2) launch(&conv3x3_wino6_kernel<false, 2>);
-  else if (abl == 3) launch(&conv3x3_wino6_kernel<false, 3>);
-  else if (abl == 4) launch(&conv3x3_wino6_kernel<false, 4>);
-  else if (abl == 12) launch(&conv3x3_wino6_kernel<false, 12>);
-  else if (abl == 28) launch(&conv3x3_wino6_kernel<false, 28>);
-  else if (abl == 29) launch(&conv3x3_wino6_kernel<false, 29>);
-  else if (abl == 31) launch(&conv3x3_wino6_kernel<false, 31>);
-#endif
-  else return (int)hipErrorInvalidValue;
+  if (a.stamps) launch(&conv3x3_wino6_kernel<true>);
+  else launch(&conv3x3_wino6_kernel<false>);
   return M4D_LAUNCH_RESULT();
 }
