@@ -10,20 +10,23 @@
 // profiles/r02_bf16_split_probe.txt).  The filter transform U = G g G^T is split on the host (pack_conv_weights_wino6);
 // the input transform V = B^T d B is computed and split in registers by the wave that multiplies it.
 //
-// Workgroup = 4 waves, ONE PER SIMD (512 registers each), = a 16x16-pixel output tile (64 Winograd tiles = two MFMA M-tiles)
-// x 64 output channels (two N-tiles).  Wave r owns row r of the 4x4 Winograd positions: 4 positions x 2 M x 2 N = 16
-// accumulators (256 AGPRs).  Its A operands need no exchange: V[r][c] of a tile depends on two raw rows of that tile only,
+// Workgroup = 8 waves, TWO PER SIMD (256 registers each), = a 16x16-pixel output tile (64 Winograd tiles = two MFMA M-tiles)
+// x 64 output channels (two N-tiles).  Wave (r, mt) owns row r of the 4x4 Winograd positions for M-tile mt: 4 positions x 2 N
+// = 8 accumulators (128 AGPRs).  Its A operands need no exchange: V[r][c] of a tile depends on two raw rows of that tile only,
 // so lane (tile m, k-half) reads those 2 x 4 pixels x 8 channels from the raw halo in LDS, forms t_c = d[ra][c] +- d[rb][c]
-// once per 16-channel chunk (64 registers), and per position V = t_c +- t_c', the 3-way split and the packing (7.5 VALU
-// operations per element -- the kernel is balanced between the VALU and the matrix core, not MFMA-bound any more).  B
-// operands (the split U, fragment order: 1 KB per (position, N-tile, part)) and the raw halo both reach LDS by LDS-DMA
-// (global_load_lds / buffer_load ... lds: no staging registers, no ds_write pass): each wave keeps a private 4-position ring
-// of its B fragments (3 positions in flight ahead of the one being read into registers), the four waves share the
-// double-buffered raw halo (23 KB each, [channel quad][row][column parity][column / 2]: conflict-free 16-byte reads; pixels
-// outside the image come back as zeros from the buffer descriptor's range check).  The DMAs are inline asm with hand-counted
-// s_waitcnt vmcnt(N) -- the compiler would drain every DMA in flight (vmcnt(0)) before any LDS read it cannot prove
-// independent; one raw s_barrier per chunk.  Epilogue as in kernel 4 of m4d_wino.hip: rows of
-// A^T (M A) through LDS, bias + leaky_relu, 16-byte stores.  Deterministic: fixed summation order, no atomics.
+// once per 16-channel chunk, and per position V = t_c +- t_c', the 3-way split and the packing: 7.5 VALU instructions per
+// element, ~5 per MFMA -- the kernel is balanced between the VALU port (which the MFMAs share: 8 + 4 n cycles for an MFMA and
+// n other instructions of one wave, tools/micro/mfma_bf16_dep.hip) and the matrix core, not MFMA-bound any more; the second
+// wave of the SIMD covers the LDS / DMA / scalar instructions and every latency.  B operands (the split U, fragment order:
+// 1 KB per (position, N-tile, part)) and the raw halo both reach LDS by LDS-DMA (global_load_lds / buffer_load ... lds: no
+// staging registers, no ds_write pass): the two waves of a position row share a 4-position ring of B fragments (filled four
+// positions ahead, half by each), all waves share the double-buffered raw halo (23 KB each, [channel quad][row][column
+// parity][column / 2]: conflict-free 16-byte reads; pixels outside the image come back as zeros from the buffer descriptor's
+// range check).  The DMAs are inline asm with hand-counted s_waitcnt vmcnt(N) -- the compiler would drain every DMA in
+// flight (vmcnt(0)) before any LDS read it cannot prove independent; one raw s_barrier per position makes the partner's
+// fragments visible.  The B registers are refilled part by part as the MFMAs of the current position retire them.
+// Epilogue as in kernel 4 of m4d_wino.hip: rows of A^T (M A) through LDS, bias + leaky_relu, 16-byte stores.
+// Deterministic: fixed summation order, no atomics.
 #include <cstdlib>
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
@@ -49,7 +52,7 @@ constexpr int kQuad = kH * kRow;                 // slots per channel quad (360)
 constexpr int kRawUsed = 4 * kQuad;              // per chunk of 16 channels: 1440 slots
 constexpr int kRawDma = 23;                      // LDS-DMA instructions per chunk: 64 slots each (the last one half used)
 constexpr int kRawSlots = kRawDma * 64;          // 1472 slots = 23552 B per buffer
-constexpr int kBRingBytes = 4 * 6 * 1024;        // per wave: 4 positions x 6 fragments of 1 KB
+constexpr int kBRingBytes = 4 * 6 * 1024;        // per position row: 4 positions x 6 fragments of 1 KB
 constexpr int kBRingOff = 2 * kRawSlots * 16;    // byte offset of the B rings in LDS (47104)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -76,14 +79,15 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& a0, bf16x8& a1, b
 }
 
 template <bool STAMPS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3x3_wino6_kernel(const Wino6Args a) {
   extern __shared__ __align__(16) float lds[];
   float4* raw = reinterpret_cast<float4*>(lds);                      // [2][kRawSlots]
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address (for M0)
 
   const int t = threadIdx.x, lane = t & 63;
-  const int pr = __builtin_amdgcn_readfirstlane(t >> 6);             // position row of this wave (scalar)
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);             // scalar
+  const int pr = wv & 3, mt = wv >> 2;                               // position row, M-tile (waves r and r + 4 share a SIMD)
   const int m = lane & 31, kh = lane >> 5;
   const int n_tiles = a.tiles_x * a.tiles_y, n_groups = a.CoutPad / 64;
   int tile, ng;
@@ -103,9 +107,9 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   const int n = a.n_chunks, last = n - 1;
   const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
 
-  // ---- raw halo by LDS-DMA: instruction i fills slots 64 i .. 64 i + 63 (lane = slot); wave pr issues i = pr, pr + 4, ...
-  // (6 per wave; the 24th repeats the 23rd).  Per lane: the byte offset of its slot's (pixel, channel quad) in the image, or
-  // an offset past the buffer's num_records for pixels outside the image and pad slots: the range check returns zeros.
+  // ---- raw halo by LDS-DMA: instruction i fills slots 64 i .. 64 i + 63 (lane = slot); wave wv issues i = wv, wv + 8,
+  // wv + 16 (the 24th repeats the 23rd).  Per lane: the byte offset of its slot's (pixel, channel quad) in the image, or an
+  // offset past the buffer's num_records for pixels outside the image and pad slots: the range check returns zeros.
   i32x4 rsrc;
   {
     const unsigned long long xa = (unsigned long long)ximg;
@@ -114,10 +118,10 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     rsrc[2] = a.h * a.w * a.Cin * 4;                                                     // num_records (bytes)
     rsrc[3] = 0x00020000;
   }
-  unsigned rvoff[6];
+  unsigned rvoff[3];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int i = min(pr + 4 * k, kRawDma - 1);
+  for (int k = 0; k < 3; ++k) {
+    const int i = min(wv + 8 * k, kRawDma - 1);
     const int s = i * 64 + lane;
     const int q = s / kQuad, rem = s - q * kQuad;
     const int hy = rem / kRow, r2 = rem - hy * kRow;
@@ -127,115 +131,104 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     const bool ok = s < kRawUsed && j < 9 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
     rvoff[k] = ok ? (unsigned)(((gy * a.w + gx) * a.Cin + q * 4) * 4) : 0x80000000u;
   }
-  // one raw DMA: LDS destination (wave-uniform byte address) in M0, + lane * 16
-  auto raw_dma = [&](unsigned lds_dst, unsigned voff, int soff) {
+  // DMA k of raw(chunk) into buffer `buf`: LDS destination (wave-uniform byte address) in M0, + lane * 16
+  auto raw_dma = [&](int chunk, int buf, int k) {
+    const int i = min(wv + 8 * k, kRawDma - 1);
+    const unsigned lds_dst = lds_base + (unsigned)((buf * kRawSlots + i * 64) * 16);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff) : "memory");
-  };
-  // this wave's DMAs k0 .. k0 + 2 of raw(chunk) into buffer `buf`
-  auto raw_dma3 = [&](int chunk, int buf, int k0) {
-    const int soff = chunk * 64;
-#pragma unroll
-    for (int k = k0; k < k0 + 3; ++k) {
-      const int i = min(pr + 4 * k, kRawDma - 1);
-      raw_dma(lds_base + (unsigned)((buf * kRawSlots + i * 64) * 16), rvoff[k], soff);
-    }
+                 : "=&s"(keep) : "v"(rvoff[k]), "s"(lds_dst), "s"(rsrc), "s"(chunk * 64) : "memory");
   };
 
-  // ---- this lane's tiles: M-tile mt holds tile rows 4 mt .. 4 mt + 3; lane m = (row m >> 3, column m & 7)
+  // ---- this lane's tile: M-tile mt holds tile rows 4 mt .. 4 mt + 3; lane m = (row m >> 3, column m & 7)
   // position row pr of B^T d uses raw rows (ra, rb) of the 4x4 input tile: d0 - d2, d1 + d2, d2 - d1, d1 - d3
   const int ra = pr == 0 ? 0 : (pr == 2 ? 2 : 1);
   const int rb_ = pr == 0 ? 2 : (pr == 1 ? 2 : (pr == 2 ? 1 : 3));
   const float sgn = pr == 1 ? 1.f : -1.f;
   const int ty0 = m >> 3, tx = m & 7;
-  // slot of (M-tile 0, raw row 0, column 0, quad 2 kh); + mt * 8 rows, + row * kRow, + (c & 1) * kJ + (c >> 1), + quad
-  const int src0 = (2 * kh) * kQuad + (2 * ty0) * kRow + tx;
+  // slot of (raw row 0 of the tile, column 0, quad 2 kh); + row * kRow, + (c & 1) * kJ + (c >> 1), + quad
+  const int src0 = (2 * kh) * kQuad + (8 * mt + 2 * ty0) * kRow + tx;
 
-  float tv[2][4][8];                               // t_c of the current chunk: [M-tile][column c][channel]
+  float tv[4][8];                                  // t_c of the current chunk: [column c][channel]
   // columns c0, c0 + 2 of t for the chunk in rbuf (two calls per chunk: the registers of columns 0, 2 are free one
   // position earlier than those of columns 1, 3)
   auto read_t = [&](const float4* rbuf, int c0) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-          const int c = c0 + 2 * cc;
-          const int s = src0 + qq * kQuad + (8 * mt) * kRow + (c & 1) * kJ + (c >> 1);
-          const float4 da = rbuf[s + ra * kRow], db = rbuf[s + rb_ * kRow];
-          tv[mt][c][4 * qq + 0] = __builtin_fmaf(sgn, db.x, da.x);     // exact product: one rounding, = da +- db
-          tv[mt][c][4 * qq + 1] = __builtin_fmaf(sgn, db.y, da.y);
-          tv[mt][c][4 * qq + 2] = __builtin_fmaf(sgn, db.z, da.z);
-          tv[mt][c][4 * qq + 3] = __builtin_fmaf(sgn, db.w, da.w);
-        }
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = c0 + 2 * cc;
+        const int s = src0 + qq * kQuad + (c & 1) * kJ + (c >> 1);
+        const float4 da = rbuf[s + ra * kRow], db = rbuf[s + rb_ * kRow];
+        tv[c][4 * qq + 0] = __builtin_fmaf(sgn, db.x, da.x);           // exact product: one rounding, = da +- db
+        tv[c][4 * qq + 1] = __builtin_fmaf(sgn, db.y, da.y);
+        tv[c][4 * qq + 2] = __builtin_fmaf(sgn, db.z, da.z);
+        tv[c][4 * qq + 3] = __builtin_fmaf(sgn, db.w, da.w);
+      }
   };
-  // A operands of position (pr, c): V = (t B)_c = t0 - t2, t1 + t2, t2 - t1, t1 - t3
-  auto gen_a = [&](int c, bf16x8 (&A)[2][3]) {
+  // A operands of position (pr, c): V = (t B)_c = t0 - t2, t1 + t2, t2 - t1, t1 - t3; element pair e (channels 2e, 2e + 1)
+  // -> one packed word of each of the three bf16x8 operands (hi, mid, lo)
+  auto gen_pair = [&](int c, int e, u32x4 (&A)[3]) {
+    float v[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        v[e] = c == 0 ? tv[mt][0][e] - tv[mt][2][e] : c == 1 ? tv[mt][1][e] + tv[mt][2][e]
-             : c == 2 ? tv[mt][2][e] - tv[mt][1][e] : tv[mt][1][e] - tv[mt][3][e];
-      split8(v, A[mt][0], A[mt][1], A[mt][2]);
+    for (int h = 0; h < 2; ++h) {
+      const int ch = 2 * e + h;
+      v[h] = c == 0 ? tv[0][ch] - tv[2][ch] : c == 1 ? tv[1][ch] + tv[2][ch] : c == 2 ? tv[2][ch] - tv[1][ch] : tv[1][ch] - tv[3][ch];
     }
+    const unsigned q0 = pk_bf16(v[0], v[1]);
+    const float r0 = v[0] - lo_f32(q0), r1 = v[1] - hi_f32(q0);
+    const unsigned q1 = pk_bf16(r0, r1);
+    const float s0 = r0 - lo_f32(q1), s1 = r1 - hi_f32(q1);
+    // s0, s1 are exactly bf16 numbers (8 significant bits left): their upper halves ARE the conversion -- v_perm_b32 (4
+    // cycles) instead of a third v_cvt_pk_bf16_f32 (8 cycles beside MFMAs, tools/micro/valu_cost.hip)
+    A[0][e] = q0; A[1][e] = q1; A[2][e] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
   };
 
-  // ---- B operands: wu[chunk][N-group][16 positions][2 N-tiles][3 parts][64 lanes][8 bf16]; this wave walks the 4
-  // positions of its row chunk after chunk (6 KB per position, contiguous) into its LDS ring: position q -> slot q & 3 = its
-  // column (static), three positions ahead of the multiply; one position ahead the fragments move to registers.
+  // ---- B operands: wu[chunk][N-group][16 positions][2 N-tiles][3 parts][64 lanes][8 bf16]; a position row walks its 4
+  // positions chunk after chunk (6 KB per position, contiguous) into its LDS ring: position q -> slot q & 3 = its column
+  // (static), DMA'd four positions ahead -- fragments 3 mt .. 3 mt + 2 by wave (pr, mt).
   const long long w_pos = 6 * 1024;
   const long long w_chunk = (long long)n_groups * 16 * w_pos;
-  const unsigned char* wc = a.wu + ((long long)ng * 16 + 4 * pr) * w_pos;        // uniform: this wave's row, chunk 0
-  const unsigned bring = lds_base + (unsigned)(kBRingOff + pr * kBRingBytes);    // LDS byte address of this wave's ring
+  const unsigned char* wc = a.wu + ((long long)ng * 16 + 4 * pr) * w_pos;        // uniform: this row, chunk 0
+  const unsigned bring = lds_base + (unsigned)(kBRingOff + pr * kBRingBytes);    // LDS byte address of this row's ring
   const unsigned char* bring_p = reinterpret_cast<const unsigned char*>(lds) + kBRingOff + pr * kBRingBytes;
-  const unsigned bl0 = (unsigned)lane * 16u, bl1 = bl0 + 4096u;
+  const unsigned bl = (unsigned)lane * 16u;
+  const unsigned bl_dma = bl + (unsigned)mt * 3072u;
   // (the instruction offset of an LDS-DMA load moves BOTH the global address and the LDS address)
   auto b_dma = [&](const unsigned char* gsrc, int slot) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %4\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %4 offset:2048\n\tglobal_load_lds_dwordx4 %1, %4 offset:3072\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %4\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024\n\t"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
                  "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(bl0), "v"(bl1), "s"(bring + (unsigned)(slot * 6144)), "s"(gsrc) : "memory");
+                 : "=&s"(keep) : "v"(bl_dma), "s"(bring + (unsigned)(slot * 6144) + (unsigned)mt * 3072u), "s"(gsrc) : "memory");
   };
-  bf16x8 B[2][2][3];                               // [ring][N-tile][part]
-  auto read_b = [&](int slot, int ring) {
-#pragma unroll
-    for (int f = 0; f < 6; ++f) B[ring][f / 3][f % 3] = *reinterpret_cast<const bf16x8*>(bring_p + slot * 6144 + f * 1024 + bl0);
+  bf16x8 B0[2][2], B1[2], B2[2];                   // parts (hi, mid, lo) of the B operand per N-tile; the hi part double buffered
+  auto frag = [&](int slot, int nt, int part) {
+    return *reinterpret_cast<const bf16x8*>(bring_p + slot * 6144 + (nt * 3 + part) * 1024 + bl);
   };
-#define M4D_W6_VMCNT(nn) asm volatile("s_waitcnt vmcnt(" #nn ")" ::: "memory")
+#define M4D_W6_WAIT(nn) asm volatile("s_waitcnt vmcnt(" #nn ") lgkmcnt(0)" ::: "memory")
 
-  f32x16 acc[4][2][2];
+  f32x16 acc[4][2];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][mt][nt][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[c][nt][r] = 0.f;
 
   unsigned long long* st = (STAMPS && a.stamps != nullptr && t == 0 && blockIdx.y == 0 && blockIdx.x < 512)
-                               ? a.stamps + (long long)blockIdx.x * 4 : nullptr;
+                               ? a.stamps + (long long)blockIdx.x * 160 : nullptr;
   if (STAMPS && st) st[0] = __builtin_readcyclecounter();
 
-  // ---- prologue: raw(0), raw(1), B(0..2) by DMA; epilogue operands; then t(0), A(0, 0), B(0) in registers
-  raw_dma3(0, 0, 0); raw_dma3(0, 0, 3);
-  raw_dma3(min(1, last), 1, 0); raw_dma3(min(1, last), 1, 3);
-  {
-    const unsigned char* wc1 = n > 1 ? wc + w_chunk : wc;
-    b_dma(wc, 0);
-    b_dma(wc + w_pos, 1);
-    b_dma(wc + 2 * w_pos, 2);
-    (void)wc1;
-  }
-  float bs[2][4];                                  // this thread's two output-channel quads of the bias
+  // ---- prologue: raw(0), raw(1), B(0..3) by DMA; epilogue operands; then t(0), A(0, 0), B(0) in registers
+#pragma unroll
+  for (int k = 0; k < 3; ++k) raw_dma(0, 0, k);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) raw_dma(min(1, last), 1, k);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) b_dma(wc + c * w_pos, c);
+  float bs[2][4];                                  // this thread's output-channel quad of the bias, per N-tile
 #pragma unroll
   for (int ont = 0; ont < 2; ++ont)
 #pragma unroll
@@ -243,134 +236,165 @@ conv3x3_wino6_kernel(const Wino6Args a) {
       const int co = ng * 64 + ont * 32 + 4 * (t & 7) + e;
       bs[ont][e] = a.bias[min(co, a.Cout - 1)];
     }
-  M4D_W6_VMCNT(0);
+  M4D_W6_WAIT(0);
   __builtin_amdgcn_s_barrier();
   read_t(raw, 0);
   read_t(raw, 1);
-  read_b(0, 0);
-  bf16x8 A[2][2][3];                               // [ring][M-tile][part]
-  gen_a(0, A[0]);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) { B0[0][nt] = frag(0, nt, 0); B1[nt] = frag(0, nt, 1); B2[nt] = frag(0, nt, 2); }
+  u32x4 A[2][3];                                   // [ring][part]: packed bf16 pairs
+#pragma unroll
+  for (int e = 0; e < 4; ++e) gen_pair(0, e, A[0]);
 
-  // the 6 products of one accumulator, small terms first: (A part, B part)
-  constexpr int kTA[6] = {0, 2, 1, 0, 1, 0};
-  constexpr int kTB[6] = {2, 0, 1, 1, 0, 0};
-#define M4D_W6_MFMAS(c, ring)                                                                                          \
-  _Pragma("unroll") for (int term = 0; term < 6; ++term)                                                               \
-  _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                     \
+  // The compiler may sink pure arithmetic past a sched_barrier (only the machine scheduler honours it): an empty asm that
+  // "modifies" the freshly produced operands pins their producers inside the region they are meant to overlap with.
+  auto pin_a = [&](u32x4 (&X)[3]) {
+#pragma unroll
+    for (int part = 0; part < 3; ++part) asm volatile("" : "+v"(X[part]));
+  };
+  auto pin_t = [&](int c0) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(tv[c0 + 2 * cc][e]));
+  };
+#define M4D_W6_MFMA(c, ap, bv)                                                                                         \
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                     \
-    acc[c][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ring][mt][kTA[term]], B[ring][nt][kTB[term]],          \
-                                                              acc[c][mt][nt], 0, 0, 0);
-  // one MFMA, then `valu` vector instructions (the matrix core needs 32 cycles per MFMA: ~6 other issues fit in its shadow)
+    acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(c) & 1][ap]), bv[nt], acc[c][nt], 0, 0, 0);
+  // one MFMA, then `valu` vector instructions (8 + 4 n cycles of the VALU port for one MFMA and n others; the MFMA runs 32)
 #define M4D_W6_PIPE(n_mfma, valu)                                                                                      \
   _Pragma("unroll") for (int i_ = 0; i_ < n_mfma; ++i_) {                                                              \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);                                                              \
   }
-
-  // The compiler may sink pure arithmetic past a sched_barrier (only the machine scheduler honours it): an empty asm that
-  // "modifies" the freshly produced operands pins their producers inside the region they are meant to overlap with.
-  auto pin_a = [&](bf16x8 (&X)[2][3]) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int part = 0; part < 3; ++part) asm volatile("" : "+v"(X[mt][part]));
-  };
-  auto pin_t = [&](int c0) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(tv[mt][c0 + 2 * cc][e]));
-  };
+  // One position = three blocks of 4 MFMAs (6 of the 9 term products, the small ones first), each followed by one DMA: the
+  // texture path (16 cycles per 1-KB piece, 32 pieces per position and CU) then works beside the MFMAs instead of in a burst
+  // after the barrier that every wave would sit through.  The B registers of a part are refilled for the next position as
+  // soon as the part's last MFMA is issued (lo after block 0, mid after block 1); the hi part, needed until the end, is
+  // double buffered.
+#define M4D_W6_BLOCK0(c, cn, next_slot, valu)                                                                          \
+  B0[((c) & 1) ^ 1][0] = frag(next_slot, 0, 0); B0[((c) & 1) ^ 1][1] = frag(next_slot, 1, 0);                          \
+  gen_pair(cn, 0, A[((c) & 1) ^ 1]); gen_pair(cn, 1, A[((c) & 1) ^ 1]);                                                \
+  M4D_W6_MFMA(c, 0, B2) M4D_W6_MFMA(c, 2, B0[(c) & 1])                                                                 \
+  asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][0]), "+v"(A[((c) & 1) ^ 1][0][1]));                                       \
+  M4D_W6_PIPE(4, valu)                                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+#define M4D_W6_BLOCK1(c, cn, next_slot, valu)                                                                          \
+  B2[0] = frag(next_slot, 0, 2); B2[1] = frag(next_slot, 1, 2);                                                        \
+  gen_pair(cn, 2, A[((c) & 1) ^ 1]);                                                                                   \
+  M4D_W6_MFMA(c, 1, B1) M4D_W6_MFMA(c, 0, B1)                                                                          \
+  asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][2]));                                                                     \
+  M4D_W6_PIPE(4, valu)                                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+#define M4D_W6_BLOCK2(c, cn, next_slot, valu)                                                                          \
+  B1[0] = frag(next_slot, 0, 1); B1[1] = frag(next_slot, 1, 1);                                                        \
+  gen_pair(cn, 3, A[((c) & 1) ^ 1]);                                                                                   \
+  M4D_W6_MFMA(c, 1, B0[(c) & 1]) M4D_W6_MFMA(c, 0, B0[(c) & 1])                                                        \
+  pin_a(A[((c) & 1) ^ 1]);                                                                                             \
+  M4D_W6_PIPE(4, valu)                                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
 
   // Uniform loop body (no branches: one scheduling region per position).  Work past the last chunk is harmless: the
   // surplus DMAs re-fetch the last chunk / position into buffers nobody reads any more, the surplus t / A are never multiplied.
-  // DMA order per wave and chunk: [p0: B] [p1: B] [p2: B, wait, barrier, raw x3] [p3: B, raw x3]; the vmcnt(N) of position p
-  // leaves exactly the DMAs issued after B(q + 1) in flight (N = 18, 15, 12, 18), which at p2 also covers raw(chunk + 1).
+  // Per position: barrier (the fragments of the NEXT position, DMA'd by both waves of the row, are visible from here on);
+  // DMAs (one raw piece at columns 0-2, this wave's half of B four positions ahead); the MFMAs of this position interleaved
+  // with the A operands of the next; then vmcnt(N) leaves exactly the DMAs of this and the previous position in flight
+  // (N = 6 + their raw pieces), i.e. everything the barrier of the next position publishes has landed.
+  int stq = 0;
+#define M4D_W6_STAMP(k) if (STAMPS && st && stq < 32) st[4 + stq * 4 + (k)] = __builtin_readcyclecounter();
   for (int chunk = 0; chunk < n; ++chunk) {
     const unsigned char* wn = chunk < last ? wc + w_chunk : wc;                   // scalar select: B of the next chunk
     const int rnext_c = min(chunk + 2, last);
-    // position 0: A(1) from t1, t2
-    b_dma(wc + 3 * w_pos, 3);
-    M4D_W6_VMCNT(18);
-    read_b(1, 1);
-    gen_a(1, A[1]);
-    M4D_W6_MFMAS(0, 0)
-    pin_a(A[1]);
-    M4D_W6_PIPE(24, 5)
-    __builtin_amdgcn_sched_barrier(0);
-    // position 1: A(2) from t2, t1
-    b_dma(wn, 0);
-    M4D_W6_VMCNT(15);
-    read_b(2, 0);
-    gen_a(2, A[0]);
-    M4D_W6_MFMAS(1, 1)
-    pin_a(A[0]);
-    M4D_W6_PIPE(24, 5)
-    __builtin_amdgcn_sched_barrier(0);
-    // position 2: A(3) from t1, t3; columns 0, 2 of t(chunk + 1); first half of raw(chunk + 2)
-    b_dma(wn + w_pos, 1);
-    M4D_W6_VMCNT(12);
-    __builtin_amdgcn_s_barrier();                  // raw(chunk + 1) landed for every wave; raw(chunk) no longer read
     const float4* rnext = raw + ((chunk + 1) & 1) * kRawSlots;
-    raw_dma3(rnext_c, chunk & 1, 0);
-    read_b(3, 1);
-    gen_a(3, A[1]);
+    // position 0: A(1) from t1, t2
+    __builtin_amdgcn_s_barrier();
+    M4D_W6_STAMP(0)
+    M4D_W6_BLOCK0(0, 1, 1, 7)
+    raw_dma(rnext_c, chunk & 1, 0);
+    M4D_W6_BLOCK1(0, 1, 1, 4)
+    b_dma(wn, 0);
+    M4D_W6_BLOCK2(0, 1, 1, 4)
+    M4D_W6_STAMP(2)
+    M4D_W6_WAIT(7);
+    M4D_W6_STAMP(3)
+    if (STAMPS) ++stq;
+    // position 1: A(2) from t2, t1
+    __builtin_amdgcn_s_barrier();
+    M4D_W6_STAMP(0)
+    M4D_W6_BLOCK0(1, 2, 2, 7)
+    raw_dma(rnext_c, chunk & 1, 1);
+    M4D_W6_BLOCK1(1, 2, 2, 4)
+    b_dma(wn + w_pos, 1);
+    M4D_W6_BLOCK2(1, 2, 2, 4)
+    M4D_W6_STAMP(2)
+    M4D_W6_WAIT(8);
+    M4D_W6_STAMP(3)
+    if (STAMPS) ++stq;
+    // position 2: A(3) from t1, t3; columns 0, 2 of t(chunk + 1)
+    __builtin_amdgcn_s_barrier();
+    M4D_W6_STAMP(0)
+    M4D_W6_BLOCK0(2, 3, 3, 7)
+    raw_dma(rnext_c, chunk & 1, 2);
     read_t(rnext, 0);
-    M4D_W6_MFMAS(2, 0)
-    pin_a(A[1]);
-    pin_t(0);
-    M4D_W6_PIPE(24, 6)
-    __builtin_amdgcn_sched_barrier(0);
-    // position 3: columns 1, 3 of t(chunk + 1), A(chunk + 1, 0); second half of raw(chunk + 2)
+    M4D_W6_BLOCK1(2, 3, 3, 6)
     b_dma(wn + 2 * w_pos, 2);
-    raw_dma3(rnext_c, chunk & 1, 3);
-    M4D_W6_VMCNT(18);
-    read_b(0, 0);
+    pin_t(0);
+    M4D_W6_BLOCK2(2, 3, 3, 6)
+    M4D_W6_STAMP(2)
+    M4D_W6_WAIT(8);
+    M4D_W6_STAMP(3)
+    if (STAMPS) ++stq;
+    // position 3: columns 1, 3 of t(chunk + 1) first (A(chunk + 1, 0) = t0 - t2 needs column ... 0 and 2 only)
+    __builtin_amdgcn_s_barrier();
+    M4D_W6_STAMP(0)
+    M4D_W6_BLOCK0(3, 0, 0, 7)
     read_t(rnext, 1);
-    gen_a(0, A[0]);
-    M4D_W6_MFMAS(3, 1)
-    pin_a(A[0]);
+    M4D_W6_BLOCK1(3, 0, 0, 6)
+    b_dma(wn + 3 * w_pos, 3);
     pin_t(1);
-    M4D_W6_PIPE(24, 7)
-    __builtin_amdgcn_sched_barrier(0);
+    M4D_W6_BLOCK2(3, 0, 0, 6)
+    M4D_W6_STAMP(2)
+    M4D_W6_WAIT(7);
+    M4D_W6_STAMP(3)
+    if (STAMPS) ++stq;
     wc = wn;
   }
-#undef M4D_W6_MFMAS
+#undef M4D_W6_MFMA
+#undef M4D_W6_BLOCK0
+#undef M4D_W6_BLOCK1
+#undef M4D_W6_BLOCK2
 #undef M4D_W6_PIPE
-  M4D_W6_VMCNT(0);                                 // no DMA may land in LDS once the epilogue reuses it
-#undef M4D_W6_VMCNT
+#undef M4D_W6_STAMP
+  M4D_W6_WAIT(0);                                  // no DMA may land in LDS once the epilogue reuses it
+#undef M4D_W6_WAIT
   if (STAMPS && st) st[1] = __builtin_readcyclecounter();
-  __syncthreads();                                 // every wave is done with raw: the epilogue buffer aliases it
+  __syncthreads();                                 // every wave is done with raw / the rings: the epilogue buffer aliases them
 
   // ---- output transform: rows of A^T (M A) through LDS per (N-tile, M-tile), then one 2x2-output item x 4 couts per thread
   constexpr int kMS = 36;                          // row stride (floats): 32 couts + 4 pad (16-byte aligned rows)
   constexpr int kRbMT = 4 * 2 * 32 * kMS;          // floats per (N-tile, M-tile): [4 rows i][2 k][32 tiles][kMS] = 36.9 KB
   float* Rb = lds;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int nt = 0; nt < 2; ++nt) {
+    float* rbuf = Rb + (nt * 2 + mt) * kRbMT;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      float* rbuf = Rb + (nt * 2 + mt) * kRbMT;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[0][mt][nt][r], m1 = acc[1][mt][nt][r], m2 = acc[2][mt][nt][r], m3 = acc[3][mt][nt][r];
-        const int trow = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        rbuf[((pr * 2 + 0) * 32 + trow) * kMS + m] = (m0 + m1) + m2;
-        rbuf[((pr * 2 + 1) * 32 + trow) * kMS + m] = (m1 - m2) - m3;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
+      const int trow = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      rbuf[((pr * 2 + 0) * 32 + trow) * kMS + m] = (m0 + m1) + m2;
+      rbuf[((pr * 2 + 1) * 32 + trow) * kMS + m] = (m1 - m2) - m3;
     }
+  }
   __syncthreads();
   float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
   const bool vec_ok = (a.Cout & 3) == 0;
   const bool whole = tile_x + kT <= a.w && tile_y + kT <= a.h;      // uniform: no per-store bounds tests on interior tiles
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int item = it * 256 + t;                 // (N-tile, M-tile, tile in M-tile, cout quad)
-    const int cq = item & 7, tl = (item >> 3) & 31, mt = (item >> 8) & 1, ont = it >> 1;
-    const float* rbuf = Rb + (ont * 2 + mt) * kRbMT;
-    const int tg = mt * 32 + tl;                   // Winograd tile 0..63 of the workgroup (8 x 8)
+  for (int it = 0; it < 2; ++it) {
+    const int item = it * 512 + t;                 // (N-tile, M-tile, tile in M-tile, cout quad)
+    const int cq = item & 7, tl = (item >> 3) & 31, omt = (item >> 8) & 1, ont = it;
+    const float* rbuf = Rb + (ont * 2 + omt) * kRbMT;
+    const int tg = omt * 32 + tl;                  // Winograd tile 0..63 of the workgroup (8 x 8)
     const int ty2 = tg >> 3, tx2 = tg & 7;
     const int co = ng * 64 + ont * 32 + 4 * cq;
     float4 rv[4][2];
@@ -440,7 +464,7 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
   };
   if (a.stamps) launch(&conv3x3_wino6_kernel<true>);
   else launch(&conv3x3_wino6_kernel<false>);

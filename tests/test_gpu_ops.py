@@ -436,7 +436,14 @@ def test_winograd_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
     assert np.max(np.abs(npy(got) - ref32)) < 1e-5 * scale
     e_gpu, e_oracle = np.abs(npy(got).astype(np.float64) - ref64), np.abs(ref32.astype(np.float64) - ref64)
     print(f"bf16-split Winograd {cin}->{cout}: mean |error| to float64: GPU {e_gpu.mean():.3e}, float32 oracle {e_oracle.mean():.3e}")
-    assert e_gpu.mean() <= 1.5 * e_oracle.mean() and e_gpu.max() <= 3.0 * e_oracle.max()
+    # Winograd's transforms add 1.5-1.8x the rounding of the oracle's direct float32 sum; the fp32-MFMA Winograd kernel is the bar
+    assert e_gpu.mean() <= 2.0 * e_oracle.mean() and e_gpu.max() <= 3.0 * e_oracle.max()
+    if cin % 4 == 0:
+        wu8, cpad8 = nops.pack_conv_weights_winograd(k, chunk=8)
+        f32k = nops.conv3x3_wino2_bias_act(xd, to_dev(wu8, dev), bd, cout, cpad8, slope)
+        e_f32 = np.abs(npy(f32k).astype(np.float64) - ref64)
+        print(f"    fp32-MFMA Winograd kernel: {e_f32.mean():.3e}")
+        assert e_gpu.mean() <= 1.02 * e_f32.mean()
     assert torch.equal(got, nops.conv3x3_wino6_bias_act(xd, wd, bd, cout, cpad, slope))          # deterministic
 
 
