@@ -135,9 +135,9 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   auto raw_dma = [&](int chunk, int buf, int k) {
     const int i = min(wv + 8 * k, kRawDma - 1);
     const unsigned lds_dst = lds_base + (unsigned)((buf * kRawSlots + i * 64) * 16);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(rvoff[k]), "s"(lds_dst), "s"(rsrc), "s"(chunk * 64) : "memory");
+    // (every DMA statement sets M0 itself and declares it clobbered: nothing else in this kernel uses M0)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                 : : "v"(rvoff[k]), "s"(lds_dst), "s"(rsrc), "s"(chunk * 64) : "memory", "m0");
   };
 
   // ---- this lane's tile: M-tile mt holds tile rows 4 mt .. 4 mt + 3; lane m = (row m >> 3, column m & 7)
@@ -196,12 +196,10 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   const unsigned bl_dma = bl + (unsigned)mt * 3072u;
   // (the instruction offset of an LDS-DMA load moves BOTH the global address and the LDS address)
   auto b_dma = [&](const unsigned char* gsrc, int slot) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(bl_dma), "s"(bring + (unsigned)(slot * 6144) + (unsigned)mt * 3072u), "s"(gsrc) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %2 offset:2048"
+                 : : "v"(bl_dma), "s"(bring + (unsigned)(slot * 6144) + (unsigned)mt * 3072u), "s"(gsrc) : "memory", "m0");
   };
   bf16x8 B0[2][2], B1[2], B2[2];                   // parts (hi, mid, lo) of the B operand per N-tile; the hi part double buffered
   auto frag = [&](int slot, int nt, int part) {
@@ -221,14 +219,9 @@ conv3x3_wino6_kernel(const Wino6Args a) {
                                ? a.stamps + (long long)blockIdx.x * 160 : nullptr;
   if (STAMPS && st) st[0] = __builtin_readcyclecounter();
 
-  // ---- prologue: raw(0), raw(1), B(0..3) by DMA; epilogue operands; then t(0), A(0, 0), B(0) in registers
-#pragma unroll
-  for (int k = 0; k < 3; ++k) raw_dma(0, 0, k);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) raw_dma(min(1, last), 1, k);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) b_dma(wc + c * w_pos, c);
-  float bs[2][4];                                  // this thread's output-channel quad of the bias, per N-tile
+  // ---- prologue: epilogue operands; raw(0), raw(1), B(0..3) by DMA in the order the K loop's vmcnt counts assume (the end
+  // of position 0 waits for everything but B(3) and its own 4); then t(0), A(0, 0), B(0) in registers
+  float bs[2][4];                                  // this thread's output-channel quad of the bias, per N-tile (oldest loads)
 #pragma unroll
   for (int ont = 0; ont < 2; ++ont)
 #pragma unroll
@@ -236,7 +229,15 @@ conv3x3_wino6_kernel(const Wino6Args a) {
       const int co = ng * 64 + ont * 32 + 4 * (t & 7) + e;
       bs[ont][e] = a.bias[min(co, a.Cout - 1)];
     }
-  M4D_W6_WAIT(0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) raw_dma(0, 0, k);
+  b_dma(wc, 0);
+  b_dma(wc + w_pos, 1);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) raw_dma(min(1, last), 1, k);
+  b_dma(wc + 2 * w_pos, 2);
+  b_dma(wc + 3 * w_pos, 3);
+  M4D_W6_WAIT(9);                                  // raw(0), B(0), B(1) landed; raw(1), B(2), B(3) (9 DMAs) still in flight:
   __builtin_amdgcn_s_barrier();
   read_t(raw, 0);
   read_t(raw, 1);

@@ -51,8 +51,12 @@ def counter_pass(counter, cmd, tag):
     out_dir = f"/tmp/pmct_{tag}_{counter}"
     subprocess.run(["rm", "-rf", out_dir])
     env = dict(os.environ, TMPDIR="/tmp")
-    res = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--",
-                          sys.executable] + cmd, cwd=ROOT, env=env, capture_output=True, text=True)
+    try:                                       # a counter pass that does not come back must not take the GPU box with it
+        res = subprocess.run(["timeout", "-k", "10", "240", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out_dir,
+                              "-o", "p", "--", sys.executable] + cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        print(f"  [{tag}] counter pass {counter} timed out")
+        return {}
     files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         print(f"  [{tag}] no counter csv for {counter}: {res.stderr[-300:]}")

@@ -12,23 +12,24 @@ for (h, w, cin, cout) in [(192, 640, 128, 128), (96, 320, 128, 128), (192, 640, 
     bias = torch.zeros(cout, device=dev)
     wu6, cpad = nops.pack_conv_weights_wino6(k.numpy()); wud = torch.from_numpy(wu6.view("int16")).to(dev)
     for _ in range(3): nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
-    st = torch.zeros(512 * 160, dtype=torch.int64, device=dev)
+    st = torch.zeros(64 * 1280, dtype=torch.int64, device=dev)
     lib.m4d_wino6_set_stamps(ctypes.c_void_p(st.data_ptr()))
     nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
     torch.cuda.synchronize()
     lib.m4d_wino6_set_stamps(None)
-    full = st.view(512, 160).cpu().double(); s = full[:, :4]
-    nwg = min(512, -(-h // 16) * -(-w // 16) * (cpad // 64))
-    s = s[:nwg]
-    t0 = s[:, 0].min()
-    kl, ep = (s[:, 1] - s[:, 0]), (s[:, 2] - s[:, 1])
-    print(f"{h}x{w} {cin}->{cout}: {nwg} stamped workgroups; start spread {(s[:,0]-t0).max():.0f} ticks; "
-          f"prologue+K loop mean {kl.mean():.0f} (min {kl.min():.0f}, max {kl.max():.0f}) = {kl.mean() / (cin // 16):.0f} per 16-channel chunk; "
-          f"epilogue mean {ep.mean():.0f} (min {ep.min():.0f} max {ep.max():.0f})")
-    pos = full[:nwg, 4:4 + 4 * min(32, cin // 4)].view(nwg, -1, 4)              # [wg][position][after barrier, after DMA issue, before wait, after wait]
-    work, wait = pos[:, :, 2] - pos[:, :, 0], pos[:, :, 3] - pos[:, :, 2]
-    bar = pos[:, 1:, 0] - pos[:, :-1, 3]
-    per = pos[:, 1:, 0] - pos[:, :-1, 0]
-    print(f"    per position (wave 0): MFMAs + A generation + DMA issue {work.mean():.0f}, vmcnt/lgkmcnt wait {wait.mean():.0f}, "
-          f"barrier {bar.mean():.0f}; position period {per.mean():.0f} ticks; by column: "
-          + ", ".join(f"p{c}: {work[:, c::4].mean():.0f}/{wait[:, c::4].mean():.0f}" for c in range(4)))
+    full = st.view(64, 1280).cpu().double()
+    nwg = min(64, -(-h // 16) * -(-w // 16) * (cpad // 64))
+    full = full[:nwg]
+    hdr = full[:, 1024:1027]
+    kl, ep = hdr[:, 1] - hdr[:, 0], hdr[:, 2] - hdr[:, 1]
+    npos = min(32, cin // 4)
+    pos = full[:, :1024].view(nwg, 8, 32, 4)[:, :, :npos]                       # [wg][wave][position][after barrier, -, before wait, after wait]
+    work, wait = pos[..., 2] - pos[..., 0], pos[..., 3] - pos[..., 2]
+    bar = pos[:, :, 1:, 0] - pos[:, :, :-1, 3]
+    per = pos[:, :, 1:, 0] - pos[:, :, :-1, 0]
+    print(f"{h}x{w} {cin}->{cout}: prologue + K loop {kl.mean():.0f} ticks ({kl.mean() / (cin // 16):.0f} per 16-channel chunk), epilogue {ep.mean():.0f}; "
+          f"position period {per.mean():.0f}")
+    for wvi in range(8):
+        print(f"    wave {wvi} (row {wvi & 3}, M-tile {wvi >> 2}): MFMAs + A generation + DMA issue {work[:, wvi].mean():.0f}, "
+              f"vmcnt/lgkmcnt wait {wait[:, wvi].mean():.0f}, barrier {bar[:, wvi].mean():.0f}; by column "
+              + ", ".join(f"{work[:, wvi, c::4].mean():.0f}" for c in range(4)))
