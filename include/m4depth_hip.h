@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 2
+#define M4D_ABI_VERSION 3
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);

@@ -42,7 +42,7 @@ struct Wino6Args {
   const float* x; const unsigned char* wu; const float* bias; float* out;
   int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
   float slope;
-  unsigned long long* stamps;   // profiling only (m4d_wino_set_stamps): per workgroup: start, end of K loop, end
+  unsigned long long* stamps;   // profiling only (m4d_wino6_set_stamps, tools/wino6_phases.py): 64 workgroups x 1280 words
 };
 
 constexpr int kT = 16, kH = kT + 2;              // output tile, halo (pixels)
@@ -215,9 +215,11 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][nt][r] = 0.f;
 
-  unsigned long long* st = (STAMPS && a.stamps != nullptr && t == 0 && blockIdx.y == 0 && blockIdx.x < 512)
-                               ? a.stamps + (long long)blockIdx.x * 160 : nullptr;
-  if (STAMPS && st) st[0] = __builtin_readcyclecounter();
+  // stamps (profiling build only): lane 0 of every wave of the first 64 workgroups; per workgroup 1280 words: per wave 32
+  // positions x (after barrier, -, before wait, after wait), then at 1024 the header of wave 0 (start, end of K loop, end)
+  unsigned long long* st = (STAMPS && a.stamps != nullptr && lane == 0 && blockIdx.y == 0 && blockIdx.x < 64)
+                               ? a.stamps + (long long)blockIdx.x * 1280 + wv * 128 : nullptr;
+  if (STAMPS && st && wv == 0) st[1024 + 0] = __builtin_readcyclecounter();
 
   // ---- prologue: epilogue operands; raw(0), raw(1), B(0..3) by DMA in the order the K loop's vmcnt counts assume (the end
   // of position 0 waits for everything but B(3) and its own 4); then t(0), A(0, 0), B(0) in registers
@@ -302,7 +304,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // with the A operands of the next; then vmcnt(N) leaves exactly the DMAs of this and the previous position in flight
   // (N = 6 + their raw pieces), i.e. everything the barrier of the next position publishes has landed.
   int stq = 0;
-#define M4D_W6_STAMP(k) if (STAMPS && st && stq < 32) st[4 + stq * 4 + (k)] = __builtin_readcyclecounter();
+#define M4D_W6_STAMP(k) if (STAMPS && st && stq < 32) st[stq * 4 + (k)] = __builtin_readcyclecounter();
   for (int chunk = 0; chunk < n; ++chunk) {
     const unsigned char* wn = chunk < last ? wc + w_chunk : wc;                   // scalar select: B of the next chunk
     const int rnext_c = min(chunk + 2, last);
@@ -368,7 +370,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 #undef M4D_W6_STAMP
   M4D_W6_WAIT(0);                                  // no DMA may land in LDS once the epilogue reuses it
 #undef M4D_W6_WAIT
-  if (STAMPS && st) st[1] = __builtin_readcyclecounter();
+  if (STAMPS && st && wv == 0) st[1024 + 1] = __builtin_readcyclecounter();
   __syncthreads();                                 // every wave is done with raw / the rings: the epilogue buffer aliases them
 
   // ---- output transform: rows of A^T (M A) through LDS per (N-tile, M-tile), then one 2x2-output item x 4 couts per thread
@@ -436,7 +438,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
           }
     }
   }
-  if (STAMPS && st) st[2] = __builtin_readcyclecounter();
+  if (STAMPS && st && wv == 0) st[1024 + 2] = __builtin_readcyclecounter();
 }
 
 unsigned long long* g_wino6_stamps = nullptr;
