@@ -372,6 +372,14 @@ int m4d_dinl_fwd(const float* x, const float* scale, const float* bias, int b, i
  *   [b,h,w,3] batch is bsz = b, stride_b = h*w*3, stride_t = 0.
  * m4d_conv3x3s2_dinl_bias_act: the stride-2 convolution on leaky_relu(DomainNormalization(raw), dn_slope), the
  *   normalisation fused into its input staging; wp packed as for m4d_conv3x3s_bias_act_ws (CoutPad = 32). */
+/* The same level in ONE call that never materialises the [b,h,w,16] map: conv3x3(3 -> 16) is recomputed from the images on
+ * 16x16x4 MFMAs in each of three passes (channel sums, squared deviations, normalise + leaky_relu(dn_slope) + conv3x3
+ * stride 2 (w2_hwio [3,3,16,16], TF 'SAME') + bias2 + leaky_relu(slope) -> out [b,(h+1)/2,(w+1)/2,16]).  Images addressed as
+ * in m4d_enc_head_fwd; workspace m4d_dinl_workspace_floats(b,16) floats (mean / var left there as by m4d_enc_head_fwd). */
+int m4d_enc_level0_fwd(const float* images, int bsz, long long stride_b, long long stride_t,
+                       const float* w1_hwio, const float* bias1, const float* dn_scale, const float* dn_bias,
+                       float dn_slope, const float* w2_hwio, const float* bias2, float slope,
+                       int b, int h, int w, float* workspace, float* out, void* stream);
 int m4d_enc_head_fwd(const float* images, int bsz, long long stride_b, long long stride_t,
                      const float* w_hwio, const float* bias, int b, int h, int w, int C,
                      float* workspace, float* raw_out, void* stream);

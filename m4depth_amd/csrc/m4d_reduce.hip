@@ -6,6 +6,7 @@
 //     largest activation of the network ([b,H,W,16]);
 //   * the 7 depth metrics of metrics.py in one pass over (gt, est).
 // Partial sums are combined in a fixed order (no atomics): results are run-to-run identical.
+#include <cstdlib>
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
 
@@ -246,6 +247,267 @@ metrics_finalize_kernel(const double* __restrict__ partial, int nblk, float* __r
   }
 }
 
+
+// ---- encoder level 0 WITHOUT its [b,H,W,16] intermediate (m4d_enc_level0_fwd) ------------------------------------------
+// The head of the network (m4depth_network.py:79-87 with DINL) is conv3x3(RGB, 3 -> 16) -> DomainNormalization ->
+// leaky_relu -> conv3x3 stride 2 (16 -> 16).  The 16-channel full-resolution map (63 MB for two 384x1280 frames) was
+// written once and read twice (two-pass variance, then the stride-2 convolution: ~190 us for two frames).  K = 27 is small
+// but not too small for v_mfma_f32_16x16x4_f32 (16 pixels x 16 channels, 7 k-steps = 224 cycles per SIMD): the first
+// convolution is cheap enough to be RECOMPUTED from the RGB image (12 MB) in every pass -- sum, squared deviations,
+// and the fused pass that normalises the recomputed map in LDS and convolves it with stride 2.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Per-lane operands of the 3 -> 16 convolution as 16x16x4 MFMAs: lane (i = lane & 15, g = lane >> 4) supplies
+// A[pixel i][k = 4 s + g] and B[k][cout i] in step s; k = (ky * 3 + kx) * 3 + channel = ky * 9 + (kx * 3 + channel), so the
+// A element sits koff[s] = ky * row_stride + k % 9 floats after the window's top-left RGB value.  k = 27 (s = 6, g = 3) is
+// padding: zero weight.
+__device__ __forceinline__ void enc0_lane_setup(const float* __restrict__ w27, int lane, int row_stride, int (&koff)[7], float (&wb)[7]) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const int k = 4 * s + g;
+    const bool valid = k < 27;
+    const int kk = valid ? k : 0;
+    koff[s] = (kk / 9) * row_stride + kk % 9;
+    wb[s] = valid ? w27[k * 16 + j] : 0.f;
+  }
+}
+// window_base = &tile[window top-left of pixel i of this lane]; returns rows 4 g .. 4 g + 3 (pixels) of column j (cout)
+__device__ __forceinline__ f32x4 enc0_conv1(const float* window_base, const int (&koff)[7], const float (&wb)[7]) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 7; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(window_base[koff[s]], wb[s], acc, 0, 0, 0);
+  return acc;
+}
+
+constexpr int kE0TW = 128, kE0TH = 8;              // statistics tile (pixels)
+constexpr int kE0RS = (kE0TW + 2) * 3;             // floats per staged RGB row (390)
+
+// PASS 0: per-channel sums of conv1 + bias; PASS 1: sums of squared deviations from `mean` -- partials in the layout of
+// dinl_partial_kernel ([image][block][16]), finished by dinl_finalize_kernel.  A workgroup walks tiles blockIdx.x, + gridDim.x, ...
+template <int PASS>
+__global__ void __launch_bounds__(256)
+enc0_stats_kernel(const float* __restrict__ img, const float* __restrict__ w27, const float* __restrict__ bias,
+                  const float* __restrict__ mean, int h, int w, int bsz, long long stride_b, long long stride_t,
+                  int tiles_x, int n_tiles, float* __restrict__ partial) {
+  __shared__ float tile[(kE0TH + 2) * kE0RS];      // 15.6 KB
+  __shared__ float sh[4][16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int bi = blockIdx.y;
+  const float* ib = img + (long long)(bi % bsz) * stride_b + (long long)(bi / bsz) * stride_t;
+  int koff[7]; float wb[7];
+  enc0_lane_setup(w27, lane, kE0RS, koff, wb);
+  const float bias_j = bias[j];
+  const float mean_j = PASS ? mean[bi * 16 + j] : 0.f;
+  float csum = 0.f;
+  for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+    const int y0 = (ti / tiles_x) * kE0TH, x0 = (ti % tiles_x) * kE0TW;
+    __syncthreads();                               // the previous tile has been consumed
+    for (int idx = t; idx < (kE0TH + 2) * kE0RS; idx += 256) {
+      const int r = idx / kE0RS, cc = idx - r * kE0RS;
+      const int gy = y0 - 1 + r, gxc = (x0 - 1) * 3 + cc;
+      const bool in = gy >= 0 && gy < h && gxc >= 0 && gxc < w * 3;
+      tile[idx] = in ? ib[(long long)gy * w * 3 + gxc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int yl = 2 * wv + rr;
+#pragma unroll
+      for (int ct = 0; ct < kE0TW / 16; ++ct) {
+        const f32x4 acc = enc0_conv1(tile + yl * kE0RS + 3 * (16 * ct + j), koff, wb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = y0 + yl < h && x0 + 16 * ct + 4 * g + r < w;
+          float v = acc[r] + bias_j;
+          if (PASS) { v = v - mean_j; v = v * v; }
+          csum += valid ? v : 0.f;
+        }
+      }
+    }
+  }
+  csum += __shfl_xor(csum, 16);                    // the four pixel groups of a channel: fixed butterfly
+  csum += __shfl_xor(csum, 32);
+  if (lane < 16) sh[wv][lane] = csum;
+  __syncthreads();
+  if (t < 16) partial[((long long)bi * gridDim.x + blockIdx.x) * 16 + t] = ((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t];
+}
+
+// The MEAN of the first convolution's output needs no convolution: the layer is linear, so
+//   mean_c = bias_c + (1 / hw) sum_{ky,kx,ch} w[ky][kx][ch][c] * S(ky - 1, kx - 1, ch),
+// S(dy, dx, ch) = the sum of channel ch over the pixels a tap (dy, dx) sees = the whole image minus one border row / column
+// (plus the corner both exclude): per image and channel the total, the first / last row and column sums and the corners.
+// enc0_rgb_total_kernel: per-workgroup partial totals; enc0_mean_kernel (one workgroup per image): totals + borders in
+// double, then the 27 x 16 combination.
+__global__ void __launch_bounds__(256)
+enc0_rgb_total_kernel(const float* __restrict__ img, int hw, int bsz, long long stride_b, long long stride_t, float* __restrict__ partial) {
+  __shared__ float sh[4][3];
+  const int t = threadIdx.x, bi = blockIdx.y;
+  const float* ib = img + (long long)(bi % bsz) * stride_b + (long long)(bi / bsz) * stride_t;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int p = blockIdx.x * 256 + t; p < hw; p += gridDim.x * 256) {
+    s0 += ib[(long long)p * 3]; s1 += ib[(long long)p * 3 + 1]; s2 += ib[(long long)p * 3 + 2];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if ((t & 63) == 0) { sh[t >> 6][0] = s0; sh[t >> 6][1] = s1; sh[t >> 6][2] = s2; }
+  __syncthreads();
+  if (t < 3) partial[((long long)bi * gridDim.x + blockIdx.x) * 3 + t] = ((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t];
+}
+
+__global__ void __launch_bounds__(256)
+enc0_mean_kernel(const float* __restrict__ img, const float* __restrict__ partial, int nblk, const float* __restrict__ w27,
+                 const float* __restrict__ bias, int h, int w, int bsz, long long stride_b, long long stride_t, float* __restrict__ mean) {
+  // sums[ch][0] total, [1] row 0, [2] row h-1, [3] column 0, [4] column w-1: every thread gathers its share of all 15, then
+  // one fixed tree over the 256 threads for all of them at once
+  __shared__ double red[15][256];
+  __shared__ double sums[3][5];
+  const int t = threadIdx.x, bi = blockIdx.x;
+  const float* ib = img + (long long)(bi % bsz) * stride_b + (long long)(bi / bsz) * stride_t;
+  double acc[15];
+#pragma unroll
+  for (int q = 0; q < 15; ++q) acc[q] = 0.0;
+  for (int k = t; k < nblk; k += 256)
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) acc[ch * 5] += (double)partial[((long long)bi * nblk + k) * 3 + ch];
+  for (int x = t; x < w; x += 256)
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      acc[ch * 5 + 1] += (double)ib[(long long)x * 3 + ch];
+      acc[ch * 5 + 2] += (double)ib[((long long)(h - 1) * w + x) * 3 + ch];
+    }
+  for (int y = t; y < h; y += 256)
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      acc[ch * 5 + 3] += (double)ib[((long long)y * w) * 3 + ch];
+      acc[ch * 5 + 4] += (double)ib[((long long)y * w + (w - 1)) * 3 + ch];
+    }
+#pragma unroll
+  for (int q = 0; q < 15; ++q) red[q][t] = acc[q];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o)
+#pragma unroll
+      for (int q = 0; q < 15; ++q) red[q][t] += red[q][t + o];
+    __syncthreads();
+  }
+  if (t < 15) sums[t / 5][t % 5] = red[t][0];
+  __syncthreads();
+  if (t < 16) {
+    double m = 0.0;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx)
+        for (int ch = 0; ch < 3; ++ch) {
+          // tap (dy, dx) = (ky - 1, kx - 1): dy = -1 never reaches the last row, dy = +1 never the first (same for columns)
+          const int ry = ky == 0 ? h - 1 : (ky == 2 ? 0 : -1), cx = kx == 0 ? w - 1 : (kx == 2 ? 0 : -1);
+          double sv = sums[ch][0];
+          if (ry >= 0) sv -= sums[ch][ry == 0 ? 1 : 2];
+          if (cx >= 0) sv -= sums[ch][cx == 0 ? 3 : 4];
+          if (ry >= 0 && cx >= 0) sv += (double)ib[((long long)ry * w + cx) * 3 + ch];
+          m += (double)w27[((ky * 3 + kx) * 3 + ch) * 16 + t] * sv;
+        }
+    mean[bi * 16 + t] = (float)((double)bias[t] + m / ((double)h * (double)w));
+  }
+}
+
+constexpr int kF0OW = 16, kF0OH = 8;               // stride-2 output tile
+constexpr int kF0CW = 2 * kF0OW + 1, kF0CH = 2 * kF0OH + 1;   // conv1 region it needs: 33 x 17 (TF 'SAME' on an even size pads bottom / right)
+constexpr int kF0RW = kF0CW + 2, kF0RH = kF0CH + 2;            // RGB region 35 x 19
+constexpr int kF0RS = kF0RW * 3;                   // floats per staged RGB row (105)
+constexpr int kF0NS = 17;                          // floats per normalised pixel in LDS (16 + 1: stride-2 reads conflict-free)
+constexpr int kF0NP = kF0CW * kF0CH;               // 561 conv1 pixels
+
+// conv1 recomputed on the 33x17 region, + bias, DomainNormalization, leaky_relu(dn_slope) -> LDS (zero outside the
+// image: the stride-2 convolution's padding), then conv3x3 stride 2 (16 -> 16) + bias + leaky_relu(slope) -> out.
+__global__ void __launch_bounds__(256)
+enc0_fused_kernel(const float* __restrict__ img, const float* __restrict__ w27, const float* __restrict__ bias1,
+                  const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ dn_scale,
+                  const float* __restrict__ dn_bias, float dn_slope, const float* __restrict__ w2, const float* __restrict__ bias2,
+                  float slope, int h, int w, int oh, int ow, int pad_y, int pad_x, int bsz, long long stride_b, long long stride_t,
+                  int tiles_x, float* __restrict__ out) {
+  __shared__ float rgb[kF0RH * kF0RS];             // 8 KB
+  __shared__ float nrm[kF0NP * kF0NS];             // 38 KB
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int bi = blockIdx.y;
+  const float* ib = img + (long long)(bi % bsz) * stride_b + (long long)(bi / bsz) * stride_t;
+  const int oy0 = (blockIdx.x / tiles_x) * kF0OH, ox0 = (blockIdx.x % tiles_x) * kF0OW;
+  const int cy0 = 2 * oy0 - pad_y, cx0 = 2 * ox0 - pad_x;   // conv1 region origin (image coordinates; TF 'SAME': pad_before = 0 on even sizes, 1 on odd)
+  for (int idx = t; idx < kF0RH * kF0RS; idx += 256) {
+    const int r = idx / kF0RS, cc = idx - r * kF0RS;
+    const int gy = cy0 - 1 + r, gxc = (cx0 - 1) * 3 + cc;
+    const bool in = gy >= 0 && gy < h && gxc >= 0 && gxc < w * 3;
+    rgb[idx] = in ? ib[(long long)gy * w * 3 + gxc] : 0.f;    // (gxc < 0 for cx0 - 1 < 0: C division, never indexed)
+  }
+  int koff[7]; float wb[7];
+  enc0_lane_setup(w27, lane, kF0RS, koff, wb);
+  const float bias_j = bias1[j];
+  __shared__ float s_mu[16], s_dv[16], s_sc[16], s_bs[16];
+  if (t < 16) {
+    s_mu[t] = mean[bi * 16 + t];
+    s_dv[t] = 1.0f / (var[bi * 16 + t] + 1e-12f); // (x - mean) / (var + 1e-12): variance, not std (:47), as a multiply
+    s_sc[t] = dn_scale[t]; s_bs[t] = dn_bias[t];
+  }
+  float wb2[36];                                   // B operand of the second convolution: k = tap * 16 + channel = 4 s + g
+#pragma unroll
+  for (int s = 0; s < 36; ++s) wb2[s] = w2[(4 * s + g) * 16 + j];
+  const float bias2_j = bias2[j];
+  __syncthreads();
+  // ---- phase 1a: conv1 + bias of the 561 region pixels as 36 tiles of 16 (pixel p = 16 tile + i, row-major), 9 per wave -> LDS
+  for (int tl = wv; tl < (kF0NP + 15) / 16; tl += 4) {
+    const int pa = min(16 * tl + j, kF0NP - 1);    // this lane's A pixel
+    const int ay = pa / kF0CW, ax = pa - ay * kF0CW;
+    const f32x4 acc = enc0_conv1(rgb + ay * kF0RS + 3 * ax, koff, wb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = 16 * tl + 4 * g + r;           // the pixel of accumulator row r
+      if (p < kF0NP) nrm[p * kF0NS + j] = acc[r] + bias_j;
+    }
+  }
+  __syncthreads();
+  // ---- phase 1b: DomainNormalization + leaky_relu per pixel, in place (one thread per pixel: the 1/sqrt once, not per channel)
+  for (int p = t; p < kF0NP; p += 256) {
+    const int py = p / kF0CW, px = p - py * kF0CW;
+    const bool inside = cy0 + py >= 0 && cy0 + py < h && cx0 + px >= 0 && cx0 + px < w;
+    float* q = nrm + p * kF0NS;
+    float n[16];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { n[c] = (q[c] - s_mu[c]) * s_dv[c]; ss = ss + n[c] * n[c]; }
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));                      // tf.math.l2_normalize
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float o = s_sc[c] * (n[c] * inv) + s_bs[c];
+      o = o > 0.f ? o : o * dn_slope;
+      q[c] = inside ? o : 0.f;                     // outside the image: the zero padding of the stride-2 convolution
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: 8 rows of 16 stride-2 outputs, 2 rows per wave; A[pixel i][k]: pixel (2 oy + ky, 2 i + kx), channel
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int oyl = 2 * wv + rr;
+    const float* base = nrm + ((2 * oyl) * kF0CW + 2 * j) * kF0NS + g;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+      const int tap = s >> 2, ky = tap / 3, kx = tap - 3 * ky;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(base[(ky * kF0CW + kx) * kF0NS + 4 * (s & 3)], wb2[s], acc, 0, 0, 0);
+    }
+    const int oy = oy0 + oyl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ox = ox0 + 4 * g + r;
+      if (oy < oh && ox < ow) {
+        float v = acc[r] + bias2_j;
+        v = v > 0.f ? v : v * slope;
+        out[(((long long)bi * oh + oy) * ow + ox) * 16 + j] = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" long long m4d_dinl_workspace_floats(int b, int C) {
@@ -306,6 +568,46 @@ extern "C" int m4d_enc_head_fwd(const float* images, int bsz, long long stride_b
   if (nblk2 > kDinlMaxBlocks) nblk2 = kDinlMaxBlocks;
   hipLaunchKernelGGL(dinl_partial_kernel, dim3(nblk2, b), dim3(256), 0, s, (const float*)raw_out, (const float*)mean, hw, C, 1, partial);
   hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk2, C, hw, var);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_enc_level0_fwd(const float* images, int bsz, long long stride_b, long long stride_t,
+                                   const float* w1_hwio, const float* bias1, const float* dn_scale, const float* dn_bias,
+                                   float dn_slope, const float* w2_hwio, const float* bias2, float slope,
+                                   int b, int h, int w, float* workspace, float* out, void* stream) {
+  M4D_CHECK_ARG(images && w1_hwio && bias1 && dn_scale && dn_bias && w2_hwio && bias2 && workspace && out);
+  M4D_CHECK_ARG(b > 0 && h > 0 && w > 0 && bsz > 0 && b % bsz == 0 && stride_b >= 0 && stride_t >= 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = 16, hw = h * w;
+  const int tiles_x = (w + kE0TW - 1) / kE0TW, n_tiles = tiles_x * ((h + kE0TH - 1) / kE0TH);
+  const int nblk = n_tiles < kDinlMaxBlocks ? n_tiles : kDinlMaxBlocks;
+  float* partial = workspace;
+  float* mean = workspace + (long long)b * kDinlMaxBlocks * C;
+  float* var = mean + (long long)b * C;
+  static int analytic_mean = -1;                   // M4D_ENC0_ANALYTIC_MEAN=0: the mean from a convolution pass instead
+  if (analytic_mean < 0) { const char* e = getenv("M4D_ENC0_ANALYTIC_MEAN"); analytic_mean = e ? atoi(e) : 1; }
+  if (analytic_mean && (h == 1 || w == 1)) analytic_mean = 0;      // (one border row / column would be excluded twice)
+  if (analytic_mean) {
+    int nb3 = (hw + 256 * 16 - 1) / (256 * 16);
+    if (nb3 > kDinlMaxBlocks) nb3 = kDinlMaxBlocks;
+    hipLaunchKernelGGL(enc0_rgb_total_kernel, dim3(nb3, b), dim3(256), 0, s, images, hw, bsz, stride_b, stride_t, partial);
+    hipLaunchKernelGGL(enc0_mean_kernel, dim3(b), dim3(256), 0, s, images, (const float*)partial, nb3, w1_hwio, bias1, h, w, bsz,
+                       stride_b, stride_t, mean);
+  } else {
+    hipLaunchKernelGGL(enc0_stats_kernel<0>, dim3(nblk, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)nullptr, h, w, bsz,
+                       stride_b, stride_t, tiles_x, n_tiles, partial);
+    hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
+  }
+  hipLaunchKernelGGL(enc0_stats_kernel<1>, dim3(nblk, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)mean, h, w, bsz,
+                     stride_b, stride_t, tiles_x, n_tiles, partial);
+  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, var);
+  const int oh = (h + 1) / 2, ow = (w + 1) / 2;
+  const int ftx = (ow + kF0OW - 1) / kF0OW, fty = (oh + kF0OH - 1) / kF0OH;
+  const int tot_y = (oh - 1) * 2 + 3 - h, tot_x = (ow - 1) * 2 + 3 - w;                 // TF 'SAME' total padding
+  const int pad_y = (tot_y > 0 ? tot_y : 0) / 2, pad_x = (tot_x > 0 ? tot_x : 0) / 2;
+  hipLaunchKernelGGL(enc0_fused_kernel, dim3(ftx * fty, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)mean,
+                     (const float*)var, dn_scale, dn_bias, dn_slope, w2_hwio, bias2, slope, h, w, oh, ow, pad_y, pad_x, bsz, stride_b,
+                     stride_t, ftx, out);
   return M4D_LAUNCH_RESULT();
 }
 

@@ -119,6 +119,9 @@ fused_refiner_tail = _os.environ.get("M4D_FUSED_TAIL", "1") == "1"
 level_pipeline_streams = int(_os.environ.get("M4D_LEVEL_PIPELINE", "8"))
 # Encoding every frame on its own stream too (instead of one encoder pass batched over the frames, before the
 # decoder) was measured slightly slower (633 vs 643 frames/s at batch 1): the batched pass has 4x fewer launches.
+# Encoder level 0 (conv 3->16, DINL, conv 16->16 stride 2) as m4d_enc_level0_fwd: three passes that recompute the first
+# convolution from the RGB frames instead of writing / re-reading its full-resolution 16-channel output.  0 = the two-call head.
+fused_encoder_level0 = _os.environ.get("M4D_FUSED_ENC0", "1") == "1"
 pipeline_encoder_per_frame = _os.environ.get("M4D_PIPELINE_ENCODER", "0") == "1"
 # Encoder in two batches instead: frames [0, split) before the decoder, frames [split, T) on frame `split`'s stream.
 pipeline_encoder_split = int(_os.environ.get("M4D_PIPELINE_ENCODER_SPLIT", "2"))
@@ -300,7 +303,7 @@ class _Conv3x3SameTF(torch.nn.Module):
                 fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
                 return _timed("conv", self.tag, lambda: fn(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
             wp, cpad = self._packed_weights(cin_)
-            if (self.small_maps_ok and self.stride == 1 and b_ * h_ * w_ <= small_map_conv_pixels and 16 <= cin_ <= 256
+            if (self.small_maps_ok and self.stride == 1 and (1 if self.per_image_dispatch else b_) * h_ * w_ <= small_map_conv_pixels and 16 <= cin_ <= 256
                     and cin_ % 4 == 0):
                 return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(
                     x_nhwc, wp, self.bias, self.out_channels, cpad, act))
@@ -361,6 +364,7 @@ class FeaturePyramid(torch.nn.Module):
         self.dn_layers = torch.nn.ModuleList([DomainNormalization(regularizer_weight) for _ in self.out_sizes])
         for conv in list(self.conv_layers_s1) + list(self.conv_layers_s2):
             conv.per_image_dispatch = True
+            conv.small_maps_ok = True            # the stride-1 layers of the coarsest levels: one launch instead of split-K + reduce
 
     def forward(self, images):
         """``images``: [b,H,W,3], or a ``network_ops.FrameStack`` (the frames of a sequence batch, encoded in one pass)."""
@@ -377,6 +381,13 @@ class FeaturePyramid(torch.nn.Module):
                 # level 0 in two fused calls: conv 3->16 + bias + DINL statistics; stride-2 conv normalising its input on the fly
                 if dn_layer.scale is None:
                     dn_layer._build(16, feature_maps.device)
+                if fused_encoder_level0 and conv_s2.out_channels == 16:
+                    # one call, no [b,H,W,16] intermediate: the 3 -> 16 convolution recomputed on the matrix cores per pass
+                    feature_maps = _timed("enc0", 0, lambda: nops.encoder_level0(
+                        feature_maps, conv_s1._hwio_device(), conv_s1.bias, dn_layer.scale, dn_layer.bias,
+                        conv_s2._hwio_device(), conv_s2.bias, 0.1))
+                    outputs.append(feature_maps)
+                    continue
                 wp2, cpad2 = conv_s2._packed_weights()
                 feature_maps = nops.encoder_head(feature_maps, conv_s1._hwio_device(), conv_s1.bias, dn_layer.scale, dn_layer.bias,
                                                  wp2, conv_s2.bias, conv_s2.out_channels, cpad2, 0.1)
@@ -794,6 +805,8 @@ class M4Depth(torch.nn.Module):
             if isinstance(conv, _Conv3x3SameTF) and conv.weight is not None and conv.weight.is_cuda:
                 cin = conv.weight.shape[1]
                 conv._packed_weights()
+                if cin == 3 or (conv.stride == 2 and cin == 16 and conv.out_channels == 16):
+                    conv._hwio_device()                # the encoder's level-0 kernels read the TF layout directly
                 if conv.stride == 1 and cin >= 16 and cin % 2 == 0:
                     conv._packed_weights_winograd(16)
                     if cin % 4 == 0:

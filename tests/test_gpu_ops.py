@@ -514,6 +514,39 @@ def test_fused_encoder_head(M, dev, weights):
     assert err < 2e-5 * max(1.0, np.abs(ref).max()), err
 
 
+@pytest.mark.parametrize("weights,b,h,w", [("random", 2, 36, 52), ("trained", 2, 36, 52), ("random", 1, 37, 53),
+                                           ("random", 3, 16, 130), ("random", 1, 64, 272)])
+def test_encoder_level0_without_intermediate(M, dev, weights, b, h, w):
+    """m4d_enc_level0_fwd: conv 3->16 recomputed on 16x16x4 MFMAs in three passes (sums, squared deviations, normalise +
+    stride-2 convolution), never writing the [b,h,w,16] map -- vs the oracle's conv -> domain_normalization -> leaky_relu ->
+    conv(stride 2) -> leaky_relu; even and odd sizes (TF 'SAME' pads differently), tiles ragged in both directions, several
+    statistics tiles per workgroup row, and the frames of a sequence batch read in place (FrameStack)."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(h * 7 + w)
+    img = rng.random([b, h, w, 3]).astype(F)
+    k1 = (rng.standard_normal([3, 3, 3, 16]) * np.sqrt(2.0 / 27)).astype(F)
+    b1 = (0.1 * rng.standard_normal([16])).astype(F)
+    k2 = (rng.standard_normal([3, 3, 16, 16]) * np.sqrt(2.0 / 144)).astype(F)
+    b2 = (0.1 * rng.standard_normal([16])).astype(F)
+    if weights == "trained":
+        tw = _trained_legacy_encoder_weights()
+        k1, b1, k2, b2 = tw[1, 1, "kernel"], tw[1, 1, "bias"], tw[1, 2, "kernel"], tw[1, 2, "bias"]
+    sc = (1.0 + 0.1 * rng.standard_normal([16])).astype(F)
+    bs = (0.1 * rng.standard_normal([16])).astype(F)
+    t = O.conv2d_same(img, k1, b1, 1)
+    t = O.leaky_relu(O.domain_normalization(t, sc, bs), 0.1)
+    ref = O.leaky_relu(O.conv2d_same(t, k2, b2, 2), 0.1)
+    args = (to_dev(k1.copy(), dev), to_dev(b1, dev), to_dev(sc, dev), to_dev(bs, dev), to_dev(k2.copy(), dev), to_dev(b2, dev), 0.1)
+    got = nops.encoder_level0(to_dev(img, dev), *args)
+    assert got.shape == ref.shape
+    err = np.max(np.abs(npy(got) - ref))
+    assert err < 2e-5 * max(1.0, np.abs(ref).max()), err
+    assert torch.equal(got, nops.encoder_level0(to_dev(img, dev), *args))          # deterministic
+    if b >= 2:                                       # [bsz=1, T=b] sequence batch read in place = the dense batch, bit for bit
+        seq = to_dev(img[None], dev)                 # [1, T, h, w, 3]
+        assert torch.equal(got, nops.encoder_level0(nops.FrameStack(seq), *args))
+
+
 def test_encoder_level_2_with_trained_weights(M, dev):
     """16->32 stride 1 and 32->32 stride 2 (TF SAME) through the MFMA convolution with the trained weights of the
     reference's legacy encoder (tests/golden/tf_legacy) vs the oracle."""
