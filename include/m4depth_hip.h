@@ -351,6 +351,10 @@ int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const float* bias, 
  * deterministic.  The caller picks it by map size (m4depth_amd.network: refiner layers with b*h*w <= 2048 and Cin <= 256). */
 int m4d_conv3x3_small_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
                                int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
+/* ... with float32 operands split exactly into three bf16 terms on the bf16 matrix cores (float32 accuracy, see
+ * m4d_conv3x3_wino6_bias_act); wp6 = network_ops.pack_conv_weights_small6 ([Cin/16][9][CoutPad][3][16] bf16). */
+int m4d_conv3x3_small6_bias_act(const float* x, const void* wp6, const float* bias, int b, int h, int w,
+                                int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
 
 /* DomainNormalization (m4depth_network.py:44-48) fused with the leaky_relu(slope) that follows it
  * at encoder level 0 (:82-84; slope = 1 for the normalisation alone).  x, out [b,h,w,C] (C = 16 or

@@ -457,6 +457,181 @@ conv3x3_small_kernel(const ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same small-map kernel with float32 operands on the BF16 matrix cores (see m4d_wino6.hip for the arithmetic: every
+// float32 value = the exact sum of three bf16 terms, 6 of the 9 term products kept, float32 accumulation).  In a DIRECT
+// convolution a staged input value meets 9 taps x 32 output channels, so the split (13 VALU instructions per pair of
+// values, once per value while the halo chunk is committed to LDS) costs next to nothing and the MFMA work of a 16-channel
+// chunk drops from 72 x 64 cycles (v_mfma_f32_32x32x2_f32) to 54 x 32 (v_mfma_f32_32x32x16_bf16) -- these launches are a
+// pure per-wave latency chain (one wave per SIMD, most of the chip idle), so that IS their run time.  Weights split on the
+// host (network_ops.pack_conv_weights_small6: [chunk][tap][CoutPad][part][16] bf16, 96 bytes per (tap, cout) row, the
+// layout the LDS image keeps); LDS per wave: halo 60 x 96 B + weights 288 x 96 B = 33 KB.
+typedef __bf16 s6_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 s6_bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int kS6Row = 24;                           // floats per LDS row: 3 parts x 16 bf16 = 96 bytes
+constexpr int kS6A = kSHP * kS6Row;                  // one wave's halo chunk   (5.8 KB)
+constexpr int kS6B = 9 * 32 * kS6Row;                // one wave's weight chunk (27.6 KB)
+
+__device__ __forceinline__ unsigned s6_pk(float a, float b) {
+  s6_bf16x2 v; v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+__global__ void __launch_bounds__(256, 1)
+conv3x3_small6_kernel(const ConvArgs a) {
+  constexpr int A_PER = (kSHP * 4 + 63) / 64;         // 4 float4 per lane (halo pixel x channel quad)
+  constexpr int B_PER = (9 * 32 * 6) / 64;            // 27 float4 per lane (row x 16-byte piece)
+  extern __shared__ __align__(16) float lds_dyn[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  float* lds_a = lds_dyn + wave * (kS6A + kS6B);
+  float* lds_b = lds_a + kS6A;
+  const int tile = blockIdx.x;
+  const int tile_y = (tile / a.tiles_x) * kSH, tile_x = (tile % a.tiles_x) * kSW;
+  const int n0 = blockIdx.y * 32;
+  const int bi = blockIdx.z;
+  const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
+  const unsigned char* wsplit = reinterpret_cast<const unsigned char*>(a.wp);
+
+  int a_off[A_PER], a_dst[A_PER];
+  unsigned a_ok = 0;
+  const int aq = lane & 3;                            // channels 4aq .. 4aq+3 of the chunk
+#pragma unroll
+  for (int u = 0; u < A_PER; ++u) {
+    const int idx = u * 64 + lane;
+    const int hp = min(idx >> 2, kSHP - 1);
+    const int gy = tile_y - 1 + hp / kSHW, gx = tile_x - 1 + hp % kSHW;
+    const bool ok = (idx >> 2) < kSHP && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    a_ok |= ok ? (1u << u) : 0u;
+    a_off[u] = (min(max(gy, 0), a.h - 1) * a.w + min(max(gx, 0), a.w - 1)) * a.Cin + 4 * aq;
+    a_dst[u] = (idx >> 2) < kSHP ? hp * kS6Row + 2 * aq : -1;        // float index of this quad's 8 bytes inside part 0
+  }
+  int b_off[B_PER];                                   // byte offsets inside a chunk's weight block
+#pragma unroll
+  for (int u = 0; u < B_PER; ++u) {
+    const int idx = u * 64 + lane;
+    const int row = idx / 6, c6 = idx - row * 6;      // row = tap * 32 + n
+    b_off[u] = (((row >> 5) * a.CoutPad + n0 + (row & 31)) * 96 + c6 * 16);
+  }
+  const long long b_chunk = 9LL * a.CoutPad * 96;     // bytes
+
+  float4 ra[1][A_PER], rb[1][3][B_PER / 3];           // thirds: one 108-dword array is not kept in registers by hipcc
+  bool ra_ch_ok[1] = {true};
+  auto load_chunk = [&](int chunk, int set) __attribute__((always_inline)) {
+    const int c0 = chunk * kKC;
+    ra_ch_ok[set] = c0 + 4 * aq < a.Cin;
+    const int cc = min(c0, a.Cin - 4 - 4 * aq);
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) ra[set][u] = *reinterpret_cast<const float4*>(ximg + a_off[u] + cc);
+    const unsigned char* wb = wsplit + chunk * b_chunk;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int u = 0; u < B_PER / 3; ++u) rb[set][g][u] = *reinterpret_cast<const float4*>(wb + b_off[g * (B_PER / 3) + u]);
+  };
+  auto commit_chunk = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < A_PER; ++u) {
+      const bool ok = ((a_ok >> u) & 1u) && ra_ch_ok[set];
+      const float v[4] = {ok ? ra[set][u].x : 0.f, ok ? ra[set][u].y : 0.f, ok ? ra[set][u].z : 0.f, ok ? ra[set][u].w : 0.f};
+      unsigned p0[2], p1[2], p2[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {                   // exact 3-way split of a pair: hi, mid (round to nearest), lo (exact)
+        const float x0 = v[2 * e], x1 = v[2 * e + 1];
+        const unsigned q0 = s6_pk(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, q0 << 16), r1 = x1 - __builtin_bit_cast(float, q0 & 0xffff0000u);
+        const unsigned q1 = s6_pk(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, q1 << 16), s1 = r1 - __builtin_bit_cast(float, q1 & 0xffff0000u);
+        p0[e] = q0; p1[e] = q1;
+        p2[e] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+      }
+      if (a_dst[u] >= 0) {
+        *reinterpret_cast<uint2*>(lds_a + a_dst[u]) = make_uint2(p0[0], p0[1]);
+        *reinterpret_cast<uint2*>(lds_a + a_dst[u] + 8) = make_uint2(p1[0], p1[1]);
+        *reinterpret_cast<uint2*>(lds_a + a_dst[u] + 16) = make_uint2(p2[0], p2[1]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int u = 0; u < B_PER / 3; ++u) {
+        const int idx = (g * (B_PER / 3) + u) * 64 + lane;
+        const float4 w4 = rb[set][g][u];              // component-wise: a whole-struct copy out of the array keeps it in scratch
+        *reinterpret_cast<float4*>(lds_b + idx * 4) = make_float4(w4.x, w4.y, w4.z, w4.w);     // rows of 6 pieces, contiguous
+      }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int m = lane & 31, kh = lane >> 5;
+  const float* a_lane = lds_a + ((m >> 3) * kSHW + (m & 7)) * kS6Row + kh * 4;       // + part * 8 floats
+  const float* b_lane = lds_b + m * kS6Row + kh * 4;
+  auto compute_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* ap = a_lane + ((tap / 3) * kSHW + (tap % 3)) * kS6Row;
+      const float* bp = b_lane + tap * 32 * kS6Row;
+      s6_bf16x8 av[3], bv[3];
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        av[part] = *reinterpret_cast<const s6_bf16x8*>(ap + part * 8);
+        bv[part] = *reinterpret_cast<const s6_bf16x8*>(bp + part * 8);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], acc, 0, 0, 0);       // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc, 0, 0, 0);
+    }
+  };
+
+  // (Measured: a second chunk of operands in flight -- 2 x 108 staging registers -- is slower: 24.2 vs 22.5 us on the
+  // 472-channel layer; the chunk time is set by how many bytes ONE CU keeps in flight, not by this wave's prefetch depth.)
+  if (wave < a.n_chunks) {
+    load_chunk(wave, 0);
+    for (int c = wave; c < a.n_chunks; c += 4) {
+      commit_chunk(0);
+      __builtin_amdgcn_wave_barrier();
+      load_chunk(min(c + 4, a.n_chunks - 1), 0);       // unconditional (the surplus load of the last round is never committed)
+      compute_chunk();
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();                                     // the reduction buffer aliases the staging regions
+
+  constexpr int kRP = 36;
+  float* red = lds_dyn;                                // [4 waves][32 pixels][kRP]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+    red[(wave * 32 + mr) * kRP + m] = acc[r];
+  }
+  __syncthreads();
+  {
+    const int p = t >> 3, cq = t & 7;
+    const int oy = tile_y + (p >> 3), ox = tile_x + (p & 7);
+    const int co = n0 + 4 * cq;
+    if (oy < a.oh && ox < a.ow && co < a.Cout) {
+      const float4 s0 = *reinterpret_cast<const float4*>(red + (0 * 32 + p) * kRP + 4 * cq);
+      const float4 s1 = *reinterpret_cast<const float4*>(red + (1 * 32 + p) * kRP + 4 * cq);
+      const float4 s2 = *reinterpret_cast<const float4*>(red + (2 * 32 + p) * kRP + 4 * cq);
+      const float4 s3 = *reinterpret_cast<const float4*>(red + (3 * 32 + p) * kRP + 4 * cq);
+      const float sum[4] = {((s0.x + s1.x) + s2.x) + s3.x, ((s0.y + s1.y) + s2.y) + s3.y,
+                            ((s0.z + s1.z) + s2.z) + s3.z, ((s0.w + s1.w) + s2.w) + s3.w};
+      float* op = a.out + (((long long)bi * a.oh + oy) * a.ow + ox) * a.Cout + co;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (co + e < a.Cout) {
+          float v = sum[e] + a.bias[co + e];
+          op[e] = v > 0.f ? v : v * a.slope;
+        }
+      }
+    }
+  }
+}
+
 // out = leaky_relu(bias + sum_ks ws[ks]) with the partial sums added in split order (deterministic)
 __global__ void __launch_bounds__(256)
 conv_splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias, long long pixels, int Cout,
@@ -534,6 +709,31 @@ extern "C" int m4d_conv3x3_small_bias_act(const float* x, const float* wp, const
     attr_set = true;
   }
   hipLaunchKernelGGL(conv3x3_small_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b), dim3(256),
+                     lds, (hipStream_t)stream, a);
+  return M4D_LAUNCH_RESULT();
+}
+
+// The same layer with float32 operands on the bf16 matrix cores (conv3x3_small6_kernel); wp6 from pack_conv_weights_small6.
+extern "C" int m4d_conv3x3_small6_bias_act(const float* x, const void* wp6, const float* bias, int b, int h, int w,
+                                           int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  M4D_CHECK_ARG(x && wp6 && bias && out && b > 0 && h > 0 && w > 0 && Cout > 0);
+  M4D_CHECK_ARG(Cin >= 16 && Cin % 4 == 0 && CoutPad % 32 == 0 && CoutPad >= Cout);
+  M4D_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)wp6)) & 15u) == 0);
+  ConvArgs a;
+  a.x = x; a.wp = reinterpret_cast<const float*>(wp6); a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
+  a.CoutPad = CoutPad; a.n_chunks = (Cin + kKC - 1) / kKC;
+  a.dn_mean = a.dn_var = a.dn_scale = a.dn_bias = nullptr; a.dn_slope = 1.0f;
+  a.ablate = 0; a.oh = h; a.ow = w; a.pad_y = a.pad_x = 1; a.slope = slope;
+  a.tiles_x = (w + kSW - 1) / kSW; a.tiles_y = (h + kSH - 1) / kSH;
+  a.ksplit = 1; a.chunks_per_split = a.n_chunks; a.ws = nullptr;
+  constexpr size_t lds = (size_t)4 * (kS6A + kS6B) * sizeof(float);                     // 134 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3x3_small6_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b), dim3(256),
                      lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

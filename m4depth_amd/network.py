@@ -54,6 +54,10 @@ winograd2_min_workgroups = int(_os.environ.get("M4D_WINO2_MIN_WG", "60"))
 # MFMA kernels, tools/bench_wino6.py -- at 2.67x less matrix-core time); "f32" = the fp32-MFMA kernels everywhere.
 conv_arith = _os.environ.get("M4D_CONV_ARITH", "bf16x3")
 wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
+# The one-launch small-map convolution in the same arithmetic (csrc/m4d_conv.hip conv3x3_small6_kernel).  These launches are
+# bound by how fast ONE CU streams its slice of the weights, not by the matrix core: -2 us per layer on the 240-channel first
+# layers, nothing elsewhere (tools/bench_small_convs.py); +0.8 % frames/s at batch 1.  0 = the fp32-MFMA small-map kernel.
+small_conv_split = _os.environ.get("M4D_SMALL_CONV_SPLIT", "1") == "1" and conv_arith == "bf16x3"
 
 
 def _use_winograd(b, h, w, cin, cout, stride):
@@ -259,6 +263,16 @@ class _Conv3x3SameTF(torch.nn.Module):
             return torch.from_numpy(wu).to(self.weight.device), cpad
         return self._cache.get(("wino", chunk, cin_pad), _stamp(self.weight), build)
 
+    def _packed_weights_small6(self, cin_pad=None):
+        """(wp6 int16 bits, CoutPad) for m4d_conv3x3_small6_bias_act: the TF kernel split into three bf16 terms on the host."""
+        if cin_pad is not None and cin_pad == self.weight.shape[1]:
+            cin_pad = None
+
+        def build():
+            wp, cpad = nops.pack_conv_weights_small6(self._hwio_numpy(cin_pad))
+            return torch.from_numpy(wp.view("int16")).to(self.weight.device), cpad
+        return self._cache.get(("small6", cin_pad), _stamp(self.weight), build)
+
     def _packed_weights_wino6(self, cin_pad=None):
         """(wu6 int16 bits, CoutPad) for m4d_conv3x3_wino6_bias_act: U = G g G^T split into three bf16 terms on the host."""
         if cin_pad is not None and cin_pad == self.weight.shape[1]:
@@ -305,6 +319,10 @@ class _Conv3x3SameTF(torch.nn.Module):
             wp, cpad = self._packed_weights(cin_)
             if (self.small_maps_ok and self.stride == 1 and (1 if self.per_image_dispatch else b_) * h_ * w_ <= small_map_conv_pixels and 16 <= cin_ <= 256
                     and cin_ % 4 == 0):
+                if small_conv_split:
+                    wp6, cpad6 = self._packed_weights_small6(cin_)
+                    return _timed("conv", self.tag, lambda: nops.conv3x3_small6_bias_act(
+                        x_nhwc, wp6, self.bias, self.out_channels, cpad6, act))
                 return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(
                     x_nhwc, wp, self.bias, self.out_channels, cpad, act))
             return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
@@ -805,6 +823,8 @@ class M4Depth(torch.nn.Module):
             if isinstance(conv, _Conv3x3SameTF) and conv.weight is not None and conv.weight.is_cuda:
                 cin = conv.weight.shape[1]
                 conv._packed_weights()
+                if small_conv_split and conv.small_maps_ok and conv.stride == 1 and 16 <= cin <= 256 and cin % 4 == 0:
+                    conv._packed_weights_small6()
                 if cin == 3 or (conv.stride == 2 and cin == 16 and conv.out_channels == 16):
                     conv._hwio_device()                # the encoder's level-0 kernels read the TF layout directly
                 if conv.stride == 1 and cin >= 16 and cin % 2 == 0:
@@ -821,6 +841,8 @@ class M4Depth(torch.nn.Module):
                 c0._packed_weights(cin_pad)
                 c0._packed_weights_winograd(16, cin_pad)
                 c0._packed_weights_winograd(8, cin_pad)
+                if small_conv_split and cin_pad <= 256:
+                    c0._packed_weights_small6(cin_pad)
                 if cin_pad % 16 == 0 and c0.out_channels >= 64:
                     c0._packed_weights_wino6(cin_pad)
             if len(convs) == 7 and convs[5].weight is not None and convs[5].weight.is_cuda \

@@ -322,6 +322,33 @@ def pack_conv_weights_wino6(kernel_hwio):
     return w.reshape(nch, ng, 16, 2, 3, 64, 8), cpad
 
 
+def pack_conv_weights_small6(kernel_hwio):
+    """A TF HWIO [3,3,Cin,Cout] kernel split exactly into three bf16 terms per weight, for m4d_conv3x3_small6_bias_act:
+    [ceil(Cin/16)][9 taps][CoutPad][3 parts][16 channels] bf16 (uint16 bits), Cin zero-padded to a multiple of 16, CoutPad = Cout
+    rounded up to 32.  numpy in, (numpy uint16, CoutPad) out."""
+    import numpy as np
+    k = np.asarray(kernel_hwio, dtype=np.float32)
+    assert k.shape[:2] == (3, 3)
+    cin, cout = k.shape[2], k.shape[3]
+    nch = -(-cin // 16)
+    cpad = -(-cout // 32) * 32
+    full = np.zeros((9, nch * 16, cpad), np.float32)
+    full[:, :cin, :cout] = k.reshape(9, cin, cout)
+    parts = split_bf16x3(full).reshape(3, 9, nch, 16, cpad)       # part, tap, chunk, channel, n
+    return np.ascontiguousarray(parts.transpose(2, 1, 4, 0, 3)), cpad   # chunk, tap, n, part, channel
+
+
+def conv3x3_small6_bias_act(x, wp6, bias, cout, cout_pad, slope=0.1):
+    """The one-launch small-map convolution with float32 operands split into three bf16 terms (csrc/m4d_conv.hip,
+    conv3x3_small6_kernel): float32 accuracy at 2.7x less matrix-core time per wave."""
+    x = as_f32(x, "x")
+    b, h, w, cin = x.shape
+    out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    check(lib.m4d_conv3x3_small6_bias_act(dptr(x, "x"), dptr(wp6, "wp6", torch.int16), dptr(bias, "bias"), b, h, w, cin, int(cout),
+                                          int(cout_pad), float(slope), dptr(out), stream_ptr()), "m4d_conv3x3_small6_bias_act")
+    return out
+
+
 def conv3x3_wino6_bias_act(x, wu6, bias, cout, cout_pad, slope=0.1):
     """3x3 stride-1 TF-'SAME' convolution + bias + leaky_relu(slope): Winograd F(2x2,3x3), float32 operands split into
     three bf16 terms, six bf16 MFMA products per term pair, float32 accumulation (csrc/m4d_wino6.hip)."""

@@ -447,6 +447,34 @@ def test_winograd_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
     assert torch.equal(got, nops.conv3x3_wino6_bias_act(xd, wd, bd, cout, cpad, slope))          # deterministic
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,slope", [(1, 6, 20, 472, 128, 0.1), (2, 12, 40, 240, 128, 0.1), (1, 24, 80, 128, 96, 0.1),
+                                                  (1, 7, 9, 100, 40, 1.0), (3, 5, 33, 16, 32, 0.1), (1, 13, 17, 64, 5, 1.0)])
+def test_small_map_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
+    """m4d_conv3x3_small6_bias_act (the one-launch small-map convolution with float32 operands split into three bf16 terms) vs the
+    oracle: the tolerance of the fp32-MFMA kernel, an error to the float64 result no larger than the fp32 kernel's, bitwise
+    deterministic; ragged tiles, a partial last chunk (Cin = 100), output-channel padding, batch."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(cin * 3 + cout)
+    x = rng.standard_normal([b, h, w, cin]).astype(F)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = (0.1 * rng.standard_normal([cout])).astype(F)
+    wp6, cpad = nops.pack_conv_weights_small6(k)
+    xd, bd = to_dev(x, dev), to_dev(bias, dev)
+    wd = torch.from_numpy(wp6.view(np.int16)).to(dev)
+    got = nops.conv3x3_small6_bias_act(xd, wd, bd, cout, cpad, slope)
+    act = lambda r: np.where(r > 0, r, r * r.dtype.type(slope))
+    ref32 = act(O.conv2d_same(x, k, bias, 1)).astype(F)
+    with O.float64_reference():
+        ref64 = act(O.conv2d_same(x.astype(np.float64), k.astype(np.float64), bias.astype(np.float64), 1))
+    assert np.max(np.abs(npy(got) - ref32)) < 1e-5 * max(1.0, np.abs(ref32).max())
+    wp, cpad32 = nops.pack_conv_weights(k)
+    f32k = nops.conv3x3_small_bias_act(xd, to_dev(wp, dev), bd, cout, cpad32, slope)
+    e6, e32 = np.abs(npy(got).astype(np.float64) - ref64).mean(), np.abs(npy(f32k).astype(np.float64) - ref64).mean()
+    print(f"small-map conv {cin}->{cout}: mean |error| to float64: bf16 split {e6:.3e}, fp32 MFMA {e32:.3e}")
+    assert e6 <= 1.05 * e32
+    assert torch.equal(got, nops.conv3x3_small6_bias_act(xd, wd, bd, cout, cpad, slope))
+
+
 @pytest.mark.parametrize("b,h,w,quat", [(2, 24, 40, True), (1, 37, 53, False), (1, 6, 20, True)])
 def test_fused_refiner_tail(M, dev, b, h, w, quat):
     """conv(32->16)+lrelu, conv(16->5) and the level tail in one kernel vs the oracle's two convolutions + the oracle's

@@ -177,3 +177,17 @@ def test_bf16_three_way_split_and_wino6_pack():
     w8, cpad8 = nops.pack_conv_weights_winograd(k, chunk=16)                          # [chunk][pos][n][channels], same U
     ref = w8.transpose(1, 0, 3, 2).reshape(16, 48, cpad8)
     assert np.array_equal(full[:, :, :cpad8], ref.astype(np.float64)) and not full[:, :, cout:].any() and not full[:, cin:].any()
+
+
+def test_small6_pack_layout():
+    """pack_conv_weights_small6: [chunk][tap][CoutPad][part][16 channels] bf16, the three parts summing exactly to the weight."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(22)
+    cin, cout = 36, 40                                                                # padded to 48 / 64
+    k = rng.standard_normal([3, 3, cin, cout]).astype(F)
+    w6, cpad = nops.pack_conv_weights_small6(k)
+    assert cpad == 64 and w6.shape == (3, 9, 64, 3, 16) and w6.dtype == np.uint16
+    rec = (w6.astype(np.uint32) << 16).view(np.float32).astype(np.float64).sum(3)     # [chunk, tap, n, channel]
+    full = rec.transpose(1, 0, 3, 2).reshape(9, 48, 64)                               # [tap][cin][cout]
+    assert np.array_equal(full[:, :cin, :cout], k.reshape(9, cin, cout).astype(np.float64))
+    assert not full[:, cin:].any() and not full[:, :, cout:].any()
