@@ -3,7 +3,7 @@ duration, workgroups, kernel -- for the small kernels of the coarse-level chains
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-heads = [i for i, r in enumerate(rows) if "enc_head_conv_kernel" in r["Kernel_Name"]]
+heads = [i for i, r in enumerate(rows) if "enc0_rgb_total_kernel" in r["Kernel_Name"] or "enc_head_conv_kernel" in r["Kernel_Name"]]
 # a step = two encoder batches; take the third-last complete step
 i0, i1 = heads[-7], heads[-5]
 t0 = int(rows[i0]["Start_Timestamp"])
