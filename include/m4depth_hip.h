@@ -351,6 +351,9 @@ int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const float* bias, 
  * deterministic.  The caller picks it by map size (m4depth_amd.network: refiner layers with b*h*w <= 2048 and Cin <= 256). */
 int m4d_conv3x3_small_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
                                int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
+/* ... with stride 1 or 2 (the coarse stride-2 layers of the encoder): out [b, ceil(h/stride), ceil(w/stride), Cout]. */
+int m4d_conv3x3s_small_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                                int Cin, int Cout, int CoutPad, int stride, float slope, float* out, void* stream);
 /* ... with float32 operands split exactly into three bf16 terms on the bf16 matrix cores (float32 accuracy, see
  * m4d_conv3x3_wino6_bias_act); wp6 = network_ops.pack_conv_weights_small6 ([Cin/16][9][CoutPad][3][16] bf16). */
 int m4d_conv3x3_small6_bias_act(const float* x, const void* wp6, const float* bias, int b, int h, int w,

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "m4d_conv3x3s_bias_act_ws": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f,
                                  _c_fp, _c_fp, ctypes.c_longlong, _c_fp],
     "m4d_conv3x3_small_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
+    "m4d_conv3x3s_small_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_small6_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino2_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],

@@ -319,9 +319,14 @@ constexpr int kSHW = kSW + 2, kSHP = (kSW + 2) * (kSH + 2);   // halo 10 x 6 = 6
 constexpr int kSA = kSHP * kRS;                      // floats of one wave's halo chunk   (4.8 KB)
 constexpr int kSB = 9 * 32 * kRS;                    // floats of one wave's weight chunk (23 KB)
 
-__global__ void __launch_bounds__(256, 1)            // one workgroup per CU (111 KB of LDS): the whole register file is available
+// STRIDE 2 (the coarse stride-2 layers of the encoder): the halo of the 8x4 output tile is 17 x 9 pixels, the A fragment of
+// output pixel (y, x) and tap (ky, kx) sits at halo pixel (2 y + ky, 2 x + kx); TF 'SAME' pad before = a.pad_y / a.pad_x.
+template <int STRIDE>
+__global__ void __launch_bounds__(256, 1)            // one workgroup per CU (111 / 141 KB of LDS): the whole register file is available
 conv3x3_small_kernel(const ConvArgs a) {
-  constexpr int A_PER = (kSHP * 4 + 63) / 64;         // 4 float4 per lane
+  constexpr int kSHW = (kSW - 1) * STRIDE + 3, kSHH = (kSH - 1) * STRIDE + 3, kSHP = kSHW * kSHH;   // halo 10 x 6 / 17 x 9 pixels
+  constexpr int kSA = kSHP * kRS;                     // floats of one wave's halo chunk (4.8 / 12.2 KB)
+  constexpr int A_PER = (kSHP * 4 + 63) / 64;         // 4 / 10 float4 per lane
   constexpr int B_PER = (9 * 32 * 4) / 64;            // 18 float4 per lane
   extern __shared__ __align__(16) float lds_dyn[];
   const int t = threadIdx.x, lane = t & 63;
@@ -342,7 +347,7 @@ conv3x3_small_kernel(const ConvArgs a) {
   for (int u = 0; u < A_PER; ++u) {
     const int idx = u * 64 + lane;
     const int hp = min(idx >> 2, kSHP - 1);
-    const int gy = tile_y - 1 + hp / kSHW, gx = tile_x - 1 + hp % kSHW;
+    const int gy = tile_y * STRIDE - a.pad_y + hp / kSHW, gx = tile_x * STRIDE - a.pad_x + hp % kSHW;
     const bool ok = (idx >> 2) < kSHP && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
     a_ok |= ok ? (1u << u) : 0u;
     a_off[u] = (min(max(gy, 0), a.h - 1) * a.w + min(max(gx, 0), a.w - 1)) * a.Cin + 4 * aq;
@@ -395,7 +400,7 @@ conv3x3_small_kernel(const ConvArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int m = lane & 31, kh = lane >> 5;
-  const float* a_lane = lds_a + ((m >> 3) * kSHW + (m & 7)) * kRS + kh * 8;
+  const float* a_lane = lds_a + ((m >> 3) * STRIDE * kSHW + (m & 7) * STRIDE) * kRS + kh * 8;
   const float* b_lane = lds_b + m * kRS + kh * 8;
   auto compute_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -689,28 +694,42 @@ extern "C" int m4d_conv3x3_bias_act(const float* x, const float* wp, const float
 }
 
 // Small maps: one launch with the K split inside the workgroup instead of split-K + reduce (conv3x3_small_kernel).
-extern "C" int m4d_conv3x3_small_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
-                                          int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
-  M4D_CHECK_ARG(x && wp && bias && out && b > 0 && h > 0 && w > 0 && Cout > 0);
+static int launch_conv3x3_small(const float* x, const float* wp, const float* bias, int b, int h, int w, int Cin, int Cout,
+                                int CoutPad, int stride, float slope, float* out, void* stream) {
+  M4D_CHECK_ARG(x && wp && bias && out && b > 0 && h > 0 && w > 0 && Cout > 0 && (stride == 1 || stride == 2));
   M4D_CHECK_ARG(Cin >= 16 && Cin % 4 == 0 && CoutPad % 32 == 0 && CoutPad >= Cout);
   M4D_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)wp)) & 15u) == 0);
   ConvArgs a;
   a.x = x; a.wp = wp; a.bias = bias; a.out = out; a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
   a.CoutPad = CoutPad; a.n_chunks = (Cin + kKC - 1) / kKC;
   a.dn_mean = a.dn_var = a.dn_scale = a.dn_bias = nullptr; a.dn_slope = 1.0f;
-  a.ablate = 0; a.oh = h; a.ow = w; a.pad_y = a.pad_x = 1; a.slope = slope;
-  a.tiles_x = (w + kSW - 1) / kSW; a.tiles_y = (h + kSH - 1) / kSH;
+  a.ablate = 0; a.slope = slope;
+  a.oh = (h + stride - 1) / stride; a.ow = (w + stride - 1) / stride;
+  const int tot_y = (a.oh - 1) * stride + 3 - h, tot_x = (a.ow - 1) * stride + 3 - w;   // TF 'SAME'
+  a.pad_y = (tot_y > 0 ? tot_y : 0) / 2; a.pad_x = (tot_x > 0 ? tot_x : 0) / 2;
+  a.tiles_x = (a.ow + kSW - 1) / kSW; a.tiles_y = (a.oh + kSH - 1) / kSH;
   a.ksplit = 1; a.chunks_per_split = a.n_chunks; a.ws = nullptr;
-  constexpr size_t lds = (size_t)4 * (kSA + kSB) * sizeof(float);                       // 111 KB
+  const int halo = ((kSW - 1) * stride + 3) * ((kSH - 1) * stride + 3);
+  const size_t lds = (size_t)4 * (halo * kRS + kSB) * sizeof(float);                    // 111 / 141 KB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv3x3_small_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b), dim3(256),
-                     lds, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b);
+  if (stride == 1) hipLaunchKernelGGL(conv3x3_small_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv3x3_small_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
+}
+extern "C" int m4d_conv3x3_small_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                                          int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  return launch_conv3x3_small(x, wp, bias, b, h, w, Cin, Cout, CoutPad, 1, slope, out, stream);
+}
+// ... with stride 1 or 2 (TF 'SAME'); out [b, ceil(h/stride), ceil(w/stride), Cout]
+extern "C" int m4d_conv3x3s_small_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
+                                           int Cin, int Cout, int CoutPad, int stride, float slope, float* out, void* stream) {
+  return launch_conv3x3_small(x, wp, bias, b, h, w, Cin, Cout, CoutPad, stride, slope, out, stream);
 }
 
 // The same layer with float32 operands on the bf16 matrix cores (conv3x3_small6_kernel); wp6 from pack_conv_weights_small6.

@@ -92,6 +92,7 @@ pad_refiner_input = _os.environ.get("M4D_PAD_REFINER_INPUT", "1") == "1"
 # batch 1, +2.5 % frames/s (tools/ab_bench.sh).  Refiner layers only: their batch is the caller's batch in every launch
 # mode, so the pipelined and the single-stream forward keep choosing the same kernel (bitwise-neutrality test).  0 = off.
 small_map_conv_pixels = int(_os.environ.get("M4D_CONV_SMALL_PX", "2048"))
+small_map_stride2 = _os.environ.get("M4D_CONV_SMALL_S2", "1") == "1"     # the coarse stride-2 encoder layers on the one-launch kernel too
 
 # DSCV and SNCV of a small level (<= 6000 pixels) in one launch (m4d_dscv_sncv_fwd).  0 = two launches.
 fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
@@ -325,6 +326,10 @@ class _Conv3x3SameTF(torch.nn.Module):
                         x_nhwc, wp6, self.bias, self.out_channels, cpad6, act))
                 return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(
                     x_nhwc, wp, self.bias, self.out_channels, cpad, act))
+            if (self.small_maps_ok and self.stride == 2 and small_map_stride2 and 16 <= cin_ <= 256 and cin_ % 4 == 0
+                    and (1 if self.per_image_dispatch else b_) * (-(-h_ // 2)) * (-(-w_ // 2)) <= small_map_conv_pixels):
+                return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(      # one launch instead of split-K + reduce
+                    x_nhwc, wp, self.bias, self.out_channels, cpad, act, stride=2))
             return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
                 x_nhwc, wp, self.bias, self.out_channels, cpad, act, stride=self.stride))
         x = x_nhwc.permute(0, 3, 1, 2)

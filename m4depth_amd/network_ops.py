@@ -219,13 +219,14 @@ def conv3x3_bias_act(x, wp, bias, cout, cout_pad, slope=0.1, stride=1):
     return out
 
 
-def conv3x3_small_bias_act(x, wp, bias, cout, cout_pad, slope=0.1):
-    """The stride-1 convolution for small maps: one launch, K split over the waves of a workgroup (no split-K reduce)."""
+def conv3x3_small_bias_act(x, wp, bias, cout, cout_pad, slope=0.1, stride=1):
+    """The convolution for small maps (stride 1 or 2): one launch, K split over the waves of a workgroup (no split-K reduce)."""
     x = as_f32(x, "x")
     b, h, w, cin = x.shape
-    out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
-    check(lib.m4d_conv3x3_small_bias_act(dptr(x, "x"), dptr(wp, "wp"), dptr(bias, "bias"), b, h, w, cin, int(cout),
-                                         int(cout_pad), float(slope), dptr(out), stream_ptr()), "m4d_conv3x3_small_bias_act")
+    out = torch.empty((b, -(-h // stride), -(-w // stride), cout), dtype=torch.float32, device=x.device)
+    check(lib.m4d_conv3x3s_small_bias_act(dptr(x, "x"), dptr(wp, "wp"), dptr(bias, "bias"), b, h, w, cin, int(cout),
+                                          int(cout_pad), int(stride), float(slope), dptr(out), stream_ptr()),
+          "m4d_conv3x3s_small_bias_act")
     return out
 
 

