@@ -191,3 +191,28 @@ def test_small6_pack_layout():
     full = rec.transpose(1, 0, 3, 2).reshape(9, 48, 64)                               # [tap][cin][cout]
     assert np.array_equal(full[:, :cin, :cout], k.reshape(9, cin, cout).astype(np.float64))
     assert not full[:, cin:].any() and not full[:, :, cout:].any()
+
+
+def test_convolution_dispatch_at_the_bench_pyramid():
+    """network._use_winograd at the 384x1280 / 6-level pyramid, batch 1: which kernel family every refiner layer shape gets
+    (6 = bf16-split Winograd, 2 = fp32-MFMA Winograd kernel 2 / 4, 0 = direct or small-map convolution) -- the dispatch the
+    measured numbers of DESIGN.md section 5 refer to; and that M4D_CONV_ARITH=f32 semantics remove kind 6 only."""
+    kinds = {}
+    for lvl, (h, w) in enumerate([(192, 640), (96, 320), (48, 160), (24, 80), (12, 40), (6, 20)], start=1):
+        for cin, cout in [(128, 128), (128, 96), (96, 64), (64, 32)]:
+            kinds[(lvl, cin, cout)] = N._use_winograd(1, h, w, cin, cout, 1)
+    for lvl in (1, 2):
+        assert [kinds[(lvl, ci, co)] for ci, co in [(128, 128), (128, 96), (96, 64)]] == [6, 6, 6], lvl
+    assert kinds[(1, 64, 32)] == 2 and kinds[(2, 64, 32)] == 2          # 32 output channels: the 64-wide split kernel would idle half
+    # level 3 (30 tiles of 16x16): the 128-wide layers are 60 workgroups of the split kernel, 96->64 would be 30 (below its 40) and
+    # takes kernel 2 (60 32-wide workgroups), 64->32 the direct kernel
+    assert [kinds[(3, ci, co)] for ci, co in [(128, 128), (128, 96), (96, 64), (64, 32)]] == [6, 6, 2, 0]
+    assert all(kinds[(lvl, ci, co)] == 0 for lvl in (4, 5, 6) for ci, co in [(128, 128), (128, 96), (96, 64), (64, 32)])
+    assert N._use_winograd(32, 24, 80, 128, 128, 1) == 6                 # batch 32: level 4 fills the chip
+    assert N._use_winograd(1, 192, 640, 128, 128, 2) == 0                # stride 2 never
+    old = N.conv_arith
+    try:
+        N.conv_arith = "f32"
+        assert N._use_winograd(1, 192, 640, 128, 128, 1) == 2 and N._use_winograd(1, 6, 20, 128, 128, 1) == 0
+    finally:
+        N.conv_arith = old
