@@ -57,7 +57,26 @@ wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
 # The one-launch small-map convolution in the same arithmetic (csrc/m4d_conv.hip conv3x3_small6_kernel).  These launches are
 # bound by how fast ONE CU streams its slice of the weights, not by the matrix core: -2 us per layer on the 240-channel first
 # layers, nothing elsewhere (tools/bench_small_convs.py); +0.8 % frames/s at batch 1.  0 = the fp32-MFMA small-map kernel.
-small_conv_split = _os.environ.get("M4D_SMALL_CONV_SPLIT", "1") == "1" and conv_arith == "bf16x3"
+_small_conv_split_env = _os.environ.get("M4D_SMALL_CONV_SPLIT", "1") == "1"
+small_conv_split = _small_conv_split_env and conv_arith == "bf16x3"
+
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def conv_arithmetic(arith):
+    """Run the enclosed calls with ``conv_arith`` = "bf16x3" or "f32" (what ``M4D_CONV_ARITH`` selects at import) and
+    everything derived from it switched consistently; the previous setting is restored on exit.  Not thread-safe."""
+    global conv_arith, small_conv_split
+    if arith not in ("bf16x3", "f32"):
+        raise ValueError(f"conv arithmetic must be 'bf16x3' or 'f32', not {arith!r}")
+    old = (conv_arith, small_conv_split)
+    conv_arith, small_conv_split = arith, _small_conv_split_env and arith == "bf16x3"
+    try:
+        yield
+    finally:
+        conv_arith, small_conv_split = old
 
 
 def _use_winograd(b, h, w, cin, cout, stride):

@@ -34,8 +34,12 @@ def f_input_channels(nbre_cuts, dscv_range=4, sncv_range=3, level_memory=True, S
     return n
 
 
-def init_weights(nbre_levels=6, seed=42, dscv_range=4, sncv_range=3, ablation=None, bias_std=0.0):
+def init_weights(nbre_levels=6, seed=42, dscv_range=4, sncv_range=3, ablation=None, bias_std=0.0, last_layer_gain=1.0):
     """Random-init weights of the M4Depth architecture.
+
+    ``last_layer_gain`` scales the kernel of every level's last refiner convolution (16 -> 5): the log-parallax update
+    and the 4 memory channels then stay small, as in a trained network, instead of the +-2 (a factor 7 in parallax) a
+    He-normal last layer produces -- see ``well_conditioned_case``.
 
     Conv kernels ~ N(0, 2/fan_in) in TF's HWIO layout [3,3,Cin,Cout] (Keras
     HeNormal is the truncated variant; the trained weights are unavailable
@@ -65,6 +69,8 @@ def init_weights(nbre_levels=6, seed=42, dscv_range=4, sncv_range=3, ablation=No
         for i, co in enumerate(REFINER_CHANNELS):
             conv(f"lvl.{d}.conv.{i}", cin, co)
             cin = co
+        if last_layer_gain != 1.0:
+            W[f"lvl.{d}.conv.6.kernel"] = (W[f"lvl.{d}.conv.6.kernel"] * np.float32(last_layer_gain)).astype(np.float32)
     return W
 
 
@@ -79,12 +85,16 @@ def _box_blur5(x):
     return (acc / 25.0).astype(np.float32)
 
 
-def make_sequence(batch, seq_len, height, width, seed=1234):
+def make_sequence(batch, seq_len, height, width, seed=1234, motion="forward"):
     """One batch of ``seq_len``-frame synthetic trajectories.
 
     Returns (traj_samples, camera): a list of per-frame sample dicts and the
     full-resolution intrinsics, exactly what ``M4Depth.call`` takes as
-    ``data = [traj_samples, camera]`` (m4depth_network.py:352-354)."""
+    ``data = [traj_samples, camera]`` (m4depth_network.py:352-354).
+
+    ``motion``: "forward" = translation ~ N((0, 0, 0.3), 0.05^2) (the epipole lies inside the image, where
+    ``depth = (s / parallax - tz) / alpha`` cancels); "lateral" = N((0.3, 0.12, 0.02), (0.03, 0.03, 0.01)^2): the
+    epipole is far outside the image and s / parallax >> |tz| at every pixel."""
     rng = np.random.default_rng(seed)
     cam = {"f": np.tile(np.array([[0.5 * width, 0.5 * height]], np.float32), [batch, 1]),
            "c": np.tile(np.array([[0.5 * width, 0.5 * height]], np.float32), [batch, 1])}
@@ -96,9 +106,34 @@ def make_sequence(batch, seq_len, height, width, seed=1234):
         ang = np.linalg.norm(aa, axis=1, keepdims=True)
         axis = aa / np.maximum(ang, 1e-12)
         quat = np.concatenate([np.cos(ang / 2), axis * np.sin(ang / 2)], axis=1).astype(np.float32)
-        trans = rng.normal([0.0, 0.0, 0.3], 0.05, [batch, 3])
+        if motion == "lateral":
+            trans = rng.normal([0.3, 0.12, 0.02], [0.03, 0.03, 0.01], [batch, 3])
+        elif motion == "forward":
+            trans = rng.normal([0.0, 0.0, 0.3], 0.05, [batch, 3])
+        else:
+            raise ValueError(f"unknown motion {motion!r}")
         nrm = np.linalg.norm(trans, axis=1, keepdims=True)
         trans = np.where(nrm > 1e-3, trans, np.array([[0.0, 0.0, 0.3]])).astype(np.float32)   # t = 0 is 0/0 in the reference
         samples.append({"RGB_im": rgb, "depth": depth, "rot": quat, "trans": trans,
                         "new_traj": np.full([batch], t == 0)})
     return samples, cam
+
+
+WELL_CONDITIONED_GAIN = 0.25
+
+
+def well_conditioned_case(nbre_levels, batch, seq_len, height, width, seed, dscv_range=4, sncv_range=3):
+    """(weights, traj_samples, camera) of the WELL-CONDITIONED parity fixture: the same He-normal weights as everywhere
+    (seed 42) with every level's last refiner layer scaled by 0.25, and lateral camera motion.
+
+    Why: the north-star tolerance is 1e-4 relative on DEPTH.  depth = (s / parallax - tz) / alpha amplifies a parallax
+    error without bound where s / parallax ~ tz (around the epipole of a forward-moving camera), and a He-normal last
+    layer makes the log-parallax span +-2, which a trained network never does; on such inputs ANY two float32
+    evaluations of the network (different convolution summation orders) differ by more than 1e-4 on 0.1-0.5 % of the
+    pixels -- the float32 numpy oracle against its own float64 evaluation included.  On THIS
+    fixture the float32 oracle is within 8e-6 of the float64 evaluation on every pixel (384x1280, 6 levels), so 1e-4
+    can be asserted on 100 % of the pixels."""
+    weights = init_weights(nbre_levels, seed=42, dscv_range=dscv_range, sncv_range=sncv_range,
+                           last_layer_gain=WELL_CONDITIONED_GAIN)
+    samples, cam = make_sequence(batch, seq_len, height, width, seed=seed, motion="lateral")
+    return weights, samples, cam

@@ -133,10 +133,36 @@ def gen_model():
     np.savez_compressed(os.path.join(OUT, "model_cfg1.npz"), **d)
 
 
+def gen_model_well_conditioned():
+    """The WELL-CONDITIONED fixture (m4depth_amd.synthetic.well_conditioned_case: last refiner layer x 0.25, lateral
+    motion), on which the north-star tolerance -- depth within 1e-4 relative -- is asserted on EVERY pixel: at BASELINE
+    config-1 size (128x256, 3 levels, ranges 2/2, one reset + two full frames) and for one 384x1280 / 6-level frame pair
+    (configs[1]'s geometry).  Inputs are regenerated from the seeds by the tests; stored: the per-level depth and
+    parallax of the last frame (the model output is the nearest x2 upsampling of level 0's depth), the 7 metrics, and
+    the float32 oracle's own largest relative depth error against its float64 evaluation (the fixture's noise floor)."""
+    for tag, (L, rd, rs, H, Wd, T, b, seed) in (("cfg1", (3, 2, 2, 128, 256, 3, 1, 1235)),
+                                                ("full", (6, 4, 3, 384, 1280, 2, 1, 1236))):
+        W, samples, cam = S.well_conditioned_case(L, b, T, H, Wd, seed, rd, rs)
+        out, seq = O.M4Depth(W, L, dscv_range=rd, sncv_range=rs)(samples, cam)
+        with O.float64_reference():
+            _, seq64 = O.M4Depth(W, L, dscv_range=rd, sncv_range=rs)(samples, cam)
+        floor = max(float(np.max(np.abs(seq[-1][l]["depth"] - seq64[-1][l]["depth"]) / np.abs(seq64[-1][l]["depth"])))
+                    for l in range(L))
+        d = {"meta": np.array([L, rd, rs, H, Wd, T, b, seed], np.int32),
+             "metrics": O.metrics_batch(samples[-1]["depth"], out["depth"]),
+             "f32_vs_f64_max_rel_depth": np.array(floor, np.float64)}
+        for l in range(L):
+            d[f"l{l}_depth"] = seq[-1][l]["depth"]
+            d[f"l{l}_parallax"] = seq[-1][l]["parallax"]
+        print(f"well-conditioned {tag}: float32 oracle vs float64 evaluation, max relative depth error {floor:.2e}")
+        np.savez_compressed(os.path.join(OUT, f"model_wc_{tag}.npz"), **d)
+
+
 if __name__ == "__main__":
     gen_ops()
     gen_cost_volumes()
     gen_model()
+    gen_model_well_conditioned()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -159,21 +159,29 @@ def _tiled(samples, cam, reps):
     return ts, {k: np.concatenate([v] * reps, axis=0) for k, v in cam.items()}
 
 
-def test_batch32_reduced_size_vs_oracle(dev):
+@pytest.mark.parametrize("fixture", ["well_conditioned", "random_weights"])
+def test_batch32_reduced_size_vs_oracle(dev, fixture):
     """configs[2]'s batch (32 = 2 unique sequences x 16) on a 192x320 / 6-level pyramid: per level the maps have as many
-    pixels as BASELINE's 384x1280 pyramid has at batch 2-8, so the large-grid choices are taken (Winograd kernels 2/4 on
+    pixels as BASELINE's 384x1280 pyramid has at batch 2-8, so the large-grid choices are taken (Winograd kernels on
     levels 1-3, the 3-workgroup/CU direct convolution, tile SNCV, wave DSCV instead of the small-map kernels on levels
     3-4; levels 5-6 still have few enough pixels for the small-map kernels -- BASELINE's own batch-32 geometry is the
-    property test below).  Replicas must be bit-identical to their originals; the two originals are checked against the oracle."""
+    property test below).  Replicas must be bit-identical to their originals; the two originals are checked against the
+    oracle: on the well-conditioned fixture depth AND parallax within 1e-4 relative on every pixel of every level (the
+    north-star tolerance, nothing else asserted on depth); with plain He-normal weights / forward motion -- the
+    documented noise-floor case, where the float32 oracle itself misses its float64 evaluation by more than 1e-4 on
+    0.1-0.5 % of the pixels -- the GPU's error quantiles against the float64 truth must not exceed the oracle's own."""
     from m4depth_amd import network as net
     L, H, Wd, T, uniq, reps = 6, 192, 320, 3, 2, 16
-    W = S.init_weights(L, seed=42)
-    samples, cam = S.make_sequence(uniq, T, H, Wd, seed=1236)
+    if fixture == "well_conditioned":
+        W, samples, cam = S.well_conditioned_case(L, uniq, T, H, Wd, 1236)
+    else:
+        W = S.init_weights(L, seed=42)
+        samples, cam = S.make_sequence(uniq, T, H, Wd, seed=1236)
     ts, tcam = _tiled(samples, cam, reps)
     b = uniq * reps
     # the dispatch this test is about (guards against the thresholds drifting away from it)
     assert net._use_winograd(b, H >> 3, Wd >> 3, 128, 128, 1) != 0           # level 3 on Winograd at this batch
-    assert b * (H >> 4) * (Wd >> 4) > 6000                                   # level 4 (C=96, 4 cuts): tile SNCV / wave DSCV, no merged launch
+    assert b * (H >> 4) * (Wd >> 4) > 6000                                   # level 4 (C=96, 4 cuts): no small-map merged launch
     model = _model(dev, L, W)
     out = model([to_dev(ts, dev), to_dev(tcam, dev)])["depth"]
     assert out.shape == (b, H, Wd, 1) and torch.isfinite(out).all()
@@ -183,23 +191,30 @@ def test_batch32_reduced_size_vs_oracle(dev):
             v = est[key]
             assert torch.equal(v, v[:uniq].repeat(reps, 1, 1, 1)), f"level {l} {key}: replicas differ"
     oout, oseq = O.M4Depth(W, L)(samples, cam)
+    # the same two sequences alone (batch 2: other kernels on most levels)
+    model2 = _model(dev, L, W)
+    out2 = model2([to_dev(samples, dev), to_dev(cam, dev)])["depth"]
+    assert torch.isfinite(out2).all()
+    rp2 = rel_err(npy(model2.last_estimates[-1][0]["parallax"]), npy(model.last_estimates[-1][0]["parallax"][:uniq]), 1e-12)
+    if fixture == "well_conditioned":
+        for l in range(L):
+            est = model.last_estimates[-1][l]
+            rd = rel_err(npy(est["depth"][:uniq]), oseq[-1][l]["depth"], 1e-30)
+            rp = rel_err(npy(est["parallax"][:uniq]), oseq[-1][l]["parallax"], 1e-30)
+            print(f"batch 32 well-conditioned level {l}: depth rel max {rd.max():.2e} parallax rel max {rp.max():.2e}")
+            assert rd.max() < 1e-4 and rp.max() < 1e-4, (l, rd.max(), rp.max())
+        assert rel_err(npy(out[:uniq]), oout["depth"], 1e-30).max() < 1e-4
+        assert rp2.max() < 1e-4, rp2.max()                # batch 2 vs batch 32: other kernels, same answer to 1e-4 everywhere
+        return
     with O.float64_reference():
         _, seq64 = O.M4Depth(W, L)(samples, cam)
     for l in range(L):
         est = model.last_estimates[-1][l]
-        check_depth_and_parallax(npy(est["depth"][:uniq]), npy(est["parallax"][:uniq]), oseq[-1][l]["depth"],
-                                 oseq[-1][l]["parallax"], samples[-1]["rot"], samples[-1]["trans"], _cam_l(cam, l),
-                                 f"batch 32 level {l}", frac_ok=0.98, max_tol=5e-4)
         check_against_float64_truth({"parallax": npy(est["parallax"][:uniq]), "depth": npy(est["depth"][:uniq])},
                                     oseq[-1][l], seq64[-1][l], f"batch 32 level {l}", factor=2.5)
     re = rel_err(npy(out[:uniq]), oout["depth"], 1e-9)
     assert np.median(re) < 1e-5 and np.mean(re < 1e-4) > 0.98
-    # the same two sequences alone (batch 2: other kernels on most levels) agree with their batch-32 run to rounding
-    model2 = _model(dev, L, W)
-    out2 = model2([to_dev(samples, dev), to_dev(cam, dev)])["depth"]
-    rp = rel_err(npy(model2.last_estimates[-1][0]["parallax"]), npy(model.last_estimates[-1][0]["parallax"][:uniq]), 1e-12)
-    assert rp.max() < 5e-4 and np.percentile(rp, 99.9) < 1e-4 and np.median(rp) < 2e-6, (rp.max(), np.median(rp))
-    assert torch.isfinite(out2).all()
+    assert np.percentile(rp2, 99.9) < 1e-4 and np.median(rp2) < 2e-6, (rp2.max(), np.median(rp2))
 
 
 def test_batch32_fullsize_properties(dev):
@@ -209,8 +224,8 @@ def test_batch32_fullsize_properties(dev):
     on the levels whose kernels do not depend on the batch size."""
     import m4depth_amd as M
     L, H, Wd, T, uniq, reps = 6, 384, 1280, 3, 2, 16
-    W = S.init_weights(L, seed=21)
-    samples, cam = S.make_sequence(uniq, T, H, Wd, seed=78)
+    W = S.init_weights(L, seed=21, last_layer_gain=S.WELL_CONDITIONED_GAIN)       # the well-conditioned recipe (other seeds)
+    samples, cam = S.make_sequence(uniq, T, H, Wd, seed=78, motion="lateral")
     ts, tcam = _tiled(samples, cam, reps)
     b = uniq * reps
     model = _model(dev, L, W)
@@ -239,7 +254,7 @@ def test_batch32_fullsize_properties(dev):
         a = npy(model2.last_estimates[-1][l]["parallax"])
         c = npy(model.last_estimates[-1][l]["parallax"][:uniq])
         rp = rel_err(a, c, 1e-12)
-        assert rp.max() < 5e-4 and np.percentile(rp, 99.9) < 1e-4 and np.median(rp) < 2e-6, (l, rp.max(), np.median(rp))
+        assert rp.max() < 1e-4 and np.median(rp) < 2e-6, (l, rp.max(), np.median(rp))
 
 
 # ------------------------------------------------------------------------------- float64 truth
@@ -259,18 +274,18 @@ def test_error_against_float64_truth(dev, winograd):
     L, H, Wd, T, b = 3, 192, 384, 3, 1
     W = S.init_weights(L, seed=42)
     samples, cam = S.make_sequence(b, T, H, Wd, seed=91)
-    old, old_arith = net.winograd_conv, net.conv_arith
+    old = net.winograd_conv
     net.winograd_conv = bool(winograd)
-    net.conv_arith = winograd if winograd else old_arith
     try:
-        if winograd:
-            kind = net._use_winograd(b, H // 2, Wd // 2, 128, 128, 1)
-            assert kind != 0, "pick a size at which level 1 runs on Winograd"
-            assert (kind == 6) == (winograd == "bf16x3"), "the bf16-split kernel must be the one under test (or not)"
-        model = _model(dev, L, W)
-        model([to_dev(samples, dev), to_dev(cam, dev)])
+        with net.conv_arithmetic(winograd if winograd else net.conv_arith):
+            if winograd:
+                kind = net._use_winograd(b, H // 2, Wd // 2, 128, 128, 1)
+                assert kind != 0, "pick a size at which level 1 runs on Winograd"
+                assert (kind == 6) == (winograd == "bf16x3"), "the bf16-split kernel must be the one under test (or not)"
+            model = _model(dev, L, W)
+            model([to_dev(samples, dev), to_dev(cam, dev)])
     finally:
-        net.winograd_conv, net.conv_arith = old, old_arith
+        net.winograd_conv = old
     _, seq32 = O.M4Depth(W, L)(samples, cam)
     with O.float64_reference():
         _, seq64 = O.M4Depth(W, L)(samples, cam)

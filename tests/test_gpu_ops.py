@@ -593,7 +593,9 @@ def test_small_map_conv_stride2(M, dev, b, h, w, cin, cout):
         assert got.shape == ref.shape
         assert np.max(np.abs(npy(got) - ref)) < 1e-5 * max(1.0, np.abs(ref).max()), stride
         assert torch.equal(got, nops.conv3x3_small_bias_act(xd, wd, bd, cout, cpad, 0.1, stride=stride))
-        assert torch.equal(got, nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, 0.1, stride=stride)) or True   # (other summation order)
+        # the split-K kernel sums the same products in another order: equal to float32 rounding, not bit for bit
+        other = nops.conv3x3_bias_act(xd, wd, bd, cout, cpad, 0.1, stride=stride)
+        assert torch.max(torch.abs(got - other)).item() < 2e-6 * max(1.0, np.abs(ref).max()), stride
 
 
 def test_encoder_level_2_with_trained_weights(M, dev):

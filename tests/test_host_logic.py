@@ -210,9 +210,11 @@ def test_convolution_dispatch_at_the_bench_pyramid():
     assert all(kinds[(lvl, ci, co)] == 0 for lvl in (4, 5, 6) for ci, co in [(128, 128), (128, 96), (96, 64), (64, 32)])
     assert N._use_winograd(32, 24, 80, 128, 128, 1) == 6                 # batch 32: level 4 fills the chip
     assert N._use_winograd(1, 192, 640, 128, 128, 2) == 0                # stride 2 never
-    old = N.conv_arith
-    try:
-        N.conv_arith = "f32"
+    before = (N.conv_arith, N.small_conv_split)
+    with N.conv_arithmetic("f32"):
         assert N._use_winograd(1, 192, 640, 128, 128, 1) == 2 and N._use_winograd(1, 6, 20, 128, 128, 1) == 0
-    finally:
-        N.conv_arith = old
+        assert N.small_conv_split is False                               # everything derived from the arithmetic follows it
+    assert (N.conv_arith, N.small_conv_split) == before
+    with pytest.raises(ValueError):
+        with N.conv_arithmetic("fp16"):
+            pass
