@@ -2,7 +2,9 @@
 """bench.py -- frames/s of the M4Depth per-frame inference path on MI355X.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it
-is launched under ``python -m torch.distributed.run`` with one rank per GPU.
+is launched under ``python -m torch.distributed.run`` with one rank per GPU -- and when it is
+invoked PLAINLY with ``--gpus N`` > 1 (no WORLD_SIZE in the environment) it launches those N ranks
+itself (``torchrun_command``); it never prints a line whose ``n_gpus`` differs from ``--gpus``.
 
 One *step* = one pass of the hot path over one batch of synthetic input = the
 reference's ``test_step`` on a 5-D sequence batch (m4depth_network.py:433-474):
@@ -215,15 +217,87 @@ def cpu_baseline(height, width, levels, rd, rs, seq_len=4, repeats=3, seed=1235,
     return res, ((W, samples, cam, out, seq) if keep else None)
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def torchrun_command(gpus, argv, port=None):
+    """The command line that runs this script as ``gpus`` ranks of one node (one process per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def check_world(args, environ, device_count):
+    """What a process started as ``bench.py --gpus N`` has to do: "run" (its world size is N), or "relaunch" (N > 1 and it
+    was invoked plainly: no WORLD_SIZE -> start the N ranks under torch.distributed.run).  Anything else is refused: a line
+    whose n_gpus is not the N that was asked for is worse than no line."""
+    if args.gpus < 1:
+        raise SystemExit(f"--gpus {args.gpus}: need at least one GPU")
+    world = environ.get("WORLD_SIZE")
+    if world is None:
+        if args.gpus == 1:
+            return "run"
+        if device_count < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {device_count} GPU(s) visible on this node")
+        return "relaunch"
+    if int(world) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: refusing to report a line whose "
+                         f"n_gpus differs from --gpus (start it with --nproc-per-node {args.gpus}, or plainly)")
+    return "run"
+
+
+def timed_region(step, steps, D, dev, sync):
+    """EXACTLY ``steps`` calls of ``step`` bracketed by a barrier + device synchronisation on both sides.  Returns
+    (max-over-ranks wall time of the region including the closing barrier, the per-rank wall times without it)."""
+    D.barrier(dev)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt_local = time.perf_counter() - t0
+    D.barrier(dev)
+    dt = time.perf_counter() - t0
+    dt = D.max_over_ranks(dt, dev)
+    per_rank_s = D.all_gather_floats(dt_local, dev)                          # RCCL all-gather (report only)
+    return dt, per_rank_s
+
+
+def report_head(args, world, dt, per_rank_s):
+    """The contract fields of the JSON line: whole-job frames/s = frames of ALL ranks / max-over-ranks time."""
+    if world != args.gpus or len(per_rank_s) != world:
+        raise SystemExit(f"bench.py: world size {world} / {len(per_rank_s)} gathered ranks, but --gpus {args.gpus}")
+    frames = world * args.batch * args.seq_len * args.steps
+    value = frames / dt
+    cfg_name = ("BASELINE.json configs[1]" if (world, args.batch) == (1, 1) else "configs[2]" if (world, args.batch) == (1, 32)
+                else "configs[3] (32 sequences per rank)" if args.batch == 32 else "custom batch")
+    return {
+        "metric": "frames/s", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "per_gpu": round(value / world, 2),
+        "full_frames_per_s": round(value * (args.seq_len - 1) / args.seq_len, 2),
+        "per_rank_frames_per_s": [round(args.batch * args.seq_len * args.steps / s, 2) for s in per_rank_s],
+        "config": {"workload": f"{args.height}x{args.width} {args.levels}-level seq_len={args.seq_len} "
+                               f"dscv_range={args.dscv_range} sncv_range={args.sncv_range} batch {args.batch}/GPU = {cfg_name}",
+                   "global_batch": world * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}"}}
+
+
 def main():
     args = parse()
     import torch
+    if check_world(args, os.environ, torch.cuda.device_count()) == "relaunch":
+        cmd = torchrun_command(args.gpus, sys.argv[1:])
+        print(f"[bench] --gpus {args.gpus} invoked without a launcher: starting the ranks with {' '.join(cmd[1:10])} ...",
+              file=sys.stderr, flush=True)
+        os.execv(cmd[0], cmd)
     from m4depth_amd import dist as D
     rank, world, local_rank, dev = D.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if args.batch is None:
         args.batch = 1 if world == 1 else 32                 # configs[1] / configs[3] (32 sequences per rank)
     import m4depth_amd as M
@@ -277,17 +351,7 @@ def main():
     for mr in replicas:
         for m in mr.compiled_metrics:
             m.reset_state()
-    D.barrier(dev)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dt_local = time.perf_counter() - t0
-    D.barrier(dev)
-    dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, dev)
-    per_rank_s = D.all_gather_floats(dt_local, dev)                          # RCCL all-gather (report only)
+    dt, per_rank_s = timed_region(step, args.steps, D, dev, torch.cuda.synchronize)
     for mr in replicas[1:]:                                                   # fold the replicas' Keras-Mean accumulators together
         for m, m2 in zip(model.compiled_metrics, mr.compiled_metrics):
             if m2.total is not None:
@@ -329,39 +393,28 @@ def main():
     if rank != 0:
         return
 
-    frames = world * args.batch * args.seq_len * args.steps
-    value = frames / dt
-    cfg_name = ("BASELINE.json configs[1]" if (world, args.batch) == (1, 1) else "configs[2]" if (world, args.batch) == (1, 32)
-                else "configs[3] (32 sequences per rank)" if args.batch == 32 else "custom batch")
-    out = {
-        "metric": "frames/s", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+    out = report_head(args, world, dt, per_rank_s)
+    out.update({
         "dtype_note": "every tensor, operand and accumulator is float32 (the reference's float16 DSCV products excepted, as in "
                       "the reference).  The wide Winograd convolutions feed the bf16 matrix cores with float32 operands split "
                       "EXACTLY into three bf16 terms (6 of the 9 term products, float32 accumulation): float32 accuracy -- "
                       "measured error against float64 0.8x that of the fp32-MFMA kernels (profiles/r02_bf16_split_probe.txt, "
                       "tools/bench_wino6.py; parity.vs_float64_oracle below) -- not a reduced-precision path; "
                       "M4D_CONV_ARITH=f32 runs the fp32-MFMA kernels instead",
-        "data": "synthetic", "per_gpu": round(value / world, 2),
-        "full_frames_per_s": round(value * (args.seq_len - 1) / args.seq_len, 2),
         "metric_note": "value counts every frame of the sequence the reference's test_step processes, including frame 0, "
                        "which carries new_traj and only runs the encoder + state reset; full_frames_per_s excludes it",
-        "per_rank_frames_per_s": [round(args.batch * args.seq_len * args.steps / s, 2) for s in per_rank_s],
-        "config": {"workload": f"{args.height}x{args.width} {args.levels}-level seq_len={args.seq_len} "
-                               f"dscv_range={args.dscv_range} sncv_range={args.sncv_range} batch {args.batch}/GPU = {cfg_name}",
-                   "global_batch": world * args.batch, "seq_len": args.seq_len, "parallelism": f"dp{world}",
-                   "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",
-                   "kernels": "every kernel of the captured forward is hand-written HIP (libm4depth_hip.so, gfx950): MFMA "
-                              "convolutions with fused bias+leaky-relu (Winograd F(2x2,3x3) on the wide stride-1 layers -- float32 "
-                              "operands as exact 3 x bf16 splits on the bf16 matrix cores, or fp32 MFMA --, direct fp32-MFMA "
-                              "implicit GEMM elsewhere), fused encoder head / refiner tail, the level kernels; no MIOpen, rocBLAS "
-                              "or PyTorch kernel in the graph (torch only launches the 7-metric kernel's host wrapper eagerly)",
-                   "hot_path": "libm4depth_hip.so (HIP, gfx950)"},
         "AbsRel": round(metrics[0], 6), "sequence_batches_in_flight": args.in_flight,
         "launch": "eager" if args.eager else "hipGraph replay of the sequence forward; frames pipelined over the decoder "
                                                   "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)",
-    }
+    })
+    out["config"].update({
+        "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",
+        "kernels": "every kernel of the captured forward is hand-written HIP (libm4depth_hip.so, gfx950): MFMA "
+                   "convolutions with fused bias+leaky-relu (Winograd F(2x2,3x3) on the wide stride-1 layers -- float32 "
+                   "operands as exact 3 x bf16 splits on the bf16 matrix cores, or fp32 MFMA --, direct fp32-MFMA "
+                   "implicit GEMM elsewhere), fused encoder head / refiner tail, the level kernels; no MIOpen, rocBLAS "
+                   "or PyTorch kernel in the graph (torch only launches the 7-metric kernel's host wrapper eagerly)",
+        "hot_path": "libm4depth_hip.so (HIP, gfx950)"})
     if host_rate is not None:
         out["host_input_frames_per_s"] = round(host_rate, 2)
     if timer.events:
@@ -483,6 +536,26 @@ def main():
                                                "oracle_f32_depth_within_1e-4": float(np.mean(rel_o64 < 1e-4)),
                                                "gpu_depth_rel_median": float(np.median(rel_g64)),
                                                "oracle_f32_depth_rel_median": float(np.median(rel_o64))}}
+        # the well-conditioned fixture (tests/golden/model_wc_full.npz: one 384x1280 / 6-level frame pair, golden depths of
+        # the float32 oracle): the north-star tolerance on EVERY pixel
+        try:
+            g = dict(np.load(os.path.join(ROOT, "tests", "golden", "model_wc_full.npz")))
+            L, rd, rs, H, Wd, T, b, seed = [int(v) for v in g["meta"]]
+            Wc, s_wc, cam_wc = S.well_conditioned_case(L, b, T, H, Wd, seed, rd, rs)
+            m_wc = M.M4Depth(nbre_levels=L, dscv_range=rd, sncv_range=rs)
+            m_wc.load_numpy_weights(Wc, dev)
+            m_wc([dv(s_wc), dv(cam_wc)])
+            worst = 0.0
+            for l in range(L):
+                d = m_wc.last_estimates[-1][l]["depth"].cpu().numpy()
+                worst = max(worst, float(np.max(np.abs(d - g[f"l{l}_depth"]) / np.abs(g[f"l{l}_depth"]))))
+            out["parity"]["well_conditioned_fixture"] = {
+                "sample": f"tests/golden/model_wc_full.npz: {H}x{Wd}, {L} levels, one reset + one full frame, last refiner layer x "
+                          f"{S.WELL_CONDITIONED_GAIN}, lateral motion (m4depth_amd.synthetic.well_conditioned_case)",
+                "depth_rel_max_over_all_levels": worst, "depth_within_1e-4": float(worst < 1e-4),
+                "oracle_f32_vs_float64_rel_max": float(g["f32_vs_f64_max_rel_depth"])}
+        except FileNotFoundError:
+            pass
     print(json.dumps(out))
 
 

@@ -1,0 +1,101 @@
+"""bench.py's N > 1 leg without a GPU: the launch decision for a plain ``--gpus N`` invocation, and -- two processes over
+gloo, the level kernels replaced by a stub step -- the rank-sharded synthetic batch, the barrier-bracketed timed region,
+the per-rank rate gather, the metric all-gather and the contract fields of the JSON line (BASELINE configs[3] on the
+GPU box: 32 sequences per rank over RCCL)."""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import bench
+
+
+def _args(**kw):
+    d = dict(gpus=1, steps=3, warmup=1, batch=None, seq_len=3, height=16, width=32, levels=2, dscv_range=4, sncv_range=3)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def test_plain_multi_gpu_invocation_relaunches_under_torchrun():
+    assert bench.check_world(_args(gpus=1), {}, 0) == "run"
+    assert bench.check_world(_args(gpus=2), {}, 8) == "relaunch"                   # invoked plainly: starts its own ranks
+    assert bench.check_world(_args(gpus=8), {"WORLD_SIZE": "8", "RANK": "3"}, 8) == "run"
+    with pytest.raises(SystemExit, match="only 1 GPU"):
+        bench.check_world(_args(gpus=2), {}, 1)
+    with pytest.raises(SystemExit, match="refusing"):                              # never a line with n_gpus != --gpus
+        bench.check_world(_args(gpus=8), {"WORLD_SIZE": "2"}, 8)
+    with pytest.raises(SystemExit, match="refusing"):
+        bench.check_world(_args(gpus=1), {"WORLD_SIZE": "2"}, 8)
+    cmd = bench.torchrun_command(4, ["--gpus", "4", "--steps", "7"], port=12345)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "12345"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    with pytest.raises(SystemExit):
+        bench.report_head(_args(gpus=2, batch=1), 1, 1.0, [1.0])                    # world 1 cannot report --gpus 2
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench as B
+    from m4depth_amd import dist as D
+    from m4depth_amd import metrics as MT
+    args = _args(gpus=world)
+    assert B.check_world(args, os.environ, 0) == "run"
+    r, w, _, dev = D.init_from_env(backend="gloo")
+    args.batch = 1 if w == 1 else 32                       # bench.main's default: configs[3]'s 32 sequences per rank
+    args.batch = 4                                         # (kept small here: the batch is real data)
+    data = B.make_batch(args, r, dev, torch)
+    mets = MT.default_metrics()
+
+    def step():                                            # stands in for model.graphed_test_step: metrics of the last frame
+        time.sleep(0.01 * (r + 1))                         # rank 1 is the slow one
+        gt = data["depth"][:, -1]
+        for m in mets:
+            m.update_state(gt, gt * (1.0 + 0.01 * (r + 1)))
+
+    dt, per_rank_s = B.timed_region(step, args.steps, D, dev, lambda: None)
+    gathered = D.all_gather_metric_states(mets, dev)
+    metrics = D.reduce_metric_states(gathered).tolist()
+    head = B.report_head(args, w, dt, per_rank_s)
+    q.put((r, head, metrics, float(data["RGB_im"].sum()), tuple(data["RGB_im"].shape), dt, per_rank_s))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_bench_leg_over_gloo():
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=180) for _ in range(world)], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, head0, met0, sum0, shape0, dt0, prs0), (r1, head1, met1, sum1, shape1, dt1, prs1) = outs
+    assert shape0 == shape1 == (4, 3, 16, 32, 3)
+    assert sum0 != sum1                                     # every rank generates ITS shard (seeded by rank), not a copy
+    assert dt0 == dt1 and prs0 == prs1 and len(prs0) == 2   # max over ranks / gathered list: the same on every rank
+    assert dt0 >= max(prs0) >= 3 * 0.02 and prs0[1] > prs0[0]
+    for head in (head0, head1):
+        assert head["n_gpus"] == 2 and head["scaling"] == "weak" and head["config"]["global_batch"] == 8
+        assert head["config"]["parallelism"] == "dp2" and len(head["per_rank_frames_per_s"]) == 2
+        frames = 2 * 4 * 3 * 3                              # world x batch x seq_len x steps
+        assert abs(head["value"] - frames / dt0) < 0.02 * head["value"]
+        assert head["per_rank_frames_per_s"][0] > head["per_rank_frames_per_s"][1]          # rank 0 was the fast one
+        assert head["value"] <= sum(head["per_rank_frames_per_s"]) + 1e-6                   # whole job = bounded by the slowest rank
+        assert abs(head["ms_per_step"] - 1e3 * dt0 / 3) < 1e-2
+    # Keras-Mean over both ranks' per-batch values: AbsRel of est = gt (1 + 0.01 (r + 1)) -> mean of 0.01 and 0.02
+    assert met0 == met1 and abs(met0[0] - 0.015) < 1e-4
