@@ -461,15 +461,14 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
   constexpr size_t lds = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);                 // epilogue staging 147 KB (K loop: 142 KB)
   static_assert(lds >= (size_t)kBRingOff + 4 * kBRingBytes, "epilogue staging must cover the K-loop buffers");
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
-  auto launch = [&](auto kernel) {
-    static bool attr_set = false;                  // more than 64 KB of dynamic LDS needs the opt-in (once per instantiation)
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
-  };
-  if (a.stamps) launch(&conv3x3_wino6_kernel<true>);
-  else launch(&conv3x3_wino6_kernel<false>);
+  // more than 64 KB of dynamic LDS needs the opt-in, per kernel (both instantiations share one function-pointer type: set both)
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();                                             // function-local static: initialised once, thread-safe (C++11)
+  (void)attr_set;
+  if (a.stamps) hipLaunchKernelGGL(conv3x3_wino6_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv3x3_wino6_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -237,7 +237,7 @@ def main(argv=None):
             continue
         if args.graph:
             if runner is None:
-                model.test_step(data)              # eager warm-up (MIOpen solver search, state allocation)
+                model.test_step(data)              # eager warm-up (state and scratch allocation, packed weights)
                 for m in model.compiled_metrics:
                     m.reset_state()
                 runner = GraphedSequence(model, data)

@@ -250,11 +250,30 @@ class _Conv3x3SameTF(torch.nn.Module):
         self._cache.clear()
 
     def load_hwio(self, kernel, bias, device):
-        """Load a TF-layout [3,3,Cin,Cout] kernel."""
+        """Load a TF-layout [3,3,Cin,Cout] kernel.  When the layer already holds parameters of the same shape on the same
+        device they are overwritten IN PLACE (``copy_``: same addresses, version bumped), so the packed copies are rebuilt
+        into their existing tensors and a hipGraph captured before the load (``GraphedSequence``) replays the new weights;
+        otherwise the parameters are replaced and any earlier capture is invalid (``GraphedSequence`` detects the changed
+        addresses and raises)."""
         w = _to_device_f32(kernel, device).permute(3, 2, 0, 1)
+        b = _to_device_f32(bias, device).contiguous()
+        if (self.weight is not None and self.bias is not None and self.weight.shape == w.shape and self.bias.shape == b.shape
+                and self.weight.device == w.device):
+            with torch.no_grad():
+                self.weight.copy_(w)
+                self.bias.copy_(b)
+            return
         self.weight = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last), requires_grad=False)
-        self.bias = torch.nn.Parameter(_to_device_f32(bias, device).contiguous(), requires_grad=False)
+        self.bias = torch.nn.Parameter(b, requires_grad=False)
         self._cache.clear()
+
+    def invalidate_packed(self):
+        """Mark every packed copy stale.  Needed only after a write that bypasses autograd's version counter
+        (``param.data.copy_(...)``, raw pointer writes): weights must otherwise be updated in place ON THE PARAMETER
+        (``copy_`` / ``load_state_dict`` / an optimizer step), which the version-keyed caches follow by themselves."""
+        with torch.no_grad():
+            if self.weight is not None:
+                self.weight.add_(0)                     # bumps ._version: every cache keyed on _stamp() rebuilds in place
 
     def _hwio_numpy(self, cin_pad=None):
         """The TF-layout kernel on the host; ``cin_pad`` > Cin appends zero input channels (for a zero-padded input)."""
@@ -315,46 +334,44 @@ class _Conv3x3SameTF(torch.nn.Module):
         return (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)
 
     def forward(self, x_nhwc, slope=None):
-        """Convolution + bias (+ leaky_relu(slope) when ``slope`` is given): one HIP kernel on the GPU.  CPU tensors are
-        only accepted so that the host-logic tests can check the padding rule / layer wiring of the modules without a GPU
-        (plain torch ops; the level kernels themselves have no CPU form and raise)."""
+        """Convolution + bias (+ leaky_relu(slope) when ``slope`` is given): ONE hand-written HIP kernel.  There is no CPU /
+        framework form of this layer in the product: a CPU tensor raises (the host-logic tests patch a torch stand-in over
+        this method from tests/helpers.py to check the layer wiring and the ``same_pads`` rule without a GPU)."""
+        if not x_nhwc.is_cuda:
+            raise RuntimeError("m4depth_amd convolutions run on the GPU only (libm4depth_hip.so): got a CPU tensor; "
+                               "there is no CPU fallback")
         if self.weight is None:
             self._build(x_nhwc.shape[-1], x_nhwc.device)
-        if x_nhwc.is_cuda:
-            if self.stride not in (1, 2):
-                raise ValueError(f"stride {self.stride} is not supported by the HIP convolution")
-            b_, h_, w_, cin_ = x_nhwc.shape
-            act = 1.0 if slope is None else slope
-            # The encoder is run on frames stacked along the batch axis, and how many are stacked depends on the launch mode
-            # (all T frames, two batches in the pipelined forward, one frame when streaming): its kernel choice must not
-            # depend on that, or the modes stop being bit-identical -- decide from the per-image grid.
-            wino = _use_winograd(1 if self.per_image_dispatch else b_, h_, w_, cin_, self.out_channels, self.stride)
-            if wino == 6:
-                wu, cpad = self._packed_weights_wino6(cin_)
-                return _timed("conv", self.tag, lambda: nops.conv3x3_wino6_bias_act(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
-            if wino:
-                wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8, cin_)     # cin_ > Cin: zero-padded input
-                fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
-                return _timed("conv", self.tag, lambda: fn(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
-            wp, cpad = self._packed_weights(cin_)
-            if (self.small_maps_ok and self.stride == 1 and (1 if self.per_image_dispatch else b_) * h_ * w_ <= small_map_conv_pixels and 16 <= cin_ <= 256
-                    and cin_ % 4 == 0):
-                if small_conv_split:
-                    wp6, cpad6 = self._packed_weights_small6(cin_)
-                    return _timed("conv", self.tag, lambda: nops.conv3x3_small6_bias_act(
-                        x_nhwc, wp6, self.bias, self.out_channels, cpad6, act))
-                return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(
-                    x_nhwc, wp, self.bias, self.out_channels, cpad, act))
-            if (self.small_maps_ok and self.stride == 2 and small_map_stride2 and 16 <= cin_ <= 256 and cin_ % 4 == 0
-                    and (1 if self.per_image_dispatch else b_) * (-(-h_ // 2)) * (-(-w_ // 2)) <= small_map_conv_pixels):
-                return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(      # one launch instead of split-K + reduce
-                    x_nhwc, wp, self.bias, self.out_channels, cpad, act, stride=2))
-            return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
-                x_nhwc, wp, self.bias, self.out_channels, cpad, act, stride=self.stride))
-        x = x_nhwc.permute(0, 3, 1, 2)
-        (pt, pb), (pl, pr) = self.same_pads(*x.shape[2:])
-        y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), self.weight, self.bias, self.stride, 0).permute(0, 2, 3, 1).contiguous()
-        return y if slope is None else F.leaky_relu(y, slope)
+        if self.stride not in (1, 2):
+            raise ValueError(f"stride {self.stride} is not supported by the HIP convolution")
+        b_, h_, w_, cin_ = x_nhwc.shape
+        act = 1.0 if slope is None else slope
+        # The encoder is run on frames stacked along the batch axis, and how many are stacked depends on the launch mode
+        # (all T frames, two batches in the pipelined forward, one frame when streaming): its kernel choice must not
+        # depend on that, or the modes stop being bit-identical -- decide from the per-image grid.
+        wino = _use_winograd(1 if self.per_image_dispatch else b_, h_, w_, cin_, self.out_channels, self.stride)
+        if wino == 6:
+            wu, cpad = self._packed_weights_wino6(cin_)
+            return _timed("conv", self.tag, lambda: nops.conv3x3_wino6_bias_act(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
+        if wino:
+            wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8, cin_)     # cin_ > Cin: zero-padded input
+            fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
+            return _timed("conv", self.tag, lambda: fn(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
+        wp, cpad = self._packed_weights(cin_)
+        if (self.small_maps_ok and self.stride == 1 and (1 if self.per_image_dispatch else b_) * h_ * w_ <= small_map_conv_pixels and 16 <= cin_ <= 256
+                and cin_ % 4 == 0):
+            if small_conv_split:
+                wp6, cpad6 = self._packed_weights_small6(cin_)
+                return _timed("conv", self.tag, lambda: nops.conv3x3_small6_bias_act(
+                    x_nhwc, wp6, self.bias, self.out_channels, cpad6, act))
+            return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(
+                x_nhwc, wp, self.bias, self.out_channels, cpad, act))
+        if (self.small_maps_ok and self.stride == 2 and small_map_stride2 and 16 <= cin_ <= 256 and cin_ % 4 == 0
+                and (1 if self.per_image_dispatch else b_) * (-(-h_ // 2)) * (-(-w_ // 2)) <= small_map_conv_pixels):
+            return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(      # one launch instead of split-K + reduce
+                x_nhwc, wp, self.bias, self.out_channels, cpad, act, stride=2))
+        return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
+            x_nhwc, wp, self.bias, self.out_channels, cpad, act, stride=self.stride))
 
 
 class DomainNormalization(torch.nn.Module):
@@ -831,8 +848,15 @@ class M4Depth(torch.nn.Module):
             self.encoder.conv_layers_s1[i].load_hwio(weights[f"enc.s1.{i}.kernel"], weights[f"enc.s1.{i}.bias"], device)
             self.encoder.conv_layers_s2[i].load_hwio(weights[f"enc.s2.{i}.kernel"], weights[f"enc.s2.{i}.bias"], device)
         dn = self.encoder.dn_layers[0]
-        dn.scale = torch.nn.Parameter(_to_device_f32(weights["enc.dn.0.scale"], device).reshape(1, 1, 1, -1), requires_grad=False)
-        dn.bias = torch.nn.Parameter(_to_device_f32(weights["enc.dn.0.bias"], device).reshape(1, 1, 1, -1), requires_grad=False)
+        sc = _to_device_f32(weights["enc.dn.0.scale"], device).reshape(1, 1, 1, -1)
+        bi = _to_device_f32(weights["enc.dn.0.bias"], device).reshape(1, 1, 1, -1)
+        if dn.scale is not None and dn.scale.shape == sc.shape and dn.scale.device == sc.device:
+            with torch.no_grad():                      # in place: kernels (and captured graphs) read these by address
+                dn.scale.copy_(sc)
+                dn.bias.copy_(bi)
+        else:
+            dn.scale = torch.nn.Parameter(sc, requires_grad=False)
+            dn.bias = torch.nn.Parameter(bi, requires_grad=False)
         for lvl in self.d_estimator.levels:
             convs = list(lvl.disp_refiner.prep_conv_layers) + list(lvl.disp_refiner.est_d_conv_layers)
             for i, conv in enumerate(convs):
@@ -873,6 +897,14 @@ class M4Depth(torch.nn.Module):
                     and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16):
                 lvl._tail_weights(convs)
         return self
+
+    def invalidate_packed(self):
+        """Every layer's ``invalidate_packed`` + ``prepack``: after weights were written behind autograd's back
+        (``param.data``-style writes); in-place updates on the parameters themselves need nothing."""
+        for conv in self.modules():
+            if isinstance(conv, _Conv3x3SameTF):
+                conv.invalidate_packed()
+        return self.prepack()
 
     def weights_stamp(self):
         """Cheap identity/version fingerprint of every convolution parameter (see ``_stamp``)."""
@@ -1019,7 +1051,8 @@ class M4Depth(torch.nn.Module):
         if acc is not None and ms and all(m.total is not None and m.total.data_ptr() == acc[i].data_ptr()
                                           and m.count == ms[0].count for i, m in enumerate(ms)):
             if getattr(self, "_metric_mean_count", -1) == ms[0].count and ms[0].count > 0:
-                res = self._metric_mean                      # written by the metric kernel itself (views: valid until the next update)
+                res = self._metric_mean.clone()              # written by the metric kernel itself; a copy: results a caller
+                                                             # keeps per step (a Keras-style history) must not alias the buffer
             else:
                 res = acc / float(max(ms[0].count, 1))
             return {m.name: res[i] for i, m in enumerate(ms)}
@@ -1144,6 +1177,9 @@ class GraphedSequence:
                     self.camera[k].copy_(data["camera"][k], non_blocking=True)
         stamp = self.model.weights_stamp()
         if stamp != self.weights_stamp:                 # the parameters changed (optimizer step, load_state_dict): refresh the
+            if [p for p, _ in stamp] != [p for p, _ in self.weights_stamp]:
+                raise RuntimeError("a convolution parameter was REPLACED (new address) after this hipGraph was captured: the "
+                                   "graph still reads the old buffers -- update weights in place or build a new GraphedSequence")
             self.model.prepack()                        # packed copies in place -- the graph reads the same addresses
             self.weights_stamp = stamp
         self.graph.replay()

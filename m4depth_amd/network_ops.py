@@ -292,12 +292,18 @@ def split_bf16x3(v):
     def widen(b):
         return (b.astype(np.uint32) << 16).view(np.float32)
     v = np.ascontiguousarray(v, dtype=np.float32)
+    if not np.isfinite(v).all():
+        raise ValueError("split_bf16x3: non-finite float32 value (NaN / Inf weights cannot be split into bf16 terms)")
+    # below 2^-110 the third residual would fall into bf16's denormal range and stop being exact: such magnitudes are
+    # 30 orders below anything a float32 accumulation of activations x weights can resolve -- flushed to zero
+    v = np.where(np.abs(v) < np.float32(2.0 ** -110), np.float32(0.0), v)
     p1 = bf16_rn(v)
     r1 = v - widen(p1)
     p2 = bf16_rn(r1)
     r2 = r1 - widen(p2)
     p3 = bf16_rn(r2)
-    assert np.array_equal(widen(p3), r2), "float32 value not representable as three bf16 terms (denormal range?)"
+    if not np.array_equal(widen(p3), r2):
+        raise ValueError("split_bf16x3: a float32 value is not the exact sum of three bf16 terms")
     return np.stack([p1, p2, p3])
 
 

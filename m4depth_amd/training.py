@@ -372,7 +372,7 @@ class GraphedTrainStep:
 
     Requirements: an optimizer whose step is capturable (``torch.optim.Adam(..., capturable=True)``),
     the batch layout of ``example`` for every later call, ``new_traj`` = first frame only (it is
-    host-side control flow baked into the capture).  The eager warm-up steps (MIOpen solver search,
+    host-side control flow baked into the capture).  The eager warm-up steps (packed-weight and
     workspace allocation) are REAL optimizer steps on ``example``."""
 
     def __init__(self, model, example, optimizer, warmup=3, grad_sync=None):

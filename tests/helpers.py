@@ -20,6 +20,30 @@ def motion_np(rng, b, quat=True, t_scale=(1.0, 1.0, 1.0)):
     return rot, trans
 
 
+class torch_convolutions_on_cpu:
+    """Host-logic tests only (no GPU): patches a plain-torch stand-in over ``_Conv3x3SameTF.forward`` -- which in the
+    product has no CPU form and raises -- so that the layer wiring of the encoder / refiner modules, ``load_hwio`` and the
+    TF 'SAME' ``same_pads`` rule can be checked against the oracle on CPU tensors.  Test infrastructure, not a fallback."""
+
+    def __enter__(self):
+        import torch.nn.functional as TF
+        from m4depth_amd import network as N
+        self._cls, self._old = N._Conv3x3SameTF, N._Conv3x3SameTF.forward
+
+        def forward(conv, x_nhwc, slope=None):
+            assert not x_nhwc.is_cuda
+            x = x_nhwc.permute(0, 3, 1, 2)
+            (pt, pb), (pl, pr) = conv.same_pads(*x.shape[2:])
+            y = TF.conv2d(TF.pad(x, (pl, pr, pt, pb)), conv.weight, conv.bias, conv.stride, 0).permute(0, 2, 3, 1).contiguous()
+            return y if slope is None else TF.leaky_relu(y, slope)
+        N._Conv3x3SameTF.forward = forward
+        return self
+
+    def __exit__(self, *exc):
+        self._cls.forward = self._old
+        return False
+
+
 def to_dev(x, dev):
     import torch
     if isinstance(x, dict):

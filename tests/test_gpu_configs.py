@@ -350,3 +350,51 @@ def test_inference_follows_parameter_updates(dev):
     fresh = _model(dev, L, model.numpy_weights())
     assert torch.equal(fresh([ds, dc])["depth"], after), "eager inference used stale packed weights"
     assert torch.equal(runner(d), after), "the captured graph replayed stale packed weights"
+
+
+def test_weight_loads_after_capture_and_metric_result_copies(dev):
+    """(1) ``load_numpy_weights`` / ``load_hwio`` on a built model overwrite the parameters in place, so a
+    hipGraph captured BEFORE the load replays the new weights; a parameter that is REPLACED after the capture makes the
+    replay raise instead of reading freed buffers; (2) a ``param.data`` write (no version bump) is picked up after
+    ``invalidate_packed()``; (3) the results ``test_step`` returns are copies, not views of the metric kernel's buffer."""
+    from m4depth_amd import network as net
+    L, H, Wd, T, b = 3, 64, 96, 2, 1
+    Wa, Wb = S.init_weights(L, seed=8), S.init_weights(L, seed=9)
+    model = _model(dev, L, Wa)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=31)
+    d = {k: torch.stack([to_dev(s[k], dev) for s in samples], dim=1) for k in ("depth", "RGB_im", "rot", "trans")}
+    d["new_traj"] = torch.stack([torch.from_numpy(s["new_traj"]) for s in samples], dim=1)
+    d["camera"] = to_dev(cam, dev)
+    ds, dc = to_dev(samples, dev), to_dev(cam, dev)
+    runner = net.GraphedSequence(model, d)
+    out_a = runner(d).clone()
+    ptrs = [p.data_ptr() for p in model.parameters()]
+    model.load_numpy_weights(Wb, dev)                                   # after the capture
+    assert [p.data_ptr() for p in model.parameters()] == ptrs, "a same-shape load must overwrite in place"
+    fresh = _model(dev, L, Wb)
+    ref_b = fresh([ds, dc])["depth"]
+    assert not torch.equal(ref_b, out_a)
+    assert torch.equal(runner(d), ref_b), "the captured graph replayed the weights of before the load"
+    # (2) a write behind the version counter
+    conv = model.d_estimator.levels[0].disp_refiner.prep_conv_layers[1]
+    v0 = conv.weight._version
+    conv.weight.data.mul_(1.5)
+    assert conv.weight._version == v0                                   # .data writes do not bump it: caches cannot see them
+    model.invalidate_packed()
+    Wc = model.numpy_weights()
+    assert torch.equal(runner(d), _model(dev, L, Wc)([ds, dc])["depth"])
+    # (1b) a replaced parameter
+    conv.weight = torch.nn.Parameter(conv.weight.detach().clone(), requires_grad=False)
+    with pytest.raises(RuntimeError, match="REPLACED"):
+        runner(d)
+    # (3) metric results of consecutive steps do not alias
+    import m4depth_amd as M
+    m2 = _model(dev, L, Wa)
+    m2.compile(metrics=M.default_metrics())
+    r1 = m2.test_step(d)
+    first = {k: float(v) for k, v in r1.items()}
+    d2 = dict(d)
+    d2["depth"] = d["depth"] * 1.7
+    r2 = m2.test_step(d2)
+    assert {k: float(v) for k, v in r1.items()} == first, "an earlier step's results changed under the caller"
+    assert float(r2["AbsRel"]) != first["AbsRel"]

@@ -10,7 +10,7 @@ from m4depth_amd import synthetic as S
 from m4depth_amd import network as N
 from m4depth_amd import metrics as MT
 from m4depth_amd import dist as D
-from helpers import F
+from helpers import F, torch_convolutions_on_cpu
 
 
 @pytest.mark.parametrize("stride,h,w", [(1, 6, 7), (2, 8, 10), (2, 7, 9), (2, 6, 9)])
@@ -21,12 +21,20 @@ def test_conv_same_tf_padding(stride, h, w):
     bias = rng.standard_normal([4]).astype(F)
     conv = N._Conv3x3SameTF(4, stride, 5)
     conv.load_hwio(k, bias, torch.device("cpu"))
-    got = conv(torch.from_numpy(x)).numpy()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):        # the product layer is a HIP kernel and nothing else
+        conv(torch.from_numpy(x))
     ref = O.conv2d_same(x, k, bias, stride)
-    assert got.shape == ref.shape == (2, -(-h // stride), -(-w // stride), 4)
-    assert np.max(np.abs(got - ref)) < 1e-5
-    got = conv(torch.from_numpy(x), slope=0.1).numpy()
-    assert np.max(np.abs(got - O.leaky_relu(ref, 0.1))) < 1e-5
+    with torch_convolutions_on_cpu():
+        got = conv(torch.from_numpy(x)).numpy()
+        assert got.shape == ref.shape == (2, -(-h // stride), -(-w // stride), 4)
+        assert np.max(np.abs(got - ref)) < 1e-5
+        got = conv(torch.from_numpy(x), slope=0.1).numpy()
+        assert np.max(np.abs(got - O.leaky_relu(ref, 0.1))) < 1e-5
+    # load_hwio on a built layer of the same shape overwrites in place (same addresses: captured graphs stay valid)
+    ptrs = (conv.weight.data_ptr(), conv.bias.data_ptr())
+    conv.load_hwio(2 * k, bias + 1, torch.device("cpu"))
+    assert (conv.weight.data_ptr(), conv.bias.data_ptr()) == ptrs
+    assert torch.equal(conv.bias, torch.from_numpy(bias + 1)) and torch.equal(conv.weight.permute(2, 3, 1, 0), torch.from_numpy(2 * k))
 
 
 def test_domain_normalization_uses_variance_not_std():
@@ -46,14 +54,15 @@ def test_encoder_and_refiner_match_oracle():
     model.load_numpy_weights(W, torch.device("cpu"))
     rng = np.random.default_rng(2)
     img = rng.random([1, 32, 48, 3]).astype(F)
-    got = model.encoder(torch.from_numpy(img))
+    lvl = model.d_estimator.levels[1]
+    fin = rng.standard_normal([1, 8, 12, lvl.f_in]).astype(F)
+    with torch_convolutions_on_cpu():
+        got = model.encoder(torch.from_numpy(img))
+        out = lvl.disp_refiner(torch.from_numpy(fin))
     ref = O.feature_pyramid(img, W, L)
     assert [tuple(g.shape) for g in got] == [(1, 16, 24, 16), (1, 8, 12, 32), (1, 4, 6, 64)]
     for g, r in zip(got, ref):
         assert np.max(np.abs(g.numpy() - r)) < 2e-5
-    lvl = model.d_estimator.levels[1]
-    fin = rng.standard_normal([1, 8, 12, lvl.f_in]).astype(F)
-    out = lvl.disp_refiner(torch.from_numpy(fin))
     assert out[0].shape == (1, 8, 12, 5) and out[1].shape == (1, 8, 12, 96)        # [out5, prep96] quirk
     assert np.max(np.abs(out[0].numpy() - O.disp_refiner(fin, W, 2))) < 5e-5
 
