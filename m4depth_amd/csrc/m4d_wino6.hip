@@ -442,10 +442,16 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 }
 
 unsigned long long* g_wino6_stamps = nullptr;
+int g_wino6_variant = 0;                           // 0 = by grid size, 1 = always this file's kernel, 2 = the wide kernel wherever it applies
 
 }  // namespace
 
+// m4d_wino6w.hip: 16x16 pixels x all 96 / 128 output channels per workgroup, two passes over the position rows; bit-identical
+int m4d_wino6w_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
+                      float slope, float* out, void* stream);
+
 extern "C" void m4d_wino6_set_stamps(unsigned long long* device_buffer) { g_wino6_stamps = device_buffer; }
+extern "C" void m4d_wino6_set_variant(int variant) { g_wino6_variant = variant; }
 
 extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                           int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
@@ -453,6 +459,15 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
   M4D_CHECK_ARG(CoutPad % 64 == 0 && CoutPad >= Cout && Cin % 16 == 0);
   M4D_CHECK_ARG(((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu6) & 15u) == 0));
   M4D_CHECK_ARG((long long)h * w * Cin * 4 < (1ll << 31));                              // one image = one buffer descriptor
+  {
+    // The wide kernel (same bits): one workgroup per pixel tile instead of one per (tile, 64 couts) -- it needs as many tiles as
+    // this kernel needs workgroups to fill the chip: level 1 of the 384x1280 pyramid at batch 1 (480 tiles), level 2 from batch 4.
+    const long long tiles = (long long)b * ((w + kT - 1) / kT) * ((h + kT - 1) / kT);
+    const bool wide_ok = CoutPad == 128 && Cout > 64 && (Cout & 3) == 0 && ((((uintptr_t)bias) | ((uintptr_t)out)) & 15u) == 0 &&
+                         g_wino6_stamps == nullptr;
+    if (wide_ok && g_wino6_variant != 1 && (g_wino6_variant == 2 || tiles >= 400))
+      return m4d_wino6w_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
+  }
   Wino6Args a;
   a.x = x; a.wu = reinterpret_cast<const unsigned char*>(wu6); a.bias = bias; a.out = out;
   a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.n_chunks = Cin / 16; a.slope = slope;

@@ -1,0 +1,40 @@
+"""The wide bf16-split Winograd kernel (m4d_wino6w.hip) against the 64-cout kernel (m4d_wino6.hip): bit equality and time
+per launch on the refiner / encoder layer shapes it serves."""
+import argparse, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from m4depth_amd import network_ops as nops
+from m4depth_amd._lib import lib
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=1); ap.add_argument("--iters", type=int, default=20)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+
+
+def timed(fn, iters):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for rep in range(3):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): fn()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+    return best
+
+
+for (h, w, cin, cout) in [(192, 640, 64, 128), (192, 640, 128, 128), (192, 640, 128, 96), (96, 320, 128, 128), (96, 320, 128, 96),
+                          (48, 160, 128, 128), (50, 70, 32, 100), (33, 47, 48, 128)]:
+    torch.manual_seed(h + cin)
+    x = torch.randn(a.batch, h, w, cin, device=dev)
+    k = torch.randn(3, 3, cin, cout) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, device=dev) * 0.1
+    wu6, cpad6 = nops.pack_conv_weights_wino6(k.numpy()); wud6 = torch.from_numpy(wu6.view("int16")).to(dev)
+    f6 = lambda: nops.conv3x3_wino6_bias_act(x, wud6, bias, cout, cpad6, 0.1)
+    lib.m4d_wino6_set_variant(1); ref = f6(); t_n = timed(f6, a.iters)
+    lib.m4d_wino6_set_variant(2); got = f6(); t_w = timed(f6, a.iters)
+    lib.m4d_wino6_set_variant(0)
+    same = torch.equal(ref, got)
+    nbad = int((ref != got).sum())
+    print(f"b={a.batch} {h}x{w} {cin:3d}->{cout:3d}: narrow {t_n:8.1f} us   wide {t_w:8.1f} us  ({t_n / t_w:.2f}x)  "
+          f"bit-identical {same} (differing {nbad} / {ref.numel()}, max abs diff {float((ref - got).abs().max()):.3e})", flush=True)
