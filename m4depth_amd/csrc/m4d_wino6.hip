@@ -460,12 +460,14 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
   M4D_CHECK_ARG(((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu6) & 15u) == 0));
   M4D_CHECK_ARG((long long)h * w * Cin * 4 < (1ll << 31));                              // one image = one buffer descriptor
   {
-    // The wide kernel (same bits): one workgroup per pixel tile instead of one per (tile, 64 couts) -- it needs as many tiles as
-    // this kernel needs workgroups to fill the chip: level 1 of the 384x1280 pyramid at batch 1 (480 tiles), level 2 from batch 4.
+    // The wide kernel (same bits): one workgroup per pixel tile instead of one per (tile, 64 couts), every transformed input
+    // element split once for all output channels.  Measured (tools/bench_wino6w.py): ahead only where this
+    // kernel wastes a quarter of its second workgroup -- the 96-wide layers (3 N-tiles) -- and only when there are enough
+    // tiles to fill the chip (level 1 of the 384x1280 pyramid at batch 1: 480 tiles); 128-wide layers stay here.
     const long long tiles = (long long)b * ((w + kT - 1) / kT) * ((h + kT - 1) / kT);
     const bool wide_ok = CoutPad == 128 && Cout > 64 && (Cout & 3) == 0 && ((((uintptr_t)bias) | ((uintptr_t)out)) & 15u) == 0 &&
                          g_wino6_stamps == nullptr;
-    if (wide_ok && g_wino6_variant != 1 && (g_wino6_variant == 2 || tiles >= 400))
+    if (wide_ok && g_wino6_variant != 1 && (g_wino6_variant == 2 || (tiles >= 400 && Cout <= 96)))
       return m4d_wino6w_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
   }
   Wino6Args a;

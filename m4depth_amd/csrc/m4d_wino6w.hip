@@ -38,6 +38,7 @@ struct W6wArgs {
   const float* x; const unsigned char* wu; const float* bias; float* out;
   int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
   float slope;
+  unsigned long long* stamps;   // profiling only (M4D_W6W_ABLATIONS builds): workgroup x wave x 16 s_memtime values
 };
 
 // raw halo layout: identical to m4d_wino6.hip
@@ -61,7 +62,9 @@ __device__ __forceinline__ float hi_f32(unsigned p) { return __builtin_bit_cast(
 
 template <int N> using IC = std::integral_constant<int, N>;
 
-template <int NT>
+// ABL: timing ablations (wrong results; tools/bench_wino6w.py --ablate): 1 = no V side work, 2 = no B DMA, 4 = no raw DMA,
+// 8 = no barrier in the K loop, 16 = no B fragment reads, 32 = no MFMAs
+template <int NT, int ABL = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3x3_wino6w_kernel(const W6wArgs a) {
   extern __shared__ __align__(16) float lds[];
@@ -174,6 +177,13 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
 #define M4D_W6W_WAIT(nn) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(nn) : "memory")
 
   float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
+#ifdef M4D_W6W_ABLATIONS
+  unsigned long long* st = (a.stamps != nullptr && lane == 0 && blockIdx.y == 0 && blockIdx.x < 64) ? a.stamps + ((long long)blockIdx.x * 8 + wv) * 16 : nullptr;
+#define M4D_W6W_STAMP(i) if (st) st[i] = __builtin_readcyclecounter();
+#else
+#define M4D_W6W_STAMP(i)
+#endif
+  M4D_W6W_STAMP(0)
 
   for (int p = 0; p < 2; ++p) {
     // position row of this pass: B^T d uses raw rows (ra, rb) of the 4x4 input tile: d0 - d2, d1 + d2, d2 - d1, d1 - d3
@@ -193,15 +203,20 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // ---- prologue: raw(0), raw(1), B(0); V(0) of both M-tiles; the fragments of step 0
+    // ---- prologue: only raw(0) and the fragments of step 0 are waited for; raw(1) and the rest of B(0) land while V(0) is
+    // produced.  Issue order raw(0), B(0)[0] | raw(1), B(0)[1..] -- the order of the steady state, so the K loop's counts hold
+    // from its first iteration on (its barrier wait leaves 3 DMAs in flight: the last fragments of B(0)).
 #pragma unroll
     for (int k = 0; k < 3; ++k) raw_dma(0, 0, k);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b_dma(wfrag(0, nt), nt);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) raw_dma(min(1, last), 1, k);
+    b_dma(wfrag(0, 0), 0);
+    M4D_W6W_STAMP(1 + 6 * p)
     M4D_W6W_WAIT(0);                               // (also: the scratch stores of pass 0 have completed)
     __builtin_amdgcn_s_barrier();
+    M4D_W6W_STAMP(2 + 6 * p)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) raw_dma(min(1, last), 1, k);
+#pragma unroll
+    for (int nt = 1; nt < NT; ++nt) b_dma(wfrag(0, nt), nt);
     u32x4 A[2][2][3];                              // [buffer][M-tile][part]: packed bf16 pairs
     bf16x8 B[2][3];                                // [set][part]
 #pragma unroll
@@ -221,20 +236,31 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
     // products of N-tile j), each step: DMA of the NEXT chunk's fragments into the slots whose fragments are in registers,
     // the fragments of the next step from LDS, and a share of V(k + 1).
     // one step = the 12 MFMAs of N-tile j (2 M-tiles x 6 term products) + its share of the side work
-    auto step = [&](auto PAR, auto J, int kn, const float4* rnext) {
+    auto step = [&](auto PAR, auto J, int k, int kn, const float4* rnext) {
       constexpr int par = decltype(PAR)::value, j = decltype(J)::value;
       constexpr int cur = (par * NT + j) & 1, nxt = cur ^ 1;
       constexpr int jn = j == NT - 1 ? 0 : j + 1;
       u32x4 (&Ac)[2][3] = A[par];
       u32x4 (&An)[2][3] = A[par ^ 1];
-      b_dma(wfrag(kn, j), j);
-      M4D_W6W_WAIT(j == NT - 1 ? 3 * NT - 3 : 3 * NT);
+      if constexpr (!(ABL & 2)) b_dma(wfrag(kn, j), j);
+      // (one piece of raw(k + 2) per step: a burst of 24 right after the barrier would block every wave at once)
+      // NT == 4: pieces in steps 0, 1, 2; NT == 3: two in step 0, one in step 1.  Either way 3 NT + 3 DMAs per chunk with the
+      // last raw piece followed by 3 fragment DMAs, so: every fragment wait leaves 3 NT DMAs in flight, the barrier wait 3.
+      if constexpr (!(ABL & 4)) {
+        if constexpr (NT == 4) { if constexpr (j < 3) raw_dma(min(k + 2, last), k & 1, j); }
+        else if constexpr (j == 0) { raw_dma(min(k + 2, last), k & 1, 0); raw_dma(min(k + 2, last), k & 1, 1); }
+        else if constexpr (j == 1) raw_dma(min(k + 2, last), k & 1, 2);
+      }
+      if constexpr (!(ABL & 6)) M4D_W6W_WAIT(3 * NT);
+      if constexpr (!(ABL & 16)) {
 #pragma unroll
-      for (int part = 0; part < 3; ++part) B[nxt][part] = frag(jn, part);
+        for (int part = 0; part < 3; ++part) B[nxt][part] = frag(jn, part);
+      }
       // V(k + 1): NT == 4: steps 0 / 2 read t of M-tile 0 / 1 and split pairs 0, 1; steps 1 / 3 split pairs 2, 3;
       // NT == 3: step 0: t(0), pairs 0-2; step 1: pair 3, t(1), pair 0; step 2: pairs 1-3
       constexpr int n_valu = NT == 4 ? ((j & 1) == 0 ? 4 : 3) : (j == 0 ? 5 : 4);
-      if constexpr (NT == 4) {
+      if constexpr (ABL & 1) {
+      } else if constexpr (NT == 4) {
         constexpr int mt2 = j >> 1;
         if constexpr ((j & 1) == 0) {
           read_t(rnext, mt2, offA, offB, sgn);
@@ -258,46 +284,78 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
 #define M4D_W6W_MFMA(ap, bp)                                                                                           \
   _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                                     \
     acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ac[mt][ap]), B[cur][bp], acc[mt][j], 0, 0, 0);
-      M4D_W6W_MFMA(0, 2) M4D_W6W_MFMA(2, 0) M4D_W6W_MFMA(1, 1) M4D_W6W_MFMA(0, 1) M4D_W6W_MFMA(1, 0) M4D_W6W_MFMA(0, 0)
+      if constexpr (!(ABL & 32)) {
+        M4D_W6W_MFMA(0, 2) M4D_W6W_MFMA(2, 0) M4D_W6W_MFMA(1, 1) M4D_W6W_MFMA(0, 1) M4D_W6W_MFMA(1, 0) M4D_W6W_MFMA(0, 0)
+      } else {
+#pragma unroll
+        for (int part = 0; part < 3; ++part) asm volatile("" : : "v"(B[cur][part]), "v"(Ac[0][part]), "v"(Ac[1][part]));
+      }
 #undef M4D_W6W_MFMA
       // issue order inside the step: every LDS read first (the next step's fragments, t of the next chunk), then one MFMA
       // and n_valu vector instructions alternately
-      constexpr bool reads_t = NT == 4 ? (j & 1) == 0 : j < 2;
-      __builtin_amdgcn_sched_group_barrier(0x100, reads_t ? 11 : 3, 0);
+      if constexpr (ABL == 0) {
+        constexpr bool reads_t = NT == 4 ? (j & 1) == 0 : j < 2;
+        __builtin_amdgcn_sched_group_barrier(0x100, reads_t ? 11 : 3, 0);
 #pragma unroll
-      for (int i_ = 0; i_ < 12; ++i_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, n_valu, 0);
+        for (int i_ = 0; i_ < 12; ++i_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, n_valu, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
     // One chunk: barrier (raw(k + 1) of every wave has landed); raw(k + 2) DMAs; then NT steps, each: DMA of the NEXT chunk's
     // fragments into the slots whose fragments are in registers, the fragments of the next step from LDS, a share of V(k + 1).
     auto body = [&](auto PAR, int k) {
-      M4D_W6W_WAIT(3 * NT);
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(ABL & 6)) M4D_W6W_WAIT(3);
+      if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
       const int kn = min(k + 1, last);
       const float4* rnext = raw + ((k + 1) & 1) * kRawSlots;
-#pragma unroll
-      for (int kk = 0; kk < 3; ++kk) raw_dma(min(k + 2, last), k & 1, kk);
-      step(PAR, IC<0>{}, kn, rnext);
-      step(PAR, IC<1>{}, kn, rnext);
-      step(PAR, IC<2>{}, kn, rnext);
-      if constexpr (NT == 4) step(PAR, IC<3>{}, kn, rnext);
+      step(PAR, IC<0>{}, k, kn, rnext);
+      step(PAR, IC<1>{}, k, kn, rnext);
+      step(PAR, IC<2>{}, k, kn, rnext);
+      if constexpr (NT == 4) step(PAR, IC<3>{}, k, kn, rnext);
     };
+    M4D_W6W_STAMP(3 + 6 * p)
     for (int chunk = 0; chunk < n; chunk += 2) {
       body(IC<0>{}, chunk);
       if (chunk + 1 < n) body(IC<1>{}, chunk + 1);
     }
+    M4D_W6W_STAMP(4 + 6 * p)
     M4D_W6W_WAIT(0);                               // no DMA may land in LDS once the staging buffer reuses it
     __syncthreads();
+    M4D_W6W_STAMP(5 + 6 * p)
 
     // ---- output transform.  Per half (two N-tiles): every wave stages its accumulators M[row][c] (tile, cout); then one item
     // = (N-tile, 2x2-output tile, cout quad) per thread: column transform R[prl][k] from the four positions of a row, then
     // pass 0: s01 = R0 + R1 and R1 -> the item's own output pixels (scratch); pass 1: reads them back and finishes.
     float* St = lds;
+    // (the item geometry is re-derived here from a laundered thread index: hoisted out of the pass loop it would stay live
+    // across the K loop, whose register budget is full, and be spilled)
+    int t_ep = t, tile_ep = tile;
+    asm volatile("" : "+v"(t_ep), "+s"(tile_ep));
+    const int cq = t_ep & 7, tl = t_ep >> 3;                          // this thread's items: cout quad, 2x2-output tile 0..63 (8 x 8)
+    const int ox = (tile_ep % a.tiles_x) * kT + 2 * (tl & 7), oy = (tile_ep / a.tiles_x) * kT + 2 * (tl >> 3);
 #pragma unroll
     for (int hf = 0; hf < (NT + 1) / 2; ++hf) {
+      // pass 1: the scratch of this half's items early -- N-tile 0's loads return while the accumulators are staged, N-tile 1's
+      // (issued after the barrier) while N-tile 0 is finished.  (All 16 loads up front would need 64 registers next to the
+      // 128 accumulators: spills, measured slower.)
+      float4 sc[2][2][2];                                             // [N-tile of the half][k][s01 / r1]
+      auto load_scratch = [&](int ntl) {
+        const int nt = 2 * hf + ntl, co = nt * 32 + 4 * cq;
+        const float* op = oimg + ((long long)oy * a.w + ox) * a.Cout + co;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          // (row 1 of an odd-height image's last tile row: its scratch was never written; nor is its result)
+          sc[ntl][k][0] = sc[ntl][k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (nt < NT && co < a.Cout && ox + k < a.w) {
+            if (oy < a.h) sc[ntl][k][0] = *reinterpret_cast<const float4*>(op + (long long)k * a.Cout);
+            if (oy + 1 < a.h) sc[ntl][k][1] = *reinterpret_cast<const float4*>(op + ((long long)a.w + k) * a.Cout);
+          }
+        }
+      };
+      if (p == 1) load_scratch(0);
 #pragma unroll
       for (int ntl = 0; ntl < 2; ++ntl) {
         const int nt = 2 * hf + ntl;
@@ -313,10 +371,10 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
         }
       }
       __syncthreads();
+      if (p == 1) load_scratch(1);
 #pragma unroll
       for (int ntl = 0; ntl < 2; ++ntl) {
         const int nt = 2 * hf + ntl;
-        const int cq = t & 7, tl = t >> 3;                            // cout quad, 2x2-output tile 0..63 (8 x 8)
         const int co = nt * 32 + 4 * cq;
         if (nt < NT && co < a.Cout) {
           float R[2][2][4];                                           // [row of the pass][k][cout]
@@ -334,8 +392,6 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
               R[rr][1][e] = (m1[e] - m2[e]) - m3[e];
             }
           }
-          const int ty2 = tl >> 3, tx2 = tl & 7;
-          const int ox = tile_x + 2 * tx2, oy = tile_y + 2 * ty2;
           float* op = oimg + ((long long)oy * a.w + ox) * a.Cout + co;
           if (p == 0) {
 #pragma unroll
@@ -353,11 +409,7 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
               if (ox + k < a.w) {
-                // (row 1 of an odd-height image's last tile row: its scratch was never written; nor is its result)
-                float4 s01 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (oy < a.h) s01 = *reinterpret_cast<const float4*>(op + (long long)k * a.Cout);
-                if (oy + 1 < a.h) r1 = *reinterpret_cast<const float4*>(op + ((long long)a.w + k) * a.Cout);
-                const float* s01p = reinterpret_cast<const float*>(&s01); const float* r1p = reinterpret_cast<const float*>(&r1);
+                const float* s01p = reinterpret_cast<const float*>(&sc[ntl][k][0]); const float* r1p = reinterpret_cast<const float*>(&sc[ntl][k][1]);
                 float y0[4], y1[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -374,6 +426,7 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
       }
       __syncthreads();                             // the staging buffer is rewritten by the next half / the next pass's DMAs
     }
+    M4D_W6W_STAMP(6 + 6 * p)
   }
 #undef M4D_W6W_WAIT
 }
@@ -381,6 +434,14 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
 }  // namespace
 
 // Launch for m4d_conv3x3_wino6_bias_act (m4d_wino6.hip decides when): CoutPad == 128, 64 < Cout <= 128, Cout % 4 == 0.
+// profiling builds only (make W6FLAGS=-DM4D_W6W_ABLATIONS; tools/w6w_ablate.py): timing ablations and phase stamps
+static int g_wino6w_ablate = 0;
+static unsigned long long* g_wino6w_stamps = nullptr;
+#ifdef M4D_W6W_ABLATIONS
+extern "C" void m4d_wino6w_set_ablation(int mask) { g_wino6w_ablate = mask; }
+extern "C" void m4d_wino6w_set_stamps(unsigned long long* device_buffer) { g_wino6w_stamps = device_buffer; }
+#endif
+
 int m4d_wino6w_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
                       float slope, float* out, void* stream) {
   M4D_CHECK_ARG(CoutPad == 128 && Cout > 64 && Cout <= 128 && (Cout & 3) == 0 && Cin % 16 == 0 && Cin >= 16);
@@ -389,6 +450,7 @@ int m4d_wino6w_launch(const float* x, const void* wu6, const float* bias, int b,
   a.x = x; a.wu = reinterpret_cast<const unsigned char*>(wu6); a.bias = bias; a.out = out;
   a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.n_chunks = Cin / 16; a.slope = slope;
   a.tiles_x = (w + kT - 1) / kT; a.tiles_y = (h + kT - 1) / kT;
+  a.stamps = g_wino6w_stamps;
   const int NT = (Cout + 31) / 32;
   constexpr size_t lds4 = (size_t)kStageFloats * sizeof(float) > (size_t)kRingOff + 8 * 4 * 3072 ? (size_t)kStageFloats * sizeof(float)
                                                                                               : (size_t)kRingOff + 8 * 4 * 3072;
@@ -399,6 +461,14 @@ int m4d_wino6w_launch(const float* x, const void* wu6, const float* bias, int b,
   }();
   (void)attr_set;
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)b);
+#ifdef M4D_W6W_ABLATIONS
+  if (NT == 4 && g_wino6w_ablate) {
+#define M4D_ABL(mask) case mask: { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6w_kernel<4, mask>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      hipLaunchKernelGGL((conv3x3_wino6w_kernel<4, mask>), grid, dim3(512), lds4, (hipStream_t)stream, a); return M4D_LAUNCH_RESULT(); }
+    switch (g_wino6w_ablate) { M4D_ABL(1) M4D_ABL(2) M4D_ABL(4) M4D_ABL(6) M4D_ABL(8) M4D_ABL(16) M4D_ABL(32) M4D_ABL(17) M4D_ABL(23) M4D_ABL(31) M4D_ABL(33) M4D_ABL(38) default: break; }
+#undef M4D_ABL
+  }
+#endif
   if (NT == 3) hipLaunchKernelGGL(conv3x3_wino6w_kernel<3>, grid, dim3(512), lds4, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(conv3x3_wino6w_kernel<4>, grid, dim3(512), lds4, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();

@@ -779,3 +779,53 @@ def test_fused_level_front_is_bitwise_the_separate_kernels(M, dev, depth, b, h, 
 
 
 S_ENC = [16, 32, 64, 96, 128, 192]
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(1, 64, 96, 128, 96), (1, 64, 96, 64, 128), (2, 33, 47, 48, 128), (1, 50, 70, 32, 100),
+                                             (3, 16, 16, 16, 96), (1, 17, 31, 96, 68)])
+def test_wide_bf16_split_winograd_is_bit_identical(dev, b, h, w, cin, cout):
+    """m4d_wino6w.hip (16x16 pixels x all 96 / 128 output channels per workgroup, two passes over the Winograd position
+    rows, the first pass's partial row transform parked in the output pixels) against m4d_wino6.hip (x 64 output channels,
+    one pass): the same float32 bits -- same products, same accumulation order, same association in the output transform --
+    on whole / ragged / odd-sized maps, batches, 3 and 4 N-tiles, channel counts that are not multiples of 32; and the
+    same bits again through the default dispatch."""
+    from m4depth_amd import network_ops as nops
+    from m4depth_amd._lib import lib
+    rng = np.random.default_rng(b * 1000 + h + cin + cout)
+    x = to_dev(rng.standard_normal([b, h, w, cin]).astype(F), dev)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = to_dev((0.1 * rng.standard_normal([cout])).astype(F), dev)
+    wu6, cpad = nops.pack_conv_weights_wino6(k)
+    wud = torch.from_numpy(wu6.view("int16")).to(dev)
+    try:
+        lib.m4d_wino6_set_variant(1)
+        narrow = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
+        lib.m4d_wino6_set_variant(2)
+        wide = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
+        wide2 = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
+    finally:
+        lib.m4d_wino6_set_variant(0)
+    auto = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
+    assert torch.equal(wide, narrow), f"{int((wide != narrow).sum())} of {narrow.numel()} elements differ"
+    assert torch.equal(wide2, wide) and torch.equal(auto, narrow)
+    ref = O.leaky_relu(O.conv2d_same(npy(x), k, npy(bias), 1), 0.1)
+    assert np.max(np.abs(npy(wide) - ref)) < 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_wide_bf16_split_winograd_default_dispatch_level1(dev):
+    """The 96-wide layer of level 1 (192x640: 480 tiles) takes the wide kernel by default; bits equal to the narrow kernel."""
+    from m4depth_amd import network_ops as nops
+    from m4depth_amd._lib import lib
+    rng = np.random.default_rng(5)
+    x = to_dev(rng.standard_normal([1, 192, 640, 128]).astype(F), dev)
+    k = (rng.standard_normal([3, 3, 128, 96]) * np.sqrt(2.0 / (9 * 128))).astype(F)
+    bias = to_dev((0.1 * rng.standard_normal([96])).astype(F), dev)
+    wu6, cpad = nops.pack_conv_weights_wino6(k)
+    wud = torch.from_numpy(wu6.view("int16")).to(dev)
+    auto = nops.conv3x3_wino6_bias_act(x, wud, bias, 96, cpad, 0.1)
+    try:
+        lib.m4d_wino6_set_variant(1)
+        narrow = nops.conv3x3_wino6_bias_act(x, wud, bias, 96, cpad, 0.1)
+    finally:
+        lib.m4d_wino6_set_variant(0)
+    assert torch.equal(auto, narrow)
