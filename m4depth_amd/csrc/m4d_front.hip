@@ -421,7 +421,8 @@ extern "C" int m4d_level_front_supported(int C, int nbre_cuts, int dscv_range, i
   const int nc = C / nbre_cuts;
   const int f_in = 58 * nbre_cuts + 6;
   if (f_stride != (f_in + 7) / 8 * 8) return 0;
-  return (nc == 16 && nbre_cuts == 1) || (nc == 16 && nbre_cuts == 2) || (nc == 32 && nbre_cuts == 2);
+  return (nc == 16 && nbre_cuts == 1) || (nc == 16 && nbre_cuts == 2) || (nc == 32 && nbre_cuts == 2) ||
+         (nc == 24 && nbre_cuts == 4) || (nc == 32 && nbre_cuts == 4) || (nc == 24 && nbre_cuts == 8);       // levels 4, 5, 6
 }
 
 extern "C" int m4d_level_front(const float* raw_f, float* norm_out, const float* prev_f, const float* depth_prev_t,
@@ -473,6 +474,12 @@ extern "C" int m4d_level_front(const float* raw_f, float* norm_out, const float*
       default: return launch_front<16, 2, 16, 8, 2>(a, s);
     }
   }
+  // levels 4-6 of the 6-level pyramid (96 / 128 / 192 channels in 4 / 4 / 8 cuts: 24 / 32 / 48 lanes per pixel in the DSCV
+  // phase, 6 or 8 lanes per cut): 8x8 tiles (8x4 for the 192-channel halo, 110 KB), half-size tiles with the window rows
+  // split four ways on small maps
+  if (nc == 24 && nbre_cuts == 4) return small_map ? launch_front<24, 4, 8, 4, 4>(a, s) : launch_front<24, 4, 8, 8, 2>(a, s);
+  if (nc == 32 && nbre_cuts == 4) return small_map ? launch_front<32, 4, 8, 4, 4>(a, s) : launch_front<32, 4, 8, 8, 2>(a, s);
+  if (nc == 24 && nbre_cuts == 8) return small_map ? launch_front<24, 8, 4, 4, 4>(a, s) : launch_front<24, 8, 8, 4, 2>(a, s);
   switch (v3 ? v3 : (small_map ? 5 : 6)) {
     case 1: return launch_front<32, 2, 8, 8, 2>(a, s);
     case 2: return launch_front<32, 2, 8, 4, 4>(a, s);

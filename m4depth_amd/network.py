@@ -124,6 +124,10 @@ fused_level_front = _os.environ.get("M4D_FUSED_LEVEL_FRONT", "1") == "1"
 # the separate kernels.  M4D_FUSED_FRONT=0 = the separate kernels everywhere (same bits).
 fused_front = _os.environ.get("M4D_FUSED_FRONT", "1") == "1"
 fused_front_min_pixels = int(_os.environ.get("M4D_FUSED_FRONT_MIN_PX", "0"))
+# The geometries of levels 4-6 (24 / 32 channels per cut x 4 cuts, 24 x 8) have instantiations too (round 3); on maps of at
+# most this many pixels (batch included: levels 4-6 at batch 1-3) the one-launch small-map cost-volume kernel stays -- a
+# handful of 8x8 tiles cannot fill the chip -- above it (batch >= 4) the fused front writes whole refiner-input rows.
+fused_front_coarse_min_pixels = int(_os.environ.get("M4D_FUSED_FRONT_COARSE_MIN_PX", "6000"))
 
 # Encoder level 0 as two fused kernels (direct 3->16 convolution + bias + DINL statistics; DINL apply fused into the
 # stride-2 convolution's input staging) instead of MIOpen conv + bias pass + 3 DINL passes + conv: no MIOpen kernel is
@@ -568,7 +572,8 @@ class DepthEstimatorLevel(torch.nn.Module):
         # the fused level front: normalisation, upsampling, both cost volumes and the log features in one launch
         use_front = (fused_front and use_state and not nt and dev.type == "cuda" and self._spare_f is not None
                      and ab.SNCV and ab.time_recurr and ab.normalize_features and ab.level_memory
-                     and b * h * w > fused_front_min_pixels and self.dscv_range == 4 and self.sncv_range == 3
+                     and b * h * w > (fused_front_min_pixels if k <= 2 else max(fused_front_min_pixels, fused_front_coarse_min_pixels))
+                     and self.dscv_range == 4 and self.sncv_range == 3
                      and bool(lib.m4d_level_front_supported(c, k, 4, 3, F_st)))
         # normalised current features land in the spare state buffer: after the level
         # ran they ARE the new prev_f_maps (:211, :259) -- a pointer swap, not a copy.

@@ -48,11 +48,17 @@ def _build(dev, L, rd, rs, weights):
     return model
 
 
-@pytest.mark.parametrize("depth,h,w", [(1, 32, 48), (2, 16, 24), (3, 16, 24), (4, 8, 12), (6, 6, 10)])
-def test_level_step_teacher_forced(dev, depth, h, w):
+@pytest.mark.parametrize("depth,h,w,coarse_front", [(1, 32, 48, False), (2, 16, 24, False), (3, 16, 24, False), (4, 8, 12, False),
+                                                     (6, 6, 10, False), (4, 8, 12, True), (5, 8, 12, True), (6, 6, 10, True)])
+def test_level_step_teacher_forced(dev, depth, h, w, coarse_front, monkeypatch):
     """One full DepthEstimatorLevel step per level geometry with identical inputs on
-    both sides; compares the assembled refiner input and the state handling."""
+    both sides; compares the assembled refiner input and the state handling.  Levels 1-3 go through the fused level front;
+    levels 4-6 through the small-map kernels (their default at this size) and, with ``coarse_front``, through the fused
+    front instantiations of their geometries (the default from batch >= 4 at 384x1280)."""
     import m4depth_amd as M
+    from m4depth_amd import network as net
+    if coarse_front:
+        monkeypatch.setattr(net, "fused_front_coarse_min_pixels", 0)
     rng = np.random.default_rng(200 + depth)
     b = 2
     C = S.ENCODER_CHANNELS[depth - 1]

@@ -731,6 +731,12 @@ def test_merged_cost_volume_launch(M, dev, b, h, w, C, k):
     (2, 2, 20, 27, True, "fp32_round"),      # C = 32, 2 cuts, padded row stride 122 -> 128
     (3, 1, 19, 33, True, "fp32_round"),      # C = 64, 2 cuts
     (3, 2, 16, 16, False, "fp16_seq"),
+    (4, 2, 21, 19, True, "fp32_round"),      # C = 96, 4 cuts of 24 (24 lanes per pixel, 6 per cut): ragged 8x8 tiles, large-map shape
+    (4, 1, 8, 12, False, "fp16_seq"),        #   ... the half-size tiles of small maps
+    (5, 2, 12, 17, True, "fp32_round"),      # C = 128, 4 cuts of 32
+    (5, 1, 9, 40, True, "fp16_seq"),
+    (6, 2, 6, 20, True, "fp32_round"),       # C = 192, 8 cuts of 24 (48 lanes per pixel): the coarsest level, no coarser estimate at step 3
+    (6, 3, 13, 11, False, "fp32_round"),
 ])
 def test_fused_level_front_is_bitwise_the_separate_kernels(M, dev, depth, b, h, w, quat, cv_accum):
     """m4d_level_front (normalise + level_pre + DSCV + SNCV in one launch, whole refiner-input rows) against the three
@@ -750,7 +756,9 @@ def test_fused_level_front_is_bitwise_the_separate_kernels(M, dev, depth, b, h, 
             cv.load_hwio(W[f"lvl.{depth}.conv.{i}.kernel"], W[f"lvl.{depth}.conv.{i}.bias"], dev)
         levels.append(gl)
     cam = to_dev(camera_np(b, h, w), dev)
-    old = (net.fused_front, net.fused_front_min_pixels)
+    old = (net.fused_front, net.fused_front_min_pixels, net.fused_front_coarse_min_pixels)
+    net.fused_front_coarse_min_pixels = 0            # levels 4-6: take the fused front on these small maps too
+    assert bool(net.lib.m4d_level_front_supported(C, 2 ** (depth // 2), 4, 3, (58 * 2 ** (depth // 2) + 6 + 7) // 8 * 8))
     try:
         for step in range(4):
             rot, trans = motion_np(rng, b, quat=quat, t_scale=(3.0, 3.0, 1.0))
@@ -775,7 +783,7 @@ def test_fused_level_front_is_bitwise_the_separate_kernels(M, dev, depth, b, h, 
                 assert_bits_equal(npy(fa), npy(fb), f"step {step}: refiner input")
                 assert torch.isfinite(fa).all()
     finally:
-        net.fused_front, net.fused_front_min_pixels = old
+        net.fused_front, net.fused_front_min_pixels, net.fused_front_coarse_min_pixels = old
 
 
 S_ENC = [16, 32, 64, 96, 128, 192]
