@@ -448,6 +448,7 @@ def main():
             out["roofline"] = {
                 "kernel": kname, "bound": "mfma", "achieved": round(tf_exec, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(tf_exec / peak, 4), "traffic": tr(key),
+                "pmc_mfma_busy_frac": None if key not in traffic else traffic[key].get("mfma_busy_frac"),
                 "traffic_kernel": None if key not in traffic else traffic[key].get("kernel"),
                 "executed_mfma_flops_per_launch": flops_exec,
                 "note": "achieved / frac = MFMA flops the kernel executes / time against the dense peak of the MFMA type it issues "

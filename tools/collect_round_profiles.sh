@@ -1,21 +1,55 @@
 #!/bin/bash
-# Round-end evidence: bench lines (batch 1 / 8 / 32), rocprofv3 kernel stats + step timeline of the batch-1 bench,
-# PMC traffic.  usage (GPU box, repo root): bash tools/collect_round_profiles.sh r02   -> gpurun_out/<tag>/
+# Round evidence, every artefact checked non-empty (the script exits non-zero naming the first empty one):
+#   bench lines (batch 1 with the PCIe-inclusive rate, 8, 32); rocprofv3 kernel-trace + stats of the batch-1 and batch-32
+#   bench -> per-kernel summary, per (kernel, grid) launch durations (level-1 front / tail are their own grids), step profile;
+#   kernel-trace durations of the roofline layer alone (level-1 refiner 128->128, batch 1 and 32); PMC passes (counters
+#   only, one rocprofv3 run per counter group): HBM traffic (profiles/pmc_traffic.json) and the matrix-core / issue counters
+#   of the roofline kernel.
+# usage (GPU box, repo root): bash tools/collect_round_profiles.sh r03   -> gpurun_out/<tag>/ ; copy what is cited into profiles/
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 1500 python tools/pmc_traffic.py --batch 1 > $OUT/pmc.log 2>&1
-timeout 900 python tools/pmc_traffic.py --batch 32 --only front,wino6_l1_128_128 >> $OUT/pmc.log 2>&1
-cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
-cp gpurun_out/pmc_traffic_rows.txt $OUT/pmc_traffic_rows.txt
-timeout 600 python bench.py --steps 20 --host-input > $OUT/bench_b1.json 2> $OUT/bench_b1.err
-timeout 600 python bench.py --steps 10 --batch 8 --no-cpu-baseline > $OUT/bench_b8.json 2>/dev/null
-timeout 600 python bench.py --steps 5 --warmup 2 --batch 32 --no-cpu-baseline > $OUT/bench_b32.json 2>/dev/null
-rm -rf /tmp/prof_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o b1 -- python bench.py --steps 20 --no-cpu-baseline --no-kernel-timing > $OUT/bench_b1_under_rocprof.json 2>/dev/null
-python tools/summarize_rocprof.py $(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1) 45 > $OUT/bench_b1_kernel_stats_summary.txt
-python tools/step_profile.py $(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1) 128 > $OUT/step_profile_b1.txt
-timeout 600 python tools/bench_train.py > $OUT/bench_train.json 2>/dev/null
-tail -3 $OUT/pmc.log; head -c 600 $OUT/bench_b1.json; echo; tail -c 300 $OUT/bench_train.json
+FAILED=""
+need() { for f in "$@"; do if [ ! -s "$f" ]; then echo "[collect] EMPTY OR MISSING: $f" >&2; FAILED="$FAILED $f"; fi; done; }
+
+timeout 600 python bench.py --steps 20 --host-input > $OUT/bench_b1.json 2> $OUT/bench_b1.err;                      need $OUT/bench_b1.json
+timeout 600 python bench.py --steps 10 --batch 8 --no-cpu-baseline > $OUT/bench_b8.json 2> $OUT/bench_b8.err;       need $OUT/bench_b8.json
+timeout 600 python bench.py --steps 5 --warmup 2 --batch 32 --no-cpu-baseline > $OUT/bench_b32.json 2> $OUT/bench_b32.err; need $OUT/bench_b32.json
+
+for B in 1 32; do
+  rm -rf /tmp/prof_${TAG}_b$B
+  STEPS=20; [ $B = 32 ] && STEPS=4
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_b$B -o t -- \
+      python bench.py --steps $STEPS --batch $B --no-cpu-baseline --no-kernel-timing > $OUT/bench_b${B}_under_rocprof.json 2> $OUT/bench_b${B}_under_rocprof.err
+  STATS=$(find /tmp/prof_${TAG}_b$B -name "*kernel_stats.csv" | head -1); TRACE=$(find /tmp/prof_${TAG}_b$B -name "*kernel_trace.csv" | head -1)
+  if [ -z "$STATS" ] || [ -z "$TRACE" ]; then echo "[collect] rocprofv3 wrote no kernel stats / trace for batch $B" >&2; FAILED="$FAILED rocprof_b$B"; continue; fi
+  python tools/summarize_rocprof.py "$STATS" 45 > $OUT/bench_b${B}_kernel_stats_summary.txt
+  python tools/trace_table.py "$TRACE" 0.3 > $OUT/bench_b${B}_launch_durations_by_grid.txt
+  [ $B = 1 ] && python tools/step_profile.py "$TRACE" 128 > $OUT/step_profile_b1.txt
+  need $OUT/bench_b${B}_kernel_stats_summary.txt $OUT/bench_b${B}_launch_durations_by_grid.txt
+done
+need $OUT/step_profile_b1.txt
+
+# the roofline layer alone: every launch of the trace is the level-1 refiner 128->128 layer
+for B in 1 32; do
+  rm -rf /tmp/prof_${TAG}_layer_b$B
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${TAG}_layer_b$B -o t -- \
+      python tools/bench_conv_one.py --winograd 6 --iters 20 --batch $B > $OUT/roofline_layer_b${B}_hip_events.txt 2>&1
+  TRACE=$(find /tmp/prof_${TAG}_layer_b$B -name "*kernel_trace.csv" | head -1)
+  if [ -n "$TRACE" ]; then python tools/trace_table.py "$TRACE" 0.0 wino6 > $OUT/roofline_layer_b${B}_rocprof_durations.txt; fi
+  need $OUT/roofline_layer_b${B}_rocprof_durations.txt $OUT/roofline_layer_b${B}_hip_events.txt
+done
+
+# PMC: HBM traffic (stamped json) and the roofline kernel's issue / matrix-core counters
+timeout 1800 python tools/pmc_traffic.py --batch 1 > $OUT/pmc.log 2>&1
+timeout 1500 python tools/pmc_traffic.py --batch 32 --only front,wino6_l1_128_128,front_l4,dscv_l4,sncv_l4 >> $OUT/pmc.log 2>&1
+cp profiles/pmc_traffic.json $OUT/pmc_traffic.json; cp gpurun_out/pmc_traffic_rows.txt $OUT/pmc_traffic_rows.txt
+need $OUT/pmc_traffic.json $OUT/pmc_traffic_rows.txt
+timeout 1200 bash tools/pmc_wino6.sh > /dev/null 2>&1; cp gpurun_out/pmc/wino6.txt $OUT/wino6_pmc.txt; need $OUT/wino6_pmc.txt
+
+timeout 600 python tools/bench_train.py > $OUT/bench_train.json 2>/dev/null; need $OUT/bench_train.json
+head -c 400 $OUT/bench_b1.json; echo
+if [ -n "$FAILED" ]; then echo "[collect] FAILED artefacts:$FAILED" >&2; exit 1; fi
+echo "[collect] all artefacts non-empty in $OUT"

@@ -30,6 +30,13 @@ TARGETS = {
              [CS + "m4d_sncv.hip", CS + "m4d_sncv_small.h", CS + "m4d_common.h"]),
     "front": (["tools/bench_kernels.py", "--iters", "5", "--which", "front"], ["level_front_kernel"],
               [CS + "m4d_front.hip", CS + "m4d_common.h"]),
+    # level 4 of the pyramid (24x80, C = 96, 4 cuts): the fused front against the separate kernels it replaces at batch >= 4
+    "front_l4": (["tools/bench_kernels.py", "--iters", "5", "--level", "4", "--which", "front"], ["level_front_kernel"],
+                 [CS + "m4d_front.hip", CS + "m4d_common.h"]),
+    "dscv_l4": (["tools/bench_kernels.py", "--iters", "5", "--level", "4", "--which", "dscv[wave]"], ["dscv_wave_kernel", "dscv_"],
+                [CS + "m4d_dscv.hip", CS + "m4d_common.h"]),
+    "sncv_l4": (["tools/bench_kernels.py", "--iters", "5", "--level", "4", "--which", "sncv"], ["sncv7_kernel", "sncv_"],
+                [CS + "m4d_sncv.hip", CS + "m4d_sncv_small.h", CS + "m4d_common.h"]),
     "wino_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "2"], ["conv3x3_wino4_kernel"],
                         [CS + "m4d_wino.hip"]),
     "wino6_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "6"], ["conv3x3_wino6_kernel"],
@@ -107,6 +114,21 @@ def main():
                                  "fetch_kib": round(vals["FETCH_SIZE"], 1), "write_kib": round(vals["WRITE_SIZE"], 1),
                                  "kernel": kname, "sources": sources, "sources_sha": sha(sources)}
                 print(f"batch {b} {name}: {entries[name]['bytes'] / 1e6:.2f} MB / launch ({kname})", flush=True)
+                if name.startswith("wino"):
+                    # matrix-core occupancy of the MFMA kernels: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) against
+                    # the kernel's GPU-active cycles (GRBM_GUI_ACTIVE, summed over the 8 XCDs) -- printed by bench.py next to roofline.frac
+                    extra = {}
+                    for counter in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+                        acc = counter_pass(counter, cmd + ["--batch", str(b)], f"{name}_b{b}")
+                        match = [(k, v) for k, v in acc.items() if any(s in k for s in kernels)]
+                        if match:
+                            k, v = max(match, key=lambda kv: sum(kv[1]))
+                            extra[counter] = sum(v) / len(v)
+                            raw_lines.append(f"batch {b:3d} {name:18s} {kname:44s} {counter:24s} launches {len(v):4d} mean {extra[counter]:14.1f}")
+                    if len(extra) == 2 and extra["GRBM_GUI_ACTIVE"] > 0:
+                        entries[name]["mfma_busy_cycles"] = extra["SQ_VALU_MFMA_BUSY_CYCLES"]
+                        entries[name]["gui_active_cycles_sum_xcd"] = extra["GRBM_GUI_ACTIVE"]
+                        entries[name]["mfma_busy_frac"] = round(extra["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * extra["GRBM_GUI_ACTIVE"] / 8.0), 4)
     json.dump(doc, open(args.out, "w"), indent=1)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "pmc_traffic_rows.txt"), "a") as fh:

@@ -1,12 +1,14 @@
 """Where in a step are only sub-chip kernels in flight?  Takes the densest window of a rocprofv3 kernel trace (graph replays),
-finds the step boundaries (the batched encoder head kernel starts a step) and prints, per 100-us bin of the step, the
+finds the step boundaries (the first kernel of an encoder batch, enc0_rgb_total_kernel, starts a step) and prints, per 100-us bin of the step, the
 share of time covered by at least one kernel of >= THR workgroups, averaged over the steps in the window."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 thr = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
              int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, int(r["Workgroup_Size_X"])), r["Kernel_Name"]) for r in rows)
-heads = [e[0] for e in ev if "enc_head_conv_kernel" in e[3]]
+heads = [e[0] for e in ev if "enc0_rgb_total_kernel" in e[3]] or [e[0] for e in ev if "enc_head_conv_kernel" in e[3]]   # first kernel of an encoder batch
+if len(heads) < 4:
+    sys.exit("step_profile: no encoder-batch head kernels (enc0_rgb_total_kernel / enc_head_conv_kernel) in the trace -- nothing to profile")
 # steps = consecutive head launches with a regular spacing (the timed graph replays): keep gaps within 20 % of the median
 per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 2         # encoder batches per step (network.pipeline_encoder_split)
 heads = heads[len(heads) % per_step::per_step][-13:]             # the last 12 steps: the timed graph replays
