@@ -14,6 +14,15 @@ export TMPDIR=/tmp
 FAILED=""
 need() { for f in "$@"; do if [ ! -s "$f" ]; then echo "[collect] EMPTY OR MISSING: $f" >&2; FAILED="$FAILED $f"; fi; done; }
 
+# PMC first: HBM traffic (stamped json: bench.py refuses entries whose kernel sources changed since) and the roofline
+# kernel's issue / matrix-core counters
+timeout 1800 python tools/pmc_traffic.py --batch 1 > $OUT/pmc.log 2>&1
+timeout 1500 python tools/pmc_traffic.py --batch 32 --only front,wino6_l1_128_128,front_l4,dscv_l4,sncv_l4 >> $OUT/pmc.log 2>&1
+cp profiles/pmc_traffic.json $OUT/pmc_traffic.json; cp gpurun_out/pmc_traffic_rows.txt $OUT/pmc_traffic_rows.txt
+need $OUT/pmc_traffic.json $OUT/pmc_traffic_rows.txt
+timeout 1200 bash tools/pmc_wino6.sh > /dev/null 2>&1; cp gpurun_out/pmc/wino6.txt $OUT/wino6_pmc.txt; need $OUT/wino6_pmc.txt
+
+
 timeout 600 python bench.py --steps 20 --host-input > $OUT/bench_b1.json 2> $OUT/bench_b1.err;                      need $OUT/bench_b1.json
 timeout 600 python bench.py --steps 10 --batch 8 --no-cpu-baseline > $OUT/bench_b8.json 2> $OUT/bench_b8.err;       need $OUT/bench_b8.json
 timeout 600 python bench.py --steps 5 --warmup 2 --batch 32 --no-cpu-baseline > $OUT/bench_b32.json 2> $OUT/bench_b32.err; need $OUT/bench_b32.json
@@ -41,13 +50,6 @@ for B in 1 32; do
   if [ -n "$TRACE" ]; then python tools/trace_table.py "$TRACE" 0.0 wino6 > $OUT/roofline_layer_b${B}_rocprof_durations.txt; fi
   need $OUT/roofline_layer_b${B}_rocprof_durations.txt $OUT/roofline_layer_b${B}_hip_events.txt
 done
-
-# PMC: HBM traffic (stamped json) and the roofline kernel's issue / matrix-core counters
-timeout 1800 python tools/pmc_traffic.py --batch 1 > $OUT/pmc.log 2>&1
-timeout 1500 python tools/pmc_traffic.py --batch 32 --only front,wino6_l1_128_128,front_l4,dscv_l4,sncv_l4 >> $OUT/pmc.log 2>&1
-cp profiles/pmc_traffic.json $OUT/pmc_traffic.json; cp gpurun_out/pmc_traffic_rows.txt $OUT/pmc_traffic_rows.txt
-need $OUT/pmc_traffic.json $OUT/pmc_traffic_rows.txt
-timeout 1200 bash tools/pmc_wino6.sh > /dev/null 2>&1; cp gpurun_out/pmc/wino6.txt $OUT/wino6_pmc.txt; need $OUT/wino6_pmc.txt
 
 timeout 600 python tools/bench_train.py > $OUT/bench_train.json 2>/dev/null; need $OUT/bench_train.json
 head -c 400 $OUT/bench_b1.json; echo

@@ -105,7 +105,7 @@ def main():
                 match = [(k, v) for k, v in acc.items() if any(s in k for s in kernels)]
                 if not match:
                     continue
-                k, v = max(match, key=lambda kv: sum(kv[1]))          # the kernel that moved the bytes
+                k, v = max(match, key=lambda kv: len(kv[1]))          # the kernel the driver launched over and over (the model step around it launches each kernel once or twice)
                 kname = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
                 vals[counter] = sum(v) / len(v)
                 raw_lines.append(f"batch {b:3d} {name:18s} {kname:44s} {counter:11s} launches {len(v):4d} mean {vals[counter]:14.1f} KiB")
@@ -122,7 +122,7 @@ def main():
                         acc = counter_pass(counter, cmd + ["--batch", str(b)], f"{name}_b{b}")
                         match = [(k, v) for k, v in acc.items() if any(s in k for s in kernels)]
                         if match:
-                            k, v = max(match, key=lambda kv: sum(kv[1]))
+                            k, v = max(match, key=lambda kv: len(kv[1]))
                             extra[counter] = sum(v) / len(v)
                             raw_lines.append(f"batch {b:3d} {name:18s} {kname:44s} {counter:24s} launches {len(v):4d} mean {extra[counter]:14.1f}")
                     if len(extra) == 2 and extra["GRBM_GUI_ACTIVE"] > 0:
