@@ -170,9 +170,10 @@ void m4d_wino_set_stamps(unsigned long long* device_buffer);
 int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
 void m4d_wino6_set_stamps(unsigned long long* device_buffer);
-/* Which kernel serves m4d_conv3x3_wino6_bias_act (results are bit-identical): 0 = chosen by grid size (default), 1 = the
- * 16x16-pixel x 64-cout workgroups of m4d_wino6.hip always, 2 = the wide kernel of m4d_wino6w.hip (16x16 pixels x all 96 / 128
- * couts, two passes over the Winograd position rows) wherever it applies (64 < Cout <= 128, Cout % 4 == 0).  Test / profiling hook. */
+/* Which kernel serves m4d_conv3x3_wino6_bias_act (results are bit-identical): 0 (default) and 1 = the 16x16-pixel x 64-cout
+ * workgroups of m4d_wino6.hip, 2 = the wide kernel of m4d_wino6w.hip (16x16 pixels x all 96 / 128 couts, two passes over the
+ * Winograd position rows) wherever it applies (64 < Cout <= 128, Cout % 4 == 0) -- measured not faster end to end,
+ * kept selectable.  Test / profiling hook. */
 void m4d_wino6_set_variant(int variant);
 
 /* The tail of a level in one kernel: the last two DispRefiner convolutions (32 -> 16 + leaky_relu(0.1), 16 -> 5;

@@ -442,7 +442,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 }
 
 unsigned long long* g_wino6_stamps = nullptr;
-int g_wino6_variant = 0;                           // 0 = by grid size, 1 = always this file's kernel, 2 = the wide kernel wherever it applies
+int g_wino6_variant = 0;                           // 0 / 1 = this file's kernel, 2 = the wide kernel (m4d_wino6w.hip) wherever it applies
 
 }  // namespace
 
@@ -460,14 +460,15 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
   M4D_CHECK_ARG(((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu6) & 15u) == 0));
   M4D_CHECK_ARG((long long)h * w * Cin * 4 < (1ll << 31));                              // one image = one buffer descriptor
   {
-    // The wide kernel (same bits): one workgroup per pixel tile instead of one per (tile, 64 couts), every transformed input
-    // element split once for all output channels.  Measured (tools/bench_wino6w.py): ahead only where this
-    // kernel wastes a quarter of its second workgroup -- the 96-wide layers (3 N-tiles) -- and only when there are enough
-    // tiles to fill the chip (level 1 of the 384x1280 pyramid at batch 1: 480 tiles); 128-wide layers stay here.
-    const long long tiles = (long long)b * ((w + kT - 1) / kT) * ((h + kT - 1) / kT);
+    // The wide kernel (m4d_wino6w.hip, same bits): one workgroup per pixel tile instead of one per (tile, 64 couts), every
+    // transformed input element split once for all output channels: ~3 VALU instructions per MFMA instead of 8.7.  Measured
+    // (round 3, DESIGN section 5 / DESIGN_HISTORY): its K loop is 15-25 % shorter per unit of work, but two passes over the
+    // position rows cost two prologues and two LDS-write-bound epilogues per tile -- per layer 0.9x (128 couts) / 1.05x (96
+    // couts) of this kernel alone, 0 % (96-wide layers only) / -11 % (everywhere) end to end.  NOT dispatched by default:
+    // m4d_wino6_set_variant(2) / M4D_WINO6_VARIANT=2 selects it wherever it applies (tests, profiling).
     const bool wide_ok = CoutPad == 128 && Cout > 64 && (Cout & 3) == 0 && ((((uintptr_t)bias) | ((uintptr_t)out)) & 15u) == 0 &&
                          g_wino6_stamps == nullptr;
-    if (wide_ok && g_wino6_variant != 1 && (g_wino6_variant == 2 || (tiles >= 400 && Cout <= 96)))
+    if (wide_ok && g_wino6_variant == 2)
       return m4d_wino6w_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
   }
   Wino6Args a;

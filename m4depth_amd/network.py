@@ -54,8 +54,8 @@ winograd2_min_workgroups = int(_os.environ.get("M4D_WINO2_MIN_WG", "60"))
 # MFMA kernels, tools/bench_wino6.py -- at 2.67x less matrix-core time); "f32" = the fp32-MFMA kernels everywhere.
 conv_arith = _os.environ.get("M4D_CONV_ARITH", "bf16x3")
 wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
-# Which kernel serves the bf16-split layers (same bits either way; include/m4depth_hip.h m4d_wino6_set_variant): 0 = by grid
-# size -- the wide kernel (m4d_wino6w.hip) for the 96-wide layers on >= 400 tiles --, 1 = m4d_wino6.hip always, 2 = wide wherever it applies
+# Which kernel serves the bf16-split layers (same bits either way; include/m4depth_hip.h m4d_wino6_set_variant): 0 / 1 =
+# m4d_wino6.hip (default), 2 = the wide kernel m4d_wino6w.hip wherever it applies (measured: not faster end to end)
 if _os.environ.get("M4D_WINO6_VARIANT"):
     lib.m4d_wino6_set_variant(int(_os.environ["M4D_WINO6_VARIANT"]))
 # The one-launch small-map convolution in the same arithmetic (csrc/m4d_conv.hip conv3x3_small6_kernel).  These launches are

@@ -820,8 +820,9 @@ def test_wide_bf16_split_winograd_is_bit_identical(dev, b, h, w, cin, cout):
     assert np.max(np.abs(npy(wide) - ref)) < 1e-5 * max(1.0, np.abs(ref).max())
 
 
-def test_wide_bf16_split_winograd_default_dispatch_level1(dev):
-    """The 96-wide layer of level 1 (192x640: 480 tiles) takes the wide kernel by default; bits equal to the narrow kernel."""
+def test_wide_bf16_split_winograd_level1_layer(dev):
+    """The 96-wide layer of level 1 (192x640: 480 tiles, 3 N-tiles) through the wide kernel (variant 2): bits equal to the
+    default kernel's."""
     from m4depth_amd import network_ops as nops
     from m4depth_amd._lib import lib
     rng = np.random.default_rng(5)
@@ -832,8 +833,8 @@ def test_wide_bf16_split_winograd_default_dispatch_level1(dev):
     wud = torch.from_numpy(wu6.view("int16")).to(dev)
     auto = nops.conv3x3_wino6_bias_act(x, wud, bias, 96, cpad, 0.1)
     try:
-        lib.m4d_wino6_set_variant(1)
-        narrow = nops.conv3x3_wino6_bias_act(x, wud, bias, 96, cpad, 0.1)
+        lib.m4d_wino6_set_variant(2)
+        wide = nops.conv3x3_wino6_bias_act(x, wud, bias, 96, cpad, 0.1)
     finally:
         lib.m4d_wino6_set_variant(0)
-    assert torch.equal(auto, narrow)
+    assert torch.equal(auto, wide)
