@@ -175,6 +175,10 @@ void m4d_wino6_set_stamps(unsigned long long* device_buffer);
  * Winograd position rows) wherever it applies (64 < Cout <= 128, Cout % 4 == 0) -- measured not faster end to end,
  * kept selectable.  Test / profiling hook. */
 void m4d_wino6_set_variant(int variant);
+/* Variant 3 = the half-tile kernel of m4d_wino6h.hip (16x8 pixels x 64 couts per workgroup) everywhere; under variant 0 it
+ * serves the launches whose m4d_wino6.hip grid would have at most `max_wg` workgroups (default 0 = none: faster alone on small
+ * grids, no gain inside the frame pipeline).  Same bits. */
+void m4d_wino6_set_half_tile_max_workgroups(int max_wg);
 
 /* The tail of a level in one kernel: the last two DispRefiner convolutions (32 -> 16 + leaky_relu(0.1), 16 -> 5;
  * m4depth_network.py:109-135) and m4d_level_post (:247-260).  x32 [b,h,w,32]; w6p [9][16][32] = kernel[ky][kx][k][n] as

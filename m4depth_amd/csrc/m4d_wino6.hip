@@ -442,6 +442,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 }
 
 unsigned long long* g_wino6_stamps = nullptr;
+int g_wino6_half_max_wg = 0;                       // grids of at most this many workgroups take the half-tile kernel under variant 0 (default: none)
 int g_wino6_variant = 0;                           // 0 / 1 = this file's kernel, 2 = the wide kernel (m4d_wino6w.hip) wherever it applies
 
 }  // namespace
@@ -449,9 +450,13 @@ int g_wino6_variant = 0;                           // 0 / 1 = this file's kernel
 // m4d_wino6w.hip: 16x16 pixels x all 96 / 128 output channels per workgroup, two passes over the position rows; bit-identical
 int m4d_wino6w_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
                       float slope, float* out, void* stream);
+// m4d_wino6h.hip: 16x8 pixels x 64 couts per workgroup (half the tile: twice the workgroups) for small grids; bit-identical
+int m4d_wino6h_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
+                      float slope, float* out, void* stream);
 
 extern "C" void m4d_wino6_set_stamps(unsigned long long* device_buffer) { g_wino6_stamps = device_buffer; }
 extern "C" void m4d_wino6_set_variant(int variant) { g_wino6_variant = variant; }
+extern "C" void m4d_wino6_set_half_tile_max_workgroups(int max_wg) { g_wino6_half_max_wg = max_wg; }
 
 extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                           int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
@@ -470,6 +475,15 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
                          g_wino6_stamps == nullptr;
     if (wide_ok && g_wino6_variant == 2)
       return m4d_wino6w_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
+    // The half-tile kernel (m4d_wino6h.hip, same bits) where this kernel's grid leaves most of the chip idle: level 3 of the
+    // 384x1280 pyramid at batch 1 is 60 workgroups here, 120 there.  Measured (round 3): alone it is 1.05-1.24x faster per layer
+    // on <= 128-workgroup grids (20.4 vs 23.8 us on level 3's 128 -> 128), but it spends 1.7x the CU-time on the same work
+    // (twice the fragment bytes per MFMA), and inside the frame pipeline, where other frames' kernels fill the idle CUs, the
+    // step does not get shorter (1334.6 / 1334.9 / 1329.2 frames/s with the threshold at 0 / 64 / 128 workgroups).  Default
+    // threshold 0 = never; m4d_wino6_set_half_tile_max_workgroups / variant 3 select it.
+    const long long wgs = (long long)b * ((w + kT - 1) / kT) * ((h + kT - 1) / kT) * (CoutPad / 64);
+    if (g_wino6_stamps == nullptr && (g_wino6_variant == 3 || (g_wino6_variant == 0 && wgs <= g_wino6_half_max_wg)))
+      return m4d_wino6h_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
   }
   Wino6Args a;
   a.x = x; a.wu = reinterpret_cast<const unsigned char*>(wu6); a.bias = bias; a.out = out;

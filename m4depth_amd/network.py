@@ -58,6 +58,8 @@ wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
 # m4d_wino6.hip (default), 2 = the wide kernel m4d_wino6w.hip wherever it applies (measured: not faster end to end)
 if _os.environ.get("M4D_WINO6_VARIANT"):
     lib.m4d_wino6_set_variant(int(_os.environ["M4D_WINO6_VARIANT"]))
+if _os.environ.get("M4D_WINO6_HALF_MAX_WG"):           # grids up to this many workgroups take the half-tile kernel m4d_wino6h.hip (default 0 = none)
+    lib.m4d_wino6_set_half_tile_max_workgroups(int(_os.environ["M4D_WINO6_HALF_MAX_WG"]))
 # The one-launch small-map convolution in the same arithmetic (csrc/m4d_conv.hip conv3x3_small6_kernel).  These launches are
 # bound by how fast ONE CU streams its slice of the weights, not by the matrix core: -2 us per layer on the 240-channel first
 # layers, nothing elsewhere (tools/bench_small_convs.py); +0.8 % frames/s at batch 1.  0 = the fp32-MFMA small-map kernel.

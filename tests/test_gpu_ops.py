@@ -790,9 +790,11 @@ S_ENC = [16, 32, 64, 96, 128, 192]
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout", [(1, 64, 96, 128, 96), (1, 64, 96, 64, 128), (2, 33, 47, 48, 128), (1, 50, 70, 32, 100),
-                                             (3, 16, 16, 16, 96), (1, 17, 31, 96, 68)])
+                                             (3, 16, 16, 16, 96), (1, 17, 31, 96, 68), (1, 20, 37, 32, 64), (2, 9, 17, 16, 38),
+                                             (1, 48, 160, 128, 128)])
 def test_wide_bf16_split_winograd_is_bit_identical(dev, b, h, w, cin, cout):
-    """m4d_wino6w.hip (16x16 pixels x all 96 / 128 output channels per workgroup, two passes over the Winograd position
+    """(Also the half-tile kernel m4d_wino6h.hip, 16x8 pixels x 64 output channels per workgroup, one pass, wave-private
+    fragment rings and three raw-halo buffers: the same bits again.)  m4d_wino6w.hip (16x16 pixels x all 96 / 128 output channels per workgroup, two passes over the Winograd position
     rows, the first pass's partial row transform parked in the output pixels) against m4d_wino6.hip (x 64 output channels,
     one pass): the same float32 bits -- same products, same accumulation order, same association in the output transform --
     on whole / ragged / odd-sized maps, batches, 3 and 4 N-tiles, channel counts that are not multiples of 32; and the
@@ -811,11 +813,18 @@ def test_wide_bf16_split_winograd_is_bit_identical(dev, b, h, w, cin, cout):
         lib.m4d_wino6_set_variant(2)
         wide = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
         wide2 = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
+        lib.m4d_wino6_set_variant(3)                # the half-tile kernel (m4d_wino6h.hip): 16x8 pixels x 64 couts per workgroup
+        half = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
+        lib.m4d_wino6_set_variant(0)
+        lib.m4d_wino6_set_half_tile_max_workgroups(1 << 20)       # ... and through the grid-size rule of the default variant
+        half2 = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
     finally:
         lib.m4d_wino6_set_variant(0)
+        lib.m4d_wino6_set_half_tile_max_workgroups(0)
     auto = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
     assert torch.equal(wide, narrow), f"{int((wide != narrow).sum())} of {narrow.numel()} elements differ"
-    assert torch.equal(wide2, wide) and torch.equal(auto, narrow)
+    assert torch.equal(half, narrow), f"half-tile kernel: {int((half != narrow).sum())} of {narrow.numel()} elements differ"
+    assert torch.equal(wide2, wide) and torch.equal(auto, narrow) and torch.equal(half2, half)
     ref = O.leaky_relu(O.conv2d_same(npy(x), k, npy(bias), 1), 0.1)
     assert np.max(np.abs(npy(wide) - ref)) < 1e-5 * max(1.0, np.abs(ref).max())
 
