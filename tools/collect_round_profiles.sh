@@ -37,9 +37,10 @@ for B in 1 32; do
   python tools/summarize_rocprof.py "$STATS" 45 > $OUT/bench_b${B}_kernel_stats_summary.txt
   python tools/trace_table.py "$TRACE" 0.3 > $OUT/bench_b${B}_launch_durations_by_grid.txt
   [ $B = 1 ] && python tools/step_profile.py "$TRACE" 128 > $OUT/step_profile_b1.txt
+  [ $B = 1 ] && python tools/chain_trace.py "$TRACE" 4000 > $OUT/step_timeline_b1.txt
   need $OUT/bench_b${B}_kernel_stats_summary.txt $OUT/bench_b${B}_launch_durations_by_grid.txt
 done
-need $OUT/step_profile_b1.txt
+need $OUT/step_profile_b1.txt $OUT/step_timeline_b1.txt
 
 # the roofline layer alone: every launch of the trace is the level-1 refiner 128->128 layer
 for B in 1 32; do
@@ -50,6 +51,10 @@ for B in 1 32; do
   if [ -n "$TRACE" ]; then python tools/trace_table.py "$TRACE" 0.0 wino6 > $OUT/roofline_layer_b${B}_rocprof_durations.txt; fi
   need $OUT/roofline_layer_b${B}_rocprof_durations.txt $OUT/roofline_layer_b${B}_hip_events.txt
 done
+
+# the round-3 Winograd variants (wide / half-tile): per-layer times and bit equality
+timeout 300 python tools/bench_wino6w.py > $OUT/wino6_variants.txt 2>&1; need $OUT/wino6_variants.txt
+timeout 120 ./build_tmp/l2_stream_probe > $OUT/l2_stream_probe.txt 2>&1 || true
 
 timeout 600 python tools/bench_train.py > $OUT/bench_train.json 2>/dev/null; need $OUT/bench_train.json
 head -c 400 $OUT/bench_b1.json; echo
