@@ -70,6 +70,10 @@ def parse():
     p.add_argument("--eager", action="store_true", help="do not replay the step from a hipGraph")
     p.add_argument("--host-input", action="store_true",
                    help="also report the PCIe-inclusive rate: the RGB / pose batch starts in pinned host memory every step (never `value`)")
+    p.add_argument("--schedule", choices=["graph", "tape"], default=os.environ.get("M4D_BENCH_SCHEDULE", "graph"),
+                   help="graph (default) = ONE hipGraph per step, the frames pipelined on the graph's internal streams; tape = the same "
+                        "(frame, level) wavefront as launch tapes of libm4depth_hip.so replayed as plain stream launches (no hipGraph; "
+                        "measured 3 %% slower, kept as the graph-free launcher)")
     p.add_argument("--in-flight", type=int, default=1,
                    help="independent sequence batches in flight (each on its own stream and model state); 1 = the quoted number")
     return p.parse_args()
@@ -319,7 +323,10 @@ def main():
     runner = None
     replicas = [model]
     if not args.eager:
-        runner = net.GraphedSequence(model, data)
+        if args.schedule == "tape":
+            runner = net.TapedSequence(model, data)
+        else:
+            runner = net.GraphedSequence(model, data)
         # the batch lives in the graph's own input buffers (inputs resident in HBM before the timed region: no hand-over copy)
         data.update({k: v for k, v in runner.input_buffers().items()})
         step = lambda: model.graphed_test_step(data, runner)
@@ -404,8 +411,10 @@ def main():
         "metric_note": "value counts every frame of the sequence the reference's test_step processes, including frame 0, "
                        "which carries new_traj and only runs the encoder + state reset; full_frames_per_s excludes it",
         "AbsRel": round(metrics[0], 6), "sequence_batches_in_flight": args.in_flight,
-        "launch": "eager" if args.eager else "hipGraph replay of the sequence forward; frames pipelined over the decoder "
-                                                  "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)",
+        "launch": "eager" if args.eager else ("launch tapes (csrc/m4d_tape.hip) replayed as plain stream launches, one HIP stream per frame"
+                                                  if args.schedule == "tape" else
+                                                  "hipGraph replay of the sequence forward; frames pipelined over the decoder "
+                                                  "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)"),
     })
     out["config"].update({
         "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",

@@ -442,6 +442,19 @@ int m4d_decode_rgb8_resize(const uint8_t* images, int n, int ih, int iw, int oh,
 int m4d_decode_depth_resize(const void* raw, int kind, int n, int ih, int iw, int oh, int ow,
                             const float* rgb_resized, const int crop[4], float* out, void* stream);
 
+/* ---- launch tape (csrc/m4d_tape.hip): a recorded sequence of this library's kernel launches, replayed as PLAIN STREAM
+ * LAUNCHES from one host loop -- the host-side cost of a hipGraph replay without its effect on concurrent small kernels
+ * (kernels issued by graph replays make each other's small launches crawl: DESIGN.md section 6).  Between m4d_tape_begin()
+ * and m4d_tape_end() every entry point called BY THE SAME THREAD records its launches (function, grid, block, LDS, a copy of
+ * every argument) instead of executing them; the recording pass must run on the buffers the replays will use.
+ * m4d_tape_begin returns the tape id (-1: already recording), m4d_tape_end the number of launches recorded,
+ * m4d_tape_replay issues them on `stream` in order (0 or a hipError_t). */
+int m4d_tape_begin(void);
+int m4d_tape_end(void);
+int m4d_tape_length(int tape);
+int m4d_tape_replay(int tape, void* stream);
+int m4d_tape_free(int tape);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,10 @@ _SIGNATURES = {
                        _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
 }
 
+# launch tape (csrc/m4d_tape.hip): int-returning, no stream implied
+_SIGNATURES.update({"m4d_tape_begin": [], "m4d_tape_end": [], "m4d_tape_length": [_c_int], "m4d_tape_replay": [_c_int, _c_fp],
+                    "m4d_tape_free": [_c_int]})
+
 _LL_SIGNATURES = {"m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
                   "m4d_dinl_workspace_floats": [_c_int, _c_int], "m4d_metrics_workspace_bytes": [],
                   "m4d_bias_act_bwd_workspace_floats": [ctypes.c_longlong, _c_int], "m4d_loss_workspace_floats": [],

@@ -14,6 +14,34 @@
 
 static inline int m4d_blocks(long long n, int threads) { return (int)((n + threads - 1) / threads); }
 
+// ---- launch tape (m4d_tape.hip) ------------------------------------------------------------------------------------
+// Every kernel of the library is launched through m4d_launch().  Normally it IS hipLaunchKernelGGL.  While the calling
+// thread records a tape (m4d_tape_begin .. m4d_tape_end) the launch is not executed but appended -- function, grid, block,
+// dynamic LDS and a private copy of every argument -- to the tape, which m4d_tape_replay() later issues as plain stream
+// launches (hipLaunchKernel) from one tight host loop: a replayable launch sequence WITHOUT hipGraph (kernels issued by
+// graph replays starve each other's small launches).
+#include <tuple>
+#include <utility>
+bool m4d_tape_recording();
+void m4d_tape_push(const void* fn, dim3 grid, dim3 block, unsigned lds, void* const* params, const size_t* sizes, int n);
+
+template <class Tuple, size_t... I>
+inline void m4d_tape_push_tuple(const void* fn, dim3 grid, dim3 block, unsigned lds, Tuple& vals, std::index_sequence<I...>) {
+  void* params[sizeof...(I) + 1] = {static_cast<void*>(&std::get<I>(vals))...};
+  const size_t sizes[sizeof...(I) + 1] = {sizeof(std::tuple_element_t<I, Tuple>)...};
+  m4d_tape_push(fn, grid, block, lds, params, sizes, (int)sizeof...(I));
+}
+
+template <class... KArgs, class... Args>
+inline void m4d_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args&&... args) {
+  if (m4d_tape_recording()) {
+    std::tuple<std::remove_cv_t<std::remove_reference_t<KArgs>>...> vals(static_cast<KArgs>(args)...);
+    m4d_tape_push_tuple(reinterpret_cast<const void*>(kernel), grid, block, (unsigned)lds, vals, std::index_sequence_for<KArgs...>{});
+    return;
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
+}
+
 // Per-sample camera motion: rotation matrix (get_rot_mat, utils/depth_operations.py:18-53),
 // translation scaled by the focal lengths, level-local intrinsics.
 struct M4dMotion {

@@ -664,7 +664,7 @@ void launch_conv(const ConvArgs& a, dim3 grid, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<NT, TS, STRIDE, DB, MINB>), grid, dim3(256), lds, s, a);
+  m4d_launch((conv3x3_mfma_kernel<NT, TS, STRIDE, DB, MINB>), grid, dim3(256), lds, s, a);
 }
 
 template <int STRIDE>
@@ -718,8 +718,8 @@ static int launch_conv3x3_small(const float* x, const float* wp, const float* bi
     attr_set = true;
   }
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b);
-  if (stride == 1) hipLaunchKernelGGL(conv3x3_small_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(conv3x3_small_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  if (stride == 1) m4d_launch(conv3x3_small_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  else m4d_launch(conv3x3_small_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }
 extern "C" int m4d_conv3x3_small_bias_act(const float* x, const float* wp, const float* bias, int b, int h, int w,
@@ -752,7 +752,7 @@ extern "C" int m4d_conv3x3_small6_bias_act(const float* x, const void* wp6, cons
                               160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv3x3_small6_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b), dim3(256),
+  m4d_launch(conv3x3_small6_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b), dim3(256),
                      lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }
@@ -795,7 +795,7 @@ extern "C" int m4d_conv3x3s2_dinl_bias_act(const float* x_raw, const float* mean
     attr_set = true;
   }
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), 1, (unsigned)b);
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<1, 9, 2, false, 2, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+  m4d_launch((conv3x3_mfma_kernel<1, 9, 2, false, 2, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -848,7 +848,7 @@ extern "C" int m4d_conv3x3s_bias_act_ws(const float* x, const float* wp, const f
     const long long pixels = (long long)b * a.oh * a.ow;
     long long g = (pixels * Cout + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, workspace, bias, pixels, Cout,
+    m4d_launch(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, workspace, bias, pixels, Cout,
                        CoutPad, ksplit, slope, out);
   }
   return M4D_LAUNCH_RESULT();

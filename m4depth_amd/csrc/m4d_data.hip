@@ -102,7 +102,7 @@ extern "C" int m4d_decode_rgb8_resize(const uint8_t* images, int n, int ih, int 
                                       void* stream) {
   M4D_CHECK_ARG(images && out && n > 0 && ih > 0 && iw > 0 && oh > 0 && ow > 0);
   const long long total = (long long)n * oh * ow * 3;
-  hipLaunchKernelGGL(rgb8_resize_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, images, ih, iw, oh, ow,
+  m4d_launch(rgb8_resize_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, images, ih, iw, oh, ow,
                      total, out);
   return M4D_LAUNCH_RESULT();
 }
@@ -114,7 +114,7 @@ extern "C" int m4d_decode_depth_resize(const void* raw, int kind, int n, int ih,
   const long long total = (long long)n * oh * ow;
   int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
   if (crop) { c0 = crop[0]; c1 = crop[1]; c2 = crop[2]; c3 = crop[3]; }
-  hipLaunchKernelGGL(depth_resize_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, raw, kind, ih, iw, oh,
+  m4d_launch(depth_resize_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, raw, kind, ih, iw, oh,
                      ow, rgb_resized, c0, c1, c2, c3, total, out);
   return M4D_LAUNCH_RESULT();
 }

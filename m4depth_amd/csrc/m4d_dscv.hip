@@ -596,9 +596,9 @@ bool launch_wave(const DscvArgs& a, int b, hipStream_t s) {
   constexpr int PPW = 64 / LP;
   const int hw = a.h * a.w;
   int nb = (hw + 4 * PPW - 1) / (4 * PPW);
-  if (a.r == 4) hipLaunchKernelGGL((dscv_wave_kernel<LP, G, 9>), dim3(nb, b), dim3(256), 0, s, a);
-  else if (a.r == 2) hipLaunchKernelGGL((dscv_wave_kernel<LP, G, 5>), dim3(nb, b), dim3(256), 0, s, a);
-  else if (a.r == 6) hipLaunchKernelGGL((dscv_wave_kernel<LP, G, 13>), dim3(nb, b), dim3(256), 0, s, a);
+  if (a.r == 4) m4d_launch((dscv_wave_kernel<LP, G, 9>), dim3(nb, b), dim3(256), 0, s, a);
+  else if (a.r == 2) m4d_launch((dscv_wave_kernel<LP, G, 5>), dim3(nb, b), dim3(256), 0, s, a);
+  else if (a.r == 6) m4d_launch((dscv_wave_kernel<LP, G, 13>), dim3(nb, b), dim3(256), 0, s, a);
   else return false;
   return true;
 }
@@ -617,7 +617,7 @@ void launch_tile_ncp(const DscvTileArgs& ta, int b, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((dscv_tile_kernel<LP, G, NCP>), dim3(ta.tiles, b), dim3(256), kDscvLdsBudget, s, ta);
+  m4d_launch((dscv_tile_kernel<LP, G, NCP>), dim3(ta.tiles, b), dim3(256), kDscvLdsBudget, s, ta);
 }
 
 template <int NC, int K, int NCP, int HPL>
@@ -628,7 +628,7 @@ void launch_hyp_ncp(const DscvTileArgs& ta, int b, size_t lds, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((dscv_hyp_kernel<NC, K, NCP, HPL>), dim3(ta.tiles, b), dim3(256), lds, s, ta);
+  m4d_launch((dscv_hyp_kernel<NC, K, NCP, HPL>), dim3(ta.tiles, b), dim3(256), lds, s, ta);
 }
 
 // Tile / LDS choice of the hypothesis-per-lane kernel: largest tile whose minimal window (tile +
@@ -738,7 +738,7 @@ extern "C" int m4d_dscv_fwd(const float* c1, const float* c2, const float* disp_
   const bool tile = fits && g_dscv_variant == 2;
   if (g_dscv_variant == 0) {
     const long long threads = (long long)h * w * nbre_cuts;
-    hipLaunchKernelGGL(dscv_generic_kernel, dim3(m4d_blocks(threads, 256), b), dim3(256), 0, s, a);
+    m4d_launch(dscv_generic_kernel, dim3(m4d_blocks(threads, 256), b), dim3(256), 0, s, a);
     return M4D_LAUNCH_RESULT();
   }
   if (tile && lp == 4 && g == 4 && launch_tile<4, 4>(a, b, s)) return M4D_LAUNCH_RESULT();
@@ -758,7 +758,7 @@ extern "C" int m4d_dscv_fwd(const float* c1, const float* c2, const float* disp_
   else if (fits && lp == 4 && g == 2) done = launch_wave<4, 2>(a, b, s);     // C=16  k=2
   if (!done) {                                  // any other shape / search range
     const long long threads = (long long)h * w * nbre_cuts;
-    hipLaunchKernelGGL(dscv_generic_kernel, dim3(m4d_blocks(threads, 256), b), dim3(256), 0, s, a);
+    m4d_launch(dscv_generic_kernel, dim3(m4d_blocks(threads, 256), b), dim3(256), 0, s, a);
   }
   return M4D_LAUNCH_RESULT();
 }
@@ -771,8 +771,8 @@ bool launch_wave_sncv(const DscvArgs& a, int b, const m4d_sncv::SncvArgs& sa, hi
   const int nb_sncv = (int)m4d_sncv::sncv_small_blocks(sa, b);
   const dim3 grid((unsigned)(nb * b + nb_sncv));
   const int total_px = b * hw;
-  if (a.r == 4) hipLaunchKernelGGL((dscv_sncv_small_kernel<LP, G, 9>), grid, dim3(256), 0, s, a, nb, b, sa, total_px, nb_sncv);
-  else if (a.r == 2) hipLaunchKernelGGL((dscv_sncv_small_kernel<LP, G, 5>), grid, dim3(256), 0, s, a, nb, b, sa, total_px, nb_sncv);
+  if (a.r == 4) m4d_launch((dscv_sncv_small_kernel<LP, G, 9>), grid, dim3(256), 0, s, a, nb, b, sa, total_px, nb_sncv);
+  else if (a.r == 2) m4d_launch((dscv_sncv_small_kernel<LP, G, 5>), grid, dim3(256), 0, s, a, nb, b, sa, total_px, nb_sncv);
   else return false;
   return true;
 }

@@ -401,7 +401,7 @@ int launch_front_acc(const FrontArgs& a0, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((level_front_kernel<NC, K, TW, TH, YS, SEQ16>), dim3((unsigned)total), dim3(Gm::NT), lds, s, a);
+  m4d_launch((level_front_kernel<NC, K, TW, TH, YS, SEQ16>), dim3((unsigned)total), dim3(Gm::NT), lds, s, a);
   return M4D_LAUNCH_RESULT();
 }
 

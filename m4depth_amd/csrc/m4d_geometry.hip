@@ -106,7 +106,7 @@ int launch_converter(const float* in, const float* rot, int rot_c, const float* 
   if (OP != OP_PREV_D2PARA) M4D_CHECK_ARG(rot && (rot_c == 3 || rot_c == 4));
   int gx = m4d_blocks((long long)h * w, 256);
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(converter_kernel<OP>, dim3(gx, b), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(converter_kernel<OP>, dim3(gx, b), dim3(256), 0, (hipStream_t)stream,
                      in, rot, rot_c, trans, cam_f, cam_c, h, w, out);
   return M4D_LAUNCH_RESULT();
 }
@@ -145,7 +145,7 @@ extern "C" int m4d_reproject_flow(const float* depth, const float* rot, int rot_
   M4D_CHECK_ARG(b > 0 && h > 0 && w > 0 && (rot_c == 3 || rot_c == 4));
   int gx = m4d_blocks((long long)h * w, 256);
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(reproject_flow_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(reproject_flow_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream,
                      depth, rot, rot_c, trans, cam_f, cam_c, h, w, flow, proj_minus_rot, rot_coord);
   return M4D_LAUNCH_RESULT();
 }

@@ -253,7 +253,7 @@ extern "C" int m4d_dscv_bwd(const float* c1, const float* c2, const float* disp_
   M4D_CHECK_ARG(PPW >= 1);
   const int ppb = 4 * PPW;
   dim3 grid((h * w + ppb - 1) / ppb, b);
-  hipLaunchKernelGGL(dscv_bwd_kernel, grid, dim3(256), 0, s, a);
+  m4d_launch(dscv_bwd_kernel, grid, dim3(256), 0, s, a);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -272,6 +272,6 @@ extern "C" int m4d_sncv_bwd(const float* c1, const float* c2, const float* out, 
   a.h = h; a.w = w; a.C = C; a.r = search_range; a.d = dilation_rate; a.k = nbre_cuts; a.slope = slope;
   a.g_c1 = g_c1; a.g_c2 = g_c2;
   const long long total = (long long)b * h * w * (C / 4);
-  hipLaunchKernelGGL(sncv_bwd_kernel, dim3(m4d_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, a, total);
+  m4d_launch(sncv_bwd_kernel, dim3(m4d_blocks(total, 256)), dim3(256), 0, (hipStream_t)stream, a, total);
   return M4D_LAUNCH_RESULT();
 }

@@ -80,7 +80,7 @@ void launch_normalize_group(const float* x, long long items, float* out, hipStre
   constexpr int GPW = 64 / LPG;
   const long long waves = (items + GPW - 1) / GPW;
   const long long blocks = (waves + 3) / 4;
-  hipLaunchKernelGGL(normalize_cuts_group_kernel<LPG>, dim3((unsigned)blocks), dim3(256), 0, s, x, items, out);
+  m4d_launch(normalize_cuts_group_kernel<LPG>, dim3((unsigned)blocks), dim3(256), 0, s, x, items, out);
 }
 
 // ---- tf.compat.v1.image.resize_bilinear, legacy coordinates (:202-204): ResizeAxis / resize_axis / resize_sample live in
@@ -299,8 +299,8 @@ extern "C" int m4d_normalize_cuts(const float* x, int b, int h, int w, int C, in
       default: break;
     }
   }
-  if (vec) hipLaunchKernelGGL(normalize_cuts_kernel<true>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, items, C, nbre_cuts, nc, out);
-  else hipLaunchKernelGGL(normalize_cuts_kernel<false>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, items, C, nbre_cuts, nc, out);
+  if (vec) m4d_launch(normalize_cuts_kernel<true>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, items, C, nbre_cuts, nc, out);
+  else m4d_launch(normalize_cuts_kernel<false>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, items, C, nbre_cuts, nc, out);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -308,7 +308,7 @@ extern "C" int m4d_resize_bilinear_v1(const float* x, int b, int ih, int iw, int
                                       float mul, float* out, void* stream) {
   M4D_CHECK_ARG(x && out && b > 0 && ih > 0 && iw > 0 && c > 0 && oh > 0 && ow > 0);
   const long long total = (long long)b * oh * ow * c;
-  hipLaunchKernelGGL(resize_bilinear_v1_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(resize_bilinear_v1_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
                      x, ih, iw, c, oh, ow, mul, total, out);
   return M4D_LAUNCH_RESULT();
 }
@@ -317,7 +317,7 @@ extern "C" int m4d_resize_nearest(const float* x, int b, int ih, int iw, int c, 
                                   float* out, void* stream) {
   M4D_CHECK_ARG(x && out && b > 0 && ih > 0 && iw > 0 && c > 0 && oh > 0 && ow > 0);
   const long long total = (long long)b * oh * ow * c;
-  hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(resize_nearest_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
                      x, ih, iw, c, oh, ow, total, out);
   return M4D_LAUNCH_RESULT();
 }
@@ -355,14 +355,14 @@ extern "C" int m4d_level_pre_normalize(const float* prev_l_depth, const float* p
     const dim3 grid((unsigned)(pre_blocks + nblocks));
     hipStream_t s = (hipStream_t)stream;
     switch (lpg) {
-      case 2: hipLaunchKernelGGL(level_pre_normalize_kernel<2>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
-      case 4: hipLaunchKernelGGL(level_pre_normalize_kernel<4>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
-      case 6: hipLaunchKernelGGL(level_pre_normalize_kernel<6>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
-      default: hipLaunchKernelGGL(level_pre_normalize_kernel<8>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
+      case 2: m4d_launch(level_pre_normalize_kernel<2>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
+      case 4: m4d_launch(level_pre_normalize_kernel<4>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
+      case 6: m4d_launch(level_pre_normalize_kernel<6>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
+      default: m4d_launch(level_pre_normalize_kernel<8>, grid, dim3(256), 0, s, a, gx, pre_blocks, norm_x, items, norm_out); break;
     }
     return M4D_LAUNCH_RESULT();
   }
-  hipLaunchKernelGGL(level_pre_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, a);      // other channel counts: two launches
+  m4d_launch(level_pre_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, a);      // other channel counts: two launches
   const int rc = M4D_LAUNCH_RESULT();
   if (rc != 0) return rc;
   return m4d_normalize_cuts(norm_x, b, h, w, C, nbre_cuts, norm_out, stream);
@@ -389,7 +389,7 @@ extern "C" int m4d_level_pre(const float* prev_l_depth, const float* prev_l_para
   a.depth_state_reset = depth_state_reset;
   int gx = m4d_blocks((long long)h * w, 256);
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(level_pre_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, a);
+  m4d_launch(level_pre_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -397,7 +397,7 @@ extern "C" int m4d_camera_pyramid(const float* cam_f, const float* cam_c, int b,
                                   void* stream) {
   M4D_CHECK_ARG(cam_f && cam_c && f_out && c_out && b > 0 && levels > 0 && levels < 31);
   const int n = 2 * b;
-  hipLaunchKernelGGL(camera_pyramid_kernel, dim3((n * levels + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(camera_pyramid_kernel, dim3((n * levels + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      cam_f, cam_c, n, levels, f_out, c_out);
   return M4D_LAUNCH_RESULT();
 }
@@ -410,7 +410,7 @@ extern "C" int m4d_level_post(const float* refiner_out, const float* rot, int ro
   M4D_CHECK_ARG((((uintptr_t)other) & 15u) == 0);
   int gx = m4d_blocks((long long)h * w, 256);
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(level_post_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(level_post_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream,
                      refiner_out, rot, rot_c, trans, cam_f, cam_c, h, w, scale, parallax, depth, other, depth_state);
   return M4D_LAUNCH_RESULT();
 }
@@ -420,8 +420,8 @@ extern "C" int m4d_bias_act(const float* x, const float* bias, long long rows, i
   M4D_CHECK_ARG(x && bias && out && rows > 0 && C > 0);
   const long long total = rows * C;
   const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias) & 15u) == 0);
-  if (vec) hipLaunchKernelGGL(bias_act_kernel<true>, dim3(grid1d(total >> 2)), dim3(256), 0, (hipStream_t)stream, x, bias, total, C, slope, out);
-  else hipLaunchKernelGGL(bias_act_kernel<false>, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, x, bias, total, C, slope, out);
+  if (vec) m4d_launch(bias_act_kernel<true>, dim3(grid1d(total >> 2)), dim3(256), 0, (hipStream_t)stream, x, bias, total, C, slope, out);
+  else m4d_launch(bias_act_kernel<false>, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, x, bias, total, C, slope, out);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -431,7 +431,7 @@ extern "C" int m4d_bias_act_padded(const float* x, const float* bias, int b, int
   M4D_CHECK_ARG(off_y >= 0 && off_x >= 0 && off_y + h <= out_h && off_x + w <= out_w);
   M4D_CHECK_ARG(((((uintptr_t)x | (uintptr_t)out | (uintptr_t)bias)) & 15u) == 0);
   const long long total4 = (long long)b * h * w * (C / 4);
-  hipLaunchKernelGGL(bias_act_padded_kernel, dim3(grid1d(total4)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(bias_act_padded_kernel, dim3(grid1d(total4)), dim3(256), 0, (hipStream_t)stream,
                      x, bias, h, w, C, slope, out, out_h, out_w, off_y, off_x, total4);
   return M4D_LAUNCH_RESULT();
 }

@@ -534,14 +534,14 @@ extern "C" int m4d_dinl_fwd_padded(const float* x, const float* scale, const flo
   float* partial = workspace;
   float* mean = workspace + (long long)b * kDinlMaxBlocks * C;
   float* var = mean + (long long)b * C;
-  hipLaunchKernelGGL(dinl_partial_kernel, dim3(nblk, b), dim3(256), 0, s, x, (const float*)nullptr, hw, C, 0, partial);
-  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
-  hipLaunchKernelGGL(dinl_partial_kernel, dim3(nblk, b), dim3(256), 0, s, x, (const float*)mean, hw, C, 1, partial);
-  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, var);
+  m4d_launch(dinl_partial_kernel, dim3(nblk, b), dim3(256), 0, s, x, (const float*)nullptr, hw, C, 0, partial);
+  m4d_launch(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
+  m4d_launch(dinl_partial_kernel, dim3(nblk, b), dim3(256), 0, s, x, (const float*)mean, hw, C, 1, partial);
+  m4d_launch(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, var);
   int gx = m4d_blocks(hw, 256);
   if (gx > 2048) gx = 2048;
-  if (C == 16) hipLaunchKernelGGL(dinl_apply_kernel<16>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, w, slope, out, out_h, out_w, off_y, off_x);
-  else hipLaunchKernelGGL(dinl_apply_kernel<32>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, w, slope, out, out_h, out_w, off_y, off_x);
+  if (C == 16) m4d_launch(dinl_apply_kernel<16>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, w, slope, out, out_h, out_w, off_y, off_x);
+  else m4d_launch(dinl_apply_kernel<32>, dim3(gx, b), dim3(256), 0, s, x, mean, var, scale, bias, hw, w, slope, out, out_h, out_w, off_y, off_x);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -560,14 +560,14 @@ extern "C" int m4d_enc_head_fwd(const float* images, int bsz, long long stride_b
   float* partial = workspace;
   float* mean = workspace + (long long)b * kDinlMaxBlocks * C;
   float* var = mean + (long long)b * C;
-  hipLaunchKernelGGL(enc_head_conv_kernel<16>, dim3(nblk, b), dim3(256), 0, s, images, w_hwio, bias, h, w, bsz, stride_b, stride_t,
+  m4d_launch(enc_head_conv_kernel<16>, dim3(nblk, b), dim3(256), 0, s, images, w_hwio, bias, h, w, bsz, stride_b, stride_t,
                      raw_out, partial);
-  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
+  m4d_launch(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
   const int ppi = 256 / (C / 4);
   int nblk2 = (hw + ppi * 8 - 1) / (ppi * 8);
   if (nblk2 > kDinlMaxBlocks) nblk2 = kDinlMaxBlocks;
-  hipLaunchKernelGGL(dinl_partial_kernel, dim3(nblk2, b), dim3(256), 0, s, (const float*)raw_out, (const float*)mean, hw, C, 1, partial);
-  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk2, C, hw, var);
+  m4d_launch(dinl_partial_kernel, dim3(nblk2, b), dim3(256), 0, s, (const float*)raw_out, (const float*)mean, hw, C, 1, partial);
+  m4d_launch(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk2, C, hw, var);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -590,22 +590,22 @@ extern "C" int m4d_enc_level0_fwd(const float* images, int bsz, long long stride
   if (analytic_mean) {
     int nb3 = (hw + 256 * 16 - 1) / (256 * 16);
     if (nb3 > kDinlMaxBlocks) nb3 = kDinlMaxBlocks;
-    hipLaunchKernelGGL(enc0_rgb_total_kernel, dim3(nb3, b), dim3(256), 0, s, images, hw, bsz, stride_b, stride_t, partial);
-    hipLaunchKernelGGL(enc0_mean_kernel, dim3(b), dim3(256), 0, s, images, (const float*)partial, nb3, w1_hwio, bias1, h, w, bsz,
+    m4d_launch(enc0_rgb_total_kernel, dim3(nb3, b), dim3(256), 0, s, images, hw, bsz, stride_b, stride_t, partial);
+    m4d_launch(enc0_mean_kernel, dim3(b), dim3(256), 0, s, images, (const float*)partial, nb3, w1_hwio, bias1, h, w, bsz,
                        stride_b, stride_t, mean);
   } else {
-    hipLaunchKernelGGL(enc0_stats_kernel<0>, dim3(nblk, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)nullptr, h, w, bsz,
+    m4d_launch(enc0_stats_kernel<0>, dim3(nblk, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)nullptr, h, w, bsz,
                        stride_b, stride_t, tiles_x, n_tiles, partial);
-    hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
+    m4d_launch(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, mean);
   }
-  hipLaunchKernelGGL(enc0_stats_kernel<1>, dim3(nblk, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)mean, h, w, bsz,
+  m4d_launch(enc0_stats_kernel<1>, dim3(nblk, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)mean, h, w, bsz,
                      stride_b, stride_t, tiles_x, n_tiles, partial);
-  hipLaunchKernelGGL(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, var);
+  m4d_launch(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, var);
   const int oh = (h + 1) / 2, ow = (w + 1) / 2;
   const int ftx = (ow + kF0OW - 1) / kF0OW, fty = (oh + kF0OH - 1) / kF0OH;
   const int tot_y = (oh - 1) * 2 + 3 - h, tot_x = (ow - 1) * 2 + 3 - w;                 // TF 'SAME' total padding
   const int pad_y = (tot_y > 0 ? tot_y : 0) / 2, pad_x = (tot_x > 0 ? tot_x : 0) / 2;
-  hipLaunchKernelGGL(enc0_fused_kernel, dim3(ftx * fty, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)mean,
+  m4d_launch(enc0_fused_kernel, dim3(ftx * fty, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)mean,
                      (const float*)var, dn_scale, dn_bias, dn_slope, w2_hwio, bias2, slope, h, w, oh, ow, pad_y, pad_x, bsz, stride_b,
                      stride_t, ftx, out);
   return M4D_LAUNCH_RESULT();
@@ -620,7 +620,7 @@ extern "C" int m4d_depth_metrics(const float* gt, const float* est, long long n,
   hipStream_t s = (hipStream_t)stream;
   long long g = (n + 255) / 256;
   const int nblk = (int)(g < kMetricBlocks ? g : kMetricBlocks);
-  hipLaunchKernelGGL(metrics_partial_kernel, dim3(nblk), dim3(256), 0, s, gt, est, n, max_d, (double*)workspace);
-  hipLaunchKernelGGL(metrics_finalize_kernel, dim3(1), dim3(kMetricSums * 32), 0, s, (const double*)workspace, nblk, out7, total7, count, mean7);
+  m4d_launch(metrics_partial_kernel, dim3(nblk), dim3(256), 0, s, gt, est, n, max_d, (double*)workspace);
+  m4d_launch(metrics_finalize_kernel, dim3(1), dim3(kMetricSums * 32), 0, s, (const double*)workspace, nblk, out7, total7, count, mean7);
   return M4D_LAUNCH_RESULT();
 }

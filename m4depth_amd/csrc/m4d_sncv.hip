@@ -300,7 +300,7 @@ bool launch_sncv7_ys(const float* c, int b, int h, int w, float* out, int out_st
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((sncv7_kernel<NC, K, TW, TH, YS>), dim3((int)nwg), dim3(256 * YS), lds, s, c, b, h, w, out, out_stride,
+  m4d_launch((sncv7_kernel<NC, K, TW, TH, YS>), dim3((int)nwg), dim3(256 * YS), lds, s, c, b, h, w, out, out_stride,
                      tiles_x, tiles_y, 0);
   return true;
 }
@@ -356,7 +356,7 @@ sncv_small_kernel(const SncvArgs a, int total_px) { m4d_sncv::sncv_small_body<NC
 
 template <int NC>
 void launch_small(const SncvArgs& a, int b, hipStream_t s) {
-  hipLaunchKernelGGL((sncv_small_kernel<NC>), dim3((int)m4d_sncv::sncv_small_blocks(a, b)), dim3(256), 0, s, a, b * a.h * a.w);
+  m4d_launch((sncv_small_kernel<NC>), dim3((int)m4d_sncv::sncv_small_blocks(a, b)), dim3(256), 0, s, a, b * a.h * a.w);
 }
 
 template <int NC, int MO>
@@ -368,7 +368,7 @@ void launch_lds_mo(const SncvArgs& a, int b, size_t lds, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((sncv_lds_kernel<NC, MO>), dim3(tiles, b), dim3(256), lds, s, a);
+  m4d_launch((sncv_lds_kernel<NC, MO>), dim3(tiles, b), dim3(256), lds, s, a);
 }
 
 template <int NC>
@@ -445,7 +445,7 @@ extern "C" int m4d_sncv_fwd(const float* c1, const float* c2, int b, int h, int 
     const long long total = (long long)b * h * w * mo * mo * nbre_cuts;
     long long g = (total + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
-    hipLaunchKernelGGL(sncv_generic_kernel, dim3((int)g), dim3(256), 0, s, a, total);
+    m4d_launch(sncv_generic_kernel, dim3((int)g), dim3(256), 0, s, a, total);
   }
   return M4D_LAUNCH_RESULT();
 }

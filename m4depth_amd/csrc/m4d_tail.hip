@@ -188,6 +188,6 @@ extern "C" int m4d_refiner_tail(const float* x32, const float* w6p, const float*
                               160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(refiner_tail_kernel, dim3(tiles, b), dim3(256), lds, (hipStream_t)stream, a);
+  m4d_launch(refiner_tail_kernel, dim3(tiles, b), dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -276,7 +276,7 @@ extern "C" int m4d_resize_bilinear_v1_bwd(const float* g_out, int b, int ih, int
                                           float mul, float* g_in, void* stream) {
   M4D_CHECK_ARG(g_out && g_in && b > 0 && ih > 0 && iw > 0 && c > 0 && oh > 0 && ow > 0);
   const long long total = (long long)b * ih * iw * c;
-  hipLaunchKernelGGL(resize_bilinear_v1_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(resize_bilinear_v1_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
                      g_out, ih, iw, c, oh, ow, mul, total, g_in);
   return M4D_LAUNCH_RESULT();
 }
@@ -290,7 +290,7 @@ extern "C" int m4d_level_post_bwd(const float* refiner_out, const float* g_paral
   if (g_other) M4D_CHECK_ARG((((uintptr_t)g_other) & 15u) == 0);
   int gx = m4d_blocks((long long)h * w, 256);
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(level_post_bwd_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, refiner_out, g_parallax,
+  m4d_launch(level_post_bwd_kernel, dim3(gx, b), dim3(256), 0, (hipStream_t)stream, refiner_out, g_parallax,
                      g_depth, g_other, rot, rot_c, trans, cam_f, cam_c, h, w, scale, g_refiner_out);
   return M4D_LAUNCH_RESULT();
 }
@@ -299,7 +299,7 @@ extern "C" int m4d_normalize_cuts_bwd(const float* x, const float* g, int b, int
                                       float* g_x, void* stream) {
   M4D_CHECK_ARG(x && g && g_x && b > 0 && h > 0 && w > 0 && C > 0 && nbre_cuts > 0 && C % nbre_cuts == 0);
   const long long groups = (long long)b * h * w * nbre_cuts;
-  hipLaunchKernelGGL(normalize_cuts_bwd_kernel, dim3(grid1d(groups)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(normalize_cuts_bwd_kernel, dim3(grid1d(groups)), dim3(256), 0, (hipStream_t)stream,
                      x, g, groups, C / nbre_cuts, g_x);
   return M4D_LAUNCH_RESULT();
 }
@@ -326,10 +326,10 @@ extern "C" int m4d_bias_act_bwd(const float* g, const float* out, long long rows
   bias_bwd_plan(rows, C, blocks, rpb);
   hipStream_t s = (hipStream_t)stream;
   if (C <= 256)
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(blocks), dim3(256), 0, s, g, out, rows, C, slope, rpb, g_pre, workspace);
+    m4d_launch(bias_act_bwd_kernel, dim3(blocks), dim3(256), 0, s, g, out, rows, C, slope, rpb, g_pre, workspace);
   else
-    hipLaunchKernelGGL(bias_act_bwd_wide_kernel, dim3(blocks), dim3(256), 0, s, g, out, rows, C, slope, rpb, g_pre, workspace);
-  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, blocks, C, g_bias);
+    m4d_launch(bias_act_bwd_wide_kernel, dim3(blocks), dim3(256), 0, s, g, out, rows, C, slope, rpb, g_pre, workspace);
+  m4d_launch(bias_grad_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, blocks, C, g_bias);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -338,7 +338,7 @@ extern "C" int m4d_pack_conv_weights(const float* w_ohwi, int O, int I, int tran
   const int K = transpose ? O : I, N = transpose ? I : O;
   const int n_pad = (N + 31) / 32 * 32;
   const long long total = (long long)((K + 15) / 16) * 9 * n_pad * 16;
-  hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(pack_conv_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      w_ohwi, O, I, transpose, n_pad, total, wp);
   return M4D_LAUNCH_RESULT();
 }
@@ -352,9 +352,9 @@ extern "C" int m4d_loss_level_fwd(const float* pred_depth, const float* gt_depth
   long long blocks = ((long long)b * h * w + 255) / 256;
   if (blocks > 512) blocks = 512;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(loss_level_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred_depth, gt_depth, b, h, w, H, W,
+  m4d_launch(loss_level_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pred_depth, gt_depth, b, h, w, H, W,
                      velodyne, workspace);
-  hipLaunchKernelGGL(loss_level_finalize_kernel, dim3(1), dim3(1), 0, s, workspace, (int)blocks, velodyne, out2);
+  m4d_launch(loss_level_finalize_kernel, dim3(1), dim3(1), 0, s, workspace, (int)blocks, velodyne, out2);
   return M4D_LAUNCH_RESULT();
 }
 
@@ -363,7 +363,7 @@ extern "C" int m4d_loss_level_bwd(const float* pred_depth, const float* gt_depth
                                   float* g_pred, void* stream) {
   M4D_CHECK_ARG(pred_depth && gt_depth && stats2 && g_out && g_pred && b > 0 && h > 0 && w > 0);
   const long long total = (long long)b * h * w;
-  hipLaunchKernelGGL(loss_level_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, pred_depth, gt_depth,
+  m4d_launch(loss_level_bwd_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, pred_depth, gt_depth,
                      stats2, g_out, b, h, w, H, W, velodyne, g_pred);
   return M4D_LAUNCH_RESULT();
 }

@@ -160,7 +160,7 @@ extern "C" int m4d_backproject_fwd(const float* input, const float* coords, cons
   for (int k = 0; k < 6; ++k) M4D_CHECK_ARG(dims[k] > 0);
   M4D_CHECK_ARG(dims[1] >= 1 && dims[2] >= 1);
   const long long total = (long long)dims[0] * dims[1] * dims[2] * dims[3] * dims[4] * dims[5];
-  hipLaunchKernelGGL(backproject_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(backproject_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      input, coords, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], total, out);
   return M4D_LAUNCH_RESULT();
 }
@@ -174,9 +174,9 @@ extern "C" int m4d_backproject_bwd(const float* grad, const float* input, const 
   const size_t in_bytes = sizeof(float) * (size_t)dims[0] * dims[1] * dims[2] * dims[4] * dims[5];
   hipError_t e = hipMemsetAsync(input_grad, 0, in_bytes, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(backproject_bwd_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(backproject_bwd_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      grad, coords, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], total, input_grad);
-  hipLaunchKernelGGL(backproject_bwd_coords_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(backproject_bwd_coords_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream,
                      grad, input, coords, dims[0], dims[1], dims[2], dims[3], dims[4], dims[5], items, coords_grad);
   return M4D_LAUNCH_RESULT();
 }
@@ -186,7 +186,7 @@ extern "C" int m4d_dense_image_warp(const float* image, const float* flow, int B
   M4D_CHECK_ARG(image && flow && out);
   M4D_CHECK_ARG(B > 0 && C > 0 && H >= 2 && W >= 2);   // dense_image_warp.py:116-119
   const long long total = (long long)B * H * W * C;
-  hipLaunchKernelGGL(interp_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(interp_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      image, flow, B, H, W, C, H * W, 1, total, out, index_out);
   return M4D_LAUNCH_RESULT();
 }
@@ -196,7 +196,7 @@ extern "C" int m4d_interpolate_bilinear(const float* grid, const float* query, i
   M4D_CHECK_ARG(grid && query && out);
   M4D_CHECK_ARG(B > 0 && C > 0 && N > 0 && H >= 2 && W >= 2);
   const long long total = (long long)B * N * C;
-  hipLaunchKernelGGL(interp_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+  m4d_launch(interp_bilinear_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      grid, query, B, H, W, C, N, 0, total, out, index_out);
   return M4D_LAUNCH_RESULT();
 }

@@ -419,10 +419,10 @@ extern "C" int m4d_conv3x3_wgrad(const float* x, const float* g, int b, int h, i
     int n_wg = (int)(items < 2048 ? (items + 3) / 4 : 512);                // <= 512 workgroups = 2048 waves
     if (n_wg < 1) n_wg = 1;
     const int pt = same_pad_before(h, stride), pl = same_pad_before(w, stride);
-    if (cin == 3) hipLaunchKernelGGL((wgrad_thin_kernel<3, 1>), dim3(n_wg), dim3(256), 0, s, x, g, b, h, w, oh, ow, cout, pt, pl, n_wg * 4, workspace);
-    else if (stride == 1) hipLaunchKernelGGL((wgrad_thin_kernel<16, 1>), dim3(n_wg), dim3(256), 0, s, x, g, b, h, w, oh, ow, cout, pt, pl, n_wg * 4, workspace);
-    else hipLaunchKernelGGL((wgrad_thin_kernel<16, 2>), dim3(n_wg), dim3(256), 0, s, x, g, b, h, w, oh, ow, cout, pt, pl, n_wg * 4, workspace);
-    hipLaunchKernelGGL(wgrad_cin3_reduce_kernel, dim3((9 * cin * cout + 63) / 64), dim3(256), 0, s,
+    if (cin == 3) m4d_launch((wgrad_thin_kernel<3, 1>), dim3(n_wg), dim3(256), 0, s, x, g, b, h, w, oh, ow, cout, pt, pl, n_wg * 4, workspace);
+    else if (stride == 1) m4d_launch((wgrad_thin_kernel<16, 1>), dim3(n_wg), dim3(256), 0, s, x, g, b, h, w, oh, ow, cout, pt, pl, n_wg * 4, workspace);
+    else m4d_launch((wgrad_thin_kernel<16, 2>), dim3(n_wg), dim3(256), 0, s, x, g, b, h, w, oh, ow, cout, pt, pl, n_wg * 4, workspace);
+    m4d_launch(wgrad_cin3_reduce_kernel, dim3((9 * cin * cout + 63) / 64), dim3(256), 0, s,
                        (const float*)workspace, n_wg, 9 * cin * cout, dw);
     return M4D_LAUNCH_RESULT();
   }
@@ -450,7 +450,7 @@ extern "C" int m4d_conv3x3_wgrad(const float* x, const float* g, int b, int h, i
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
       attr_set = true;                                                                                                     \
     }                                                                                                                      \
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<S, G, X>), grid, dim3(256), lds, s, a);                                      \
+    m4d_launch((conv3x3_wgrad_kernel<S, G, X>), grid, dim3(256), lds, s, a);                                      \
   } while (0)
   if (stride == 1) {
     if (vg == 4 && vx == 4) M4D_WGRAD_LAUNCH(1, 4, 4);
@@ -464,7 +464,7 @@ extern "C" int m4d_conv3x3_wgrad(const float* x, const float* g, int b, int h, i
   const long long total = (long long)cout * 9 * cin;
   long long gsz = (total + 63) / 64;
   if (gsz > 8192) gsz = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, s, (const float*)workspace, a.slices,
+  m4d_launch(wgrad_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, s, (const float*)workspace, a.slices,
                      a.mblk * 32, a.nblk * 32, cout, cin, dw);
   return M4D_LAUNCH_RESULT();
 }
@@ -479,6 +479,6 @@ extern "C" int m4d_dilate2(const float* g, int b, int oh, int ow, int C, int h, 
   const long long total4 = (long long)b * h * w * (C / 4);
   long long gsz = (total4 + 255) / 256;
   if (gsz > 8192) gsz = 8192;
-  hipLaunchKernelGGL(dilate2_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g, oh, ow, C, h, w, dy, dx, total4, out);
+  m4d_launch(dilate2_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, g, oh, ow, C, h, w, dy, dx, total4, out);
   return M4D_LAUNCH_RESULT();
 }

@@ -275,7 +275,7 @@ template <int NT>
 void launch_wino(const WinoArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)(kHP * kRS + 16 * kNT32 * kRS) * sizeof(float);       // 14.4 + 40 KB
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (a.CoutPad / (32 * NT))), (unsigned)a.b);
-  hipLaunchKernelGGL((conv3x3_wino_kernel<NT>), grid, dim3(256), lds, s, a);
+  m4d_launch((conv3x3_wino_kernel<NT>), grid, dim3(256), lds, s, a);
 }
 
 }  // namespace
@@ -865,10 +865,10 @@ extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, cons
       attr4_set = true;
     }
     const dim3 grid4((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
-    if (a.stamps) hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, grid4, dim3(512), lds4, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, grid4, dim3(512), lds4, (hipStream_t)stream, a);
+    if (a.stamps) m4d_launch(conv3x3_wino4_kernel<true>, grid4, dim3(512), lds4, (hipStream_t)stream, a);
+    else m4d_launch(conv3x3_wino4_kernel<false>, grid4, dim3(512), lds4, (hipStream_t)stream, a);
     return M4D_LAUNCH_RESULT();
   }
-  hipLaunchKernelGGL(conv3x3_wino2_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+  m4d_launch(conv3x3_wino2_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -500,7 +500,7 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
     return true;
   }();                                             // function-local static: initialised once, thread-safe (C++11)
   (void)attr_set;
-  if (a.stamps) hipLaunchKernelGGL(conv3x3_wino6_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(conv3x3_wino6_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, a);
+  if (a.stamps) m4d_launch(conv3x3_wino6_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, a);
+  else m4d_launch(conv3x3_wino6_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -349,6 +349,6 @@ int m4d_wino6h_launch(const float* x, const void* wu6, const float* bias, int b,
   }();
   (void)attr_set;
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
-  hipLaunchKernelGGL(conv3x3_wino6h_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
+  m4d_launch(conv3x3_wino6h_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

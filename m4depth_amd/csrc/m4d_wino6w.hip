@@ -464,12 +464,12 @@ int m4d_wino6w_launch(const float* x, const void* wu6, const float* bias, int b,
 #ifdef M4D_W6W_ABLATIONS
   if (NT == 4 && g_wino6w_ablate) {
 #define M4D_ABL(mask) case mask: { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6w_kernel<4, mask>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      hipLaunchKernelGGL((conv3x3_wino6w_kernel<4, mask>), grid, dim3(512), lds4, (hipStream_t)stream, a); return M4D_LAUNCH_RESULT(); }
+      m4d_launch((conv3x3_wino6w_kernel<4, mask>), grid, dim3(512), lds4, (hipStream_t)stream, a); return M4D_LAUNCH_RESULT(); }
     switch (g_wino6w_ablate) { M4D_ABL(1) M4D_ABL(2) M4D_ABL(4) M4D_ABL(6) M4D_ABL(8) M4D_ABL(16) M4D_ABL(32) M4D_ABL(17) M4D_ABL(23) M4D_ABL(31) M4D_ABL(33) M4D_ABL(38) default: break; }
 #undef M4D_ABL
   }
 #endif
-  if (NT == 3) hipLaunchKernelGGL(conv3x3_wino6w_kernel<3>, grid, dim3(512), lds4, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(conv3x3_wino6w_kernel<4>, grid, dim3(512), lds4, (hipStream_t)stream, a);
+  if (NT == 3) m4d_launch(conv3x3_wino6w_kernel<3>, grid, dim3(512), lds4, (hipStream_t)stream, a);
+  else m4d_launch(conv3x3_wino6w_kernel<4>, grid, dim3(512), lds4, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -1195,3 +1195,170 @@ class GraphedSequence:
             self.weights_stamp = stamp
         self.graph.replay()
         return self.depth
+
+
+class TapedSequence:
+    """The sequence forward as LAUNCH TAPES (csrc/m4d_tape.hip) replayed on real HIP streams -- the (frame, level) wavefront
+    of ``DepthEstimatorPyramid._forward_pipelined`` WITHOUT hipGraph:
+
+        stream 0        enc_a: camera pyramid, encoder batch of frames < split, the reset frame's levels
+        encoder stream  enc_b: encoder batch of the remaining frames
+        stream t        level L, L-1, ... 1 of full frame t, one tape per (frame, level); level l of frame t waits for the
+                        event recorded after level l of frame t - 1 (its temporal memory) and for its encoder batch
+
+    A tape replay costs the host one C loop (~3 us per launch, ~180 launches per 4-frame step) and issues plain stream
+    launches.  Measured (round 3): a chain of small kernels is NOT slowed by chip-filling kernels when
+    both are plain stream launches (340 us against ~700 us as soon as either side is a hipGraph replay;
+    profiles/r03_stream_vs_graph_probe.txt), yet the whole step is 3 % slower this way than as ONE hipGraph (1326-1338 against
+    1379 frames/s): the step is bound by chip-time, not by the chains.  Kept as the graph-free launcher (same kernels in the
+    same per-stream order: bit-identical results, tests/test_gpu_model.py); ``bench.py --schedule tape``."""
+
+    def __init__(self, model, example, warmup=2, encoder_split=None):
+        self.model = model
+        nt = example["new_traj"]
+        self.new_traj = nt.clone() if isinstance(nt, torch.Tensor) else torch.as_tensor(np.asarray(nt))
+        flags = [bool(v) for v in self.new_traj[0].reshape(-1).tolist()]
+        if len(flags) < 2 or not flags[0] or any(flags[1:]):
+            raise ValueError("TapedSequence: expected a sequence that starts with new_traj and continues without")
+        self.static = {k: example[k].clone() for k in ("RGB_im", "rot", "trans")}
+        self.camera = {k: v.clone() for k, v in example["camera"].items()}
+        self.seq_len = T = self.static["RGB_im"].shape[1]
+        self.n_lvls = L = len(model.d_estimator.levels)
+        self.split = min(max(1, pipeline_encoder_split if encoder_split is None else int(encoder_split)), T)
+        model.prepack()
+        self.streams = [torch.cuda.Stream() for _ in range(T)]        # [0]: encoder batch a + reset frame; [t]: full frame t
+        self.s_enc = torch.cuda.Stream()
+        self.ctx = {}
+        segs = [("enc_a", self.streams[0], self._seg_enc_a)]
+        if self.split < T:
+            segs.append(("enc_b", self.s_enc, lambda: self._encode(self.split, T)))
+        for t in range(1, T):
+            for l in range(L):
+                segs.append(((t, l), self.streams[t], lambda t=t, l=l: self._seg_level(t, l)))
+        cur = torch.cuda.current_stream()
+        for _ in range(max(warmup, 1)):                     # eager passes: state, scratch (keyed by stream), packed weights
+            for _, st, fn in segs:
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    fn()
+                torch.cuda.synchronize()
+        self._pools, self.tapes = [], {}
+        import warnings
+        for name, st, fn in segs:
+            # Recorded under a torch graph capture: the library's launches go to the tape, the torch graph stays EMPTY (the
+            # forward launches nothing but libm4depth_hip.so kernels) and only its private memory pool matters -- it pins
+            # the address of every tensor the segment allocates.
+            g = torch.cuda.CUDAGraph()
+            with warnings.catch_warnings():
+                warnings.filterwarnings("ignore", message="The CUDA Graph is empty")
+                with torch.cuda.graph(g, stream=st):
+                    tid = int(lib.m4d_tape_begin())
+                    if tid < 0:
+                        raise RuntimeError("m4d_tape_begin: this thread is already recording a tape")
+                    try:
+                        fn()
+                    finally:
+                        n_rec = int(lib.m4d_tape_end())
+            self._pools.append(g)
+            self.tapes[name] = (tid, n_rec, st)
+        torch.cuda.synchronize()
+        self.depth = self.ctx["depth"]
+        self.weights_stamp = model.weights_stamp()
+        self._ev = {name: torch.cuda.Event() for name in self.tapes}
+        self._ev_start, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+        # issue order: anti-diagonals of the (frame, level) grid, as in DepthEstimatorPyramid._forward_pipelined
+        self._order = [(t, diag - (t - 1)) for diag in range((T - 1) + L - 1)
+                       for t in range(max(1, diag - L + 2), min(T - 1, diag + 1) + 1)]
+
+    def __del__(self):
+        try:
+            for tid, _, _ in self.tapes.values():
+                lib.m4d_tape_free(tid)
+        except Exception:
+            pass
+
+    def launches_per_step(self):
+        return sum(n for _, n, _ in self.tapes.values())
+
+    def _samples(self):
+        nt = torch.unbind(self.new_traj, dim=1)
+        return [{"RGB_im": self.static["RGB_im"][:, t], "rot": self.static["rot"][:, t],
+                 "trans": self.static["trans"][:, t], "new_traj": nt[t]} for t in range(self.seq_len)]
+
+    def _encode(self, a, b):
+        samples = self._samples()
+        bsz = samples[0]["RGB_im"].shape[0]
+        out = self.model.encoder(_stack_frames(samples[a:b]))
+        for j, t in enumerate(range(a, b)):
+            self.ctx[("f", t)] = [lvl[j * bsz:(j + 1) * bsz] for lvl in out]
+
+    def _seg_enc_a(self):
+        self.ctx["cams"] = nops.camera_pyramid(self.camera, self.n_lvls)
+        self._encode(0, self.split)
+        self.ctx[("est", 0)] = []
+        for l in range(self.n_lvls):
+            self._level(0, l)                              # the reset frame: state seeding only
+
+    def _seg_level(self, t, l):
+        if l == 0:
+            self.ctx[("est", t)] = []
+        self._level(t, l)
+        if l == self.n_lvls - 1 and t == self.seq_len - 1:
+            h, w = self.static["RGB_im"].shape[2:4]
+            self.ctx["depth"] = nops.resize_nearest(self.ctx[("est", t)][-1]["depth"], h, w)
+            self.model.last_estimates = [self.ctx[("est", i)][::-1] for i in range(self.seq_len)]
+
+    def _level(self, t, l):
+        """Level l (0 = coarsest) of frame t."""
+        sample = self._samples()[t]
+        ests = self.ctx[("est", t)]
+        lvl = self.n_lvls - 1 - l
+        prev = None if not ests else dict(ests[-1])
+        ests.append(self.model.d_estimator.levels[lvl](self.ctx[("f", t)][lvl], prev, sample["rot"], sample["trans"],
+                                                      self.ctx["cams"][lvl], sample["new_traj"]))
+
+    def input_buffers(self):
+        return dict(self.static, camera=self.camera)
+
+    def _replay(self, name):
+        tid, _, st = self.tapes[name]
+        check(lib.m4d_tape_replay(tid, ctypes.c_void_p(st.cuda_stream)), "m4d_tape_replay")
+        self._ev[name].record(st)
+
+    def __call__(self, data=None):
+        if data is not None:
+            for k in self.static:
+                if tuple(data[k].shape) != tuple(self.static[k].shape):
+                    raise ValueError(f"TapedSequence: {k} has shape {tuple(data[k].shape)}, recorded {tuple(self.static[k].shape)}")
+                if data[k].data_ptr() != self.static[k].data_ptr():
+                    self.static[k].copy_(data[k], non_blocking=True)
+            for k in self.camera:
+                if data["camera"][k].data_ptr() != self.camera[k].data_ptr():
+                    self.camera[k].copy_(data["camera"][k], non_blocking=True)
+        stamp = self.model.weights_stamp()
+        if stamp != self.weights_stamp:
+            if [p for p, _ in stamp] != [p for p, _ in self.weights_stamp]:
+                raise RuntimeError("a convolution parameter was REPLACED after these tapes were recorded: build a new TapedSequence")
+            self.model.prepack()
+            self.weights_stamp = stamp
+        cur = torch.cuda.current_stream()
+        T, ev = self.seq_len, self._ev
+        self._ev_start.record(cur)
+        for st in self.streams + [self.s_enc]:
+            st.wait_event(self._ev_start)
+        self._replay("enc_a")
+        if "enc_b" in self.tapes:
+            self._replay("enc_b")
+        for (t, l) in self._order:
+            st = self.streams[t]
+            if l == 0:
+                st.wait_event(ev["enc_a"])                     # the reset frame's state, the camera pyramid (+ frame t's features)
+                if t >= self.split:
+                    st.wait_event(ev["enc_b"])
+            if t > 1:
+                st.wait_event(ev[(t - 1, l)])
+            self._replay((t, l))
+        self._ev_join.record(self.streams[T - 1])
+        cur.wait_event(self._ev_join)
+        return self.depth
+
