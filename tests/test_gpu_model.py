@@ -396,3 +396,40 @@ def test_main_eval_with_host_resident_input(dev, tmp_path, capsys):
     a = np.loadtxt(tmp_path / "a" / "perfs-synthetic.txt")
     b = np.loadtxt(tmp_path / "b" / "perfs-synthetic.txt")
     assert a.shape == (7,) and np.array_equal(a, b)
+
+
+def test_taped_sequence_is_bitwise_the_graphed_sequence(dev):
+    """network.TapedSequence (launch tapes of libm4depth_hip.so replayed as plain stream launches, one stream per frame)
+    against network.GraphedSequence (one hipGraph) and the eager forward: the same depth bits, stable over replays, new input
+    batches picked up through the static buffers; the recorded tapes hold every launch of the step."""
+    import m4depth_amd as M
+    from m4depth_amd import network as net
+    L, H, Wd, T, b = 4, 96, 160, 4, 2
+    W = S.init_weights(L, seed=12)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=55)
+    samples2, _ = S.make_sequence(b, T, H, Wd, seed=56)
+
+    def batch(smp):
+        d = {k: torch.stack([to_dev(s[k], dev) for s in smp], dim=1) for k in ("depth", "RGB_im", "rot", "trans")}
+        d["new_traj"] = torch.stack([torch.from_numpy(s["new_traj"]) for s in smp], dim=1)
+        d["camera"] = to_dev(cam, dev)
+        return d
+    d1, d2 = batch(samples), batch(samples2)
+    models = [_build(dev, L, 4, 3, W) for _ in range(3)]
+    eager1 = models[0]([to_dev(samples, dev), to_dev(cam, dev)])["depth"].clone()
+    models[0].reset_state()
+    eager2 = models[0]([to_dev(samples2, dev), to_dev(cam, dev)])["depth"].clone()
+    graphed = net.GraphedSequence(models[1], d1)
+    taped = net.TapedSequence(models[2], d1)
+    assert taped.launches_per_step() > 50 and all(n > 0 for _, n, _ in taped.tapes.values())
+    for d, want in ((d1, eager1), (d2, eager2), (d1, eager1)):
+        g = graphed(d).clone()
+        t = taped(d).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(g, want) and torch.equal(t, want)
+    est_t, est_g = models[2].last_estimates, models[1].last_estimates
+    assert len(est_t) == T and all(torch.equal(est_t[-1][l]["parallax"], est_g[-1][l]["parallax"]) for l in range(L))
+    with pytest.raises(ValueError):
+        bad = dict(d1)
+        bad["RGB_im"] = d1["RGB_im"][:, :, :-2]
+        taped(bad)

@@ -56,3 +56,16 @@ def test_cpu_tensor_is_rejected():
     import m4depth_amd as M
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         M.dense_image_warp(torch.zeros(1, 4, 4, 1), torch.zeros(1, 4, 4, 2))
+
+
+def test_launch_tape_bookkeeping_without_gpu():
+    """m4d_tape_begin / _end / _length / _free (csrc/m4d_tape.hip): an empty recording is a valid tape of length 0, nested
+    recordings are refused, unknown ids are errors -- no device involved."""
+    from m4depth_amd._lib import lib
+    t = lib.m4d_tape_begin()
+    assert t >= 0
+    assert lib.m4d_tape_begin() == -1                       # this thread is already recording
+    assert lib.m4d_tape_replay(t, None) != 0                # a tape cannot be replayed while it records
+    assert lib.m4d_tape_end() == 0 and lib.m4d_tape_end() == -1
+    assert lib.m4d_tape_length(t) == 0 and lib.m4d_tape_length(t + 1000) == -1
+    assert lib.m4d_tape_free(t) == 0 and lib.m4d_tape_free(t) != 0 and lib.m4d_tape_length(t) == -1
