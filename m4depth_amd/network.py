@@ -1220,8 +1220,13 @@ class TapedSequence:
         flags = [bool(v) for v in self.new_traj[0].reshape(-1).tolist()]
         if len(flags) < 2 or not flags[0] or any(flags[1:]):
             raise ValueError("TapedSequence: expected a sequence that starts with new_traj and continues without")
-        self.static = {k: example[k].clone() for k in ("RGB_im", "rot", "trans")}
-        self.camera = {k: v.clone() for k, v in example["camera"].items()}
+        # rot / trans are kept frame-major ([T,b,k]) so that a frame's slice is contiguous at every batch size: a non-contiguous
+        # slice would make the level wrappers launch a framework copy kernel, which a tape cannot record.  The batch-major
+        # [b,T,k] views of the same memory are what input_buffers() hands out.
+        self._rot = example["rot"].transpose(0, 1).contiguous()
+        self._trans = example["trans"].transpose(0, 1).contiguous()
+        self.static = {"RGB_im": example["RGB_im"].clone(), "rot": self._rot.transpose(0, 1), "trans": self._trans.transpose(0, 1)}
+        self.camera = {k: v.clone().contiguous() for k, v in example["camera"].items()}
         self.seq_len = T = self.static["RGB_im"].shape[1]
         self.n_lvls = L = len(model.d_estimator.levels)
         self.split = min(max(1, pipeline_encoder_split if encoder_split is None else int(encoder_split)), T)
@@ -1249,8 +1254,8 @@ class TapedSequence:
             # forward launches nothing but libm4depth_hip.so kernels) and only its private memory pool matters -- it pins
             # the address of every tensor the segment allocates.
             g = torch.cuda.CUDAGraph()
-            with warnings.catch_warnings():
-                warnings.filterwarnings("ignore", message="The CUDA Graph is empty")
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
                 with torch.cuda.graph(g, stream=st):
                     tid = int(lib.m4d_tape_begin())
                     if tid < 0:
@@ -1259,6 +1264,11 @@ class TapedSequence:
                         fn()
                     finally:
                         n_rec = int(lib.m4d_tape_end())
+            if not any("CUDA Graph is empty" in str(w.message) for w in caught):
+                # torch captured something: a framework kernel (a copy of a non-contiguous input, a fill) sits in this
+                # segment of the forward and would be missing from the replay
+                raise RuntimeError(f"TapedSequence: segment {name} of the forward launched framework kernels beside "
+                                   "libm4depth_hip.so's; it cannot be replayed from a launch tape (use GraphedSequence)")
             self._pools.append(g)
             self.tapes[name] = (tid, n_rec, st)
         torch.cuda.synchronize()
@@ -1282,8 +1292,8 @@ class TapedSequence:
 
     def _samples(self):
         nt = torch.unbind(self.new_traj, dim=1)
-        return [{"RGB_im": self.static["RGB_im"][:, t], "rot": self.static["rot"][:, t],
-                 "trans": self.static["trans"][:, t], "new_traj": nt[t]} for t in range(self.seq_len)]
+        return [{"RGB_im": self.static["RGB_im"][:, t], "rot": self._rot[t], "trans": self._trans[t], "new_traj": nt[t]}
+                for t in range(self.seq_len)]
 
     def _encode(self, a, b):
         samples = self._samples()
