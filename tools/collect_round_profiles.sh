@@ -55,6 +55,9 @@ done
 # the round-3 Winograd variants (wide / half-tile): per-layer times and bit equality
 timeout 300 python tools/bench_wino6w.py > $OUT/wino6_variants.txt 2>&1; need $OUT/wino6_variants.txt
 timeout 120 ./build_tmp/l2_stream_probe > $OUT/l2_stream_probe.txt 2>&1 || true
+# plain stream launches vs hipGraph replays of small kernels beside chip-filling ones; the graph-free launcher end to end
+timeout 300 python tools/stream_vs_graph_probe.py > $OUT/stream_vs_graph_probe.txt 2>&1; need $OUT/stream_vs_graph_probe.txt
+timeout 600 python bench.py --steps 20 --schedule tape --no-cpu-baseline --no-kernel-timing > $OUT/bench_b1_tape.json 2> $OUT/bench_b1_tape.err; need $OUT/bench_b1_tape.json
 
 timeout 600 python tools/bench_train.py > $OUT/bench_train.json 2>/dev/null; need $OUT/bench_train.json
 head -c 400 $OUT/bench_b1.json; echo
