@@ -435,9 +435,9 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
 
 // Launch for m4d_conv3x3_wino6_bias_act (m4d_wino6.hip decides when): CoutPad == 128, 64 < Cout <= 128, Cout % 4 == 0.
 // profiling builds only (make W6FLAGS=-DM4D_W6W_ABLATIONS; tools/w6w_ablate.py): timing ablations and phase stamps
-static int g_wino6w_ablate = 0;
 static unsigned long long* g_wino6w_stamps = nullptr;
 #ifdef M4D_W6W_ABLATIONS
+static int g_wino6w_ablate = 0;
 extern "C" void m4d_wino6w_set_ablation(int mask) { g_wino6w_ablate = mask; }
 extern "C" void m4d_wino6w_set_stamps(unsigned long long* device_buffer) { g_wino6w_stamps = device_buffer; }
 #endif

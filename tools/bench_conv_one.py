@@ -9,7 +9,11 @@ ap.add_argument("--batch", type=int, default=1); ap.add_argument("--cin", type=i
 ap.add_argument("--cout", type=int, default=128); ap.add_argument("--h", type=int, default=192)
 ap.add_argument("--w", type=int, default=640); ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--winograd", type=int, default=0, help="0 = direct MFMA kernel, 1 / 2 = fp32-MFMA Winograd kernel 1 / 2(4), 6 = the bf16-split Winograd kernel")
+ap.add_argument("--variant", type=int, default=0, help="m4d_wino6_set_variant: 0 / 1 = m4d_wino6.hip, 2 = the wide kernel, 3 = the half-tile kernel")
 a = ap.parse_args()
+if a.variant:
+    from m4depth_amd._lib import lib
+    lib.m4d_wino6_set_variant(a.variant)
 dev = torch.device("cuda:0")
 x = torch.randn(a.batch, a.h, a.w, a.cin, device=dev)
 k = torch.randn(3, 3, a.cin, a.cout) * (2.0 / (9 * a.cin)) ** 0.5
