@@ -179,6 +179,10 @@ void m4d_wino6_set_variant(int variant);
  * serves the launches whose m4d_wino6.hip grid would have at most `max_wg` workgroups (default 0 = none: faster alone on small
  * grids, no gain inside the frame pipeline).  Same bits. */
 void m4d_wino6_set_half_tile_max_workgroups(int max_wg);
+/* Variant 4 = m4d_wino6.hip's kernel with ONE barrier per TWO Winograd positions (fragment DMAs issued in pairs, tighter
+ * waits) everywhere; under variant 0 it serves the launches of at least `min_wg` workgroups (default: never = negative;
+ * 1.03-1.05x per layer alone on chip-filling grids, 0.8 % slower end to end).  Same bits. */
+void m4d_wino6_set_two_position_barrier_min_workgroups(int min_wg);
 
 /* The tail of a level in one kernel: the last two DispRefiner convolutions (32 -> 16 + leaky_relu(0.1), 16 -> 5;
  * m4depth_network.py:109-135) and m4d_level_post (:247-260).  x32 [b,h,w,32]; w6p [9][16][32] = kernel[ky][kx][k][n] as

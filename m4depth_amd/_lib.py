@@ -108,7 +108,8 @@ _LL_SIGNATURES = {"m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_in
 _VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
                     "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp], "m4d_wino_set_stamps": [_c_fp],
                     "m4d_front_set_stamps": [_c_fp], "m4d_wino6_set_stamps": [_c_fp], "m4d_wino6_set_variant": [_c_int],
-                    "m4d_wino6_set_half_tile_max_workgroups": [_c_int]}
+                    "m4d_wino6_set_half_tile_max_workgroups": [_c_int],
+                    "m4d_wino6_set_two_position_barrier_min_workgroups": [_c_int]}
 
 EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES) + list(_VOID_SIGNATURES) + list(_LL_SIGNATURES)
 

@@ -58,6 +58,8 @@ wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
 # m4d_wino6.hip (default), 2 = the wide kernel m4d_wino6w.hip wherever it applies (measured: not faster end to end)
 if _os.environ.get("M4D_WINO6_VARIANT"):
     lib.m4d_wino6_set_variant(int(_os.environ["M4D_WINO6_VARIANT"]))
+if _os.environ.get("M4D_WINO6_BAR2_MIN_WG"):           # grids from this many workgroups on: one barrier per two positions (default: never)
+    lib.m4d_wino6_set_two_position_barrier_min_workgroups(int(_os.environ["M4D_WINO6_BAR2_MIN_WG"]))
 if _os.environ.get("M4D_WINO6_HALF_MAX_WG"):           # grids up to this many workgroups take the half-tile kernel m4d_wino6h.hip (default 0 = none)
     lib.m4d_wino6_set_half_tile_max_workgroups(int(_os.environ["M4D_WINO6_HALF_MAX_WG"]))
 # The one-launch small-map convolution in the same arithmetic (csrc/m4d_conv.hip conv3x3_small6_kernel).  These launches are

@@ -815,6 +815,8 @@ def test_wide_bf16_split_winograd_is_bit_identical(dev, b, h, w, cin, cout):
         wide2 = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
         lib.m4d_wino6_set_variant(3)                # the half-tile kernel (m4d_wino6h.hip): 16x8 pixels x 64 couts per workgroup
         half = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
+        lib.m4d_wino6_set_variant(4)                # m4d_wino6.hip with one barrier per two positions
+        bar2 = [nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1) for _ in range(5)]
         lib.m4d_wino6_set_variant(0)
         lib.m4d_wino6_set_half_tile_max_workgroups(1 << 20)       # ... and through the grid-size rule of the default variant
         half2 = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
@@ -825,6 +827,7 @@ def test_wide_bf16_split_winograd_is_bit_identical(dev, b, h, w, cin, cout):
     assert torch.equal(wide, narrow), f"{int((wide != narrow).sum())} of {narrow.numel()} elements differ"
     assert torch.equal(half, narrow), f"half-tile kernel: {int((half != narrow).sum())} of {narrow.numel()} elements differ"
     assert torch.equal(wide2, wide) and torch.equal(auto, narrow) and torch.equal(half2, half)
+    assert all(torch.equal(o, narrow) for o in bar2), "one barrier per two positions: a race would show as differing repeats"
     ref = O.leaky_relu(O.conv2d_same(npy(x), k, npy(bias), 1), 0.1)
     assert np.max(np.abs(npy(wide) - ref)) < 1e-5 * max(1.0, np.abs(ref).max())
 

@@ -38,7 +38,10 @@ for (h, w, cin, cout) in [(192, 640, 64, 128), (192, 640, 128, 128), (192, 640, 
     else:
         got, t_w = ref, float("nan")
     lib.m4d_wino6_set_variant(3); goth = f6(); t_h = timed(f6, a.iters)
+    lib.m4d_wino6_set_variant(4); gotb = f6(); t_b = timed(f6, a.iters)
+    bad_b = sum(int(not torch.equal(f6(), ref)) for _ in range(30))          # a race in the barrier scheme would show up here
     lib.m4d_wino6_set_variant(0)
     wgs = a.batch * -(-h // 16) * -(-w // 16) * -(-cout // 64)
     print(f"b={a.batch} {h}x{w} {cin:3d}->{cout:3d} ({wgs:4d} wg): 16x16x64 {t_n:7.1f} us   wide {t_w:7.1f} us ({t_n / t_w:.2f}x, same bits {torch.equal(ref, got)})"
-          f"   half-tile {t_h:7.1f} us ({t_n / t_h:.2f}x, same bits {torch.equal(ref, goth)}, differing {int((ref != goth).sum())})", flush=True)
+          f"   half-tile {t_h:7.1f} us ({t_n / t_h:.2f}x, same bits {torch.equal(ref, goth)})"
+          f"   one barrier per two positions {t_b:7.1f} us ({t_n / t_b:.2f}x, same bits {torch.equal(ref, gotb)}, {bad_b} of 30 repeats differ)", flush=True)
