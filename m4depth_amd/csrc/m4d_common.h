@@ -42,6 +42,41 @@ inline void m4d_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t l
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
 }
 
+// ---- exact 3-way bf16 split of a pair of float32 values (m4d_wino6*.hip) ---------------------------------------------------
+// Default (M4D_SPLIT_RN = 1): round to nearest -- hi = bf16(v), mid = bf16(v - hi), lo = (v - hi) - mid (exact, 8 significant
+// bits left: its upper half IS the conversion); 13 VALU instructions per pair, two of them v_cvt_pk_bf16_f32 (8 issue
+// cycles each beside MFMAs, tools/micro/valu_cost.hip); dropped term products <= 2^-26 |a b|.
+// -DM4D_SPLIT_RN=0 builds the split by TRUNCATION: hi = the upper 16 bits of v, r = v - hi exact, mid = the upper 16 bits of
+// r, lo = r - mid exact: 11 plain VALU instructions per pair (-23 % of the operand-generation issue slots); mid / lo are up
+// to 2x / 4x larger, dropped products <= 2^-24 |a b| (weights stay split round-to-nearest on the host, so the dropped terms
+// stay unbiased); every accuracy test passes with it.  Measured (round 3, profiles/r03_split_truncation_ab.txt): the level-1
+// layers 1-2 % faster alone (144.2 -> 140.7 us), end to end nothing (1354 vs 1355 frames/s, 5 interleaved runs each) -- the
+// Winograd kernel is not bound by VALU issue slots alone -- so the more accurate split stays.  Packed words: element 0 in
+// the low half.
+#ifndef M4D_SPLIT_RN
+#define M4D_SPLIT_RN 1
+#endif
+__device__ __forceinline__ void m4d_split3_pair(float v0, float v1, unsigned& hi, unsigned& mid, unsigned& lo) {
+#if M4D_SPLIT_RN
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  bf16x2_t c0; c0[0] = (__bf16)v0; c0[1] = (__bf16)v1;
+  const unsigned q0 = __builtin_bit_cast(unsigned, c0);
+  const float r0 = v0 - __builtin_bit_cast(float, q0 << 16), r1 = v1 - __builtin_bit_cast(float, q0 & 0xffff0000u);
+  bf16x2_t c1; c1[0] = (__bf16)r0; c1[1] = (__bf16)r1;
+  const unsigned q1 = __builtin_bit_cast(unsigned, c1);
+  const float s0 = r0 - __builtin_bit_cast(float, q1 << 16), s1 = r1 - __builtin_bit_cast(float, q1 & 0xffff0000u);
+  hi = q0; mid = q1;
+#else
+  const unsigned u0 = __builtin_bit_cast(unsigned, v0), u1 = __builtin_bit_cast(unsigned, v1);
+  hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  const float r0 = v0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = v1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+  const unsigned w0 = __builtin_bit_cast(unsigned, r0), w1 = __builtin_bit_cast(unsigned, r1);
+  mid = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+  const float s0 = r0 - __builtin_bit_cast(float, w0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, w1 & 0xffff0000u);
+#endif
+  lo = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+}
+
 // Per-sample camera motion: rotation matrix (get_rot_mat, utils/depth_operations.py:18-53),
 // translation scaled by the focal lengths, level-local intrinsics.
 struct M4dMotion {

@@ -183,13 +183,9 @@ conv3x3_wino6_kernel(const Wino6Args a) {
       const int ch = 2 * e + h;
       v[h] = c == 0 ? tv[0][ch] - tv[2][ch] : c == 1 ? tv[1][ch] + tv[2][ch] : c == 2 ? tv[2][ch] - tv[1][ch] : tv[1][ch] - tv[3][ch];
     }
-    const unsigned q0 = pk_bf16(v[0], v[1]);
-    const float r0 = v[0] - lo_f32(q0), r1 = v[1] - hi_f32(q0);
-    const unsigned q1 = pk_bf16(r0, r1);
-    const float s0 = r0 - lo_f32(q1), s1 = r1 - hi_f32(q1);
-    // s0, s1 are exactly bf16 numbers (8 significant bits left): their upper halves ARE the conversion -- v_perm_b32 (4
-    // cycles) instead of a third v_cvt_pk_bf16_f32 (8 cycles beside MFMAs, tools/micro/valu_cost.hip)
-    A[0][e] = q0; A[1][e] = q1; A[2][e] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+    unsigned p_hi, p_mid, p_lo;
+    m4d_split3_pair(v[0], v[1], p_hi, p_mid, p_lo);                            // m4d_common.h
+    A[0][e] = p_hi; A[1][e] = p_mid; A[2][e] = p_lo;
   };
 
   // ---- B operands: wu[chunk][N-group][16 positions][2 N-tiles][3 parts][64 lanes][8 bf16]; a position row walks its 4

@@ -149,12 +149,9 @@ conv3x3_wino6w_kernel(const W6wArgs a) {
   auto gen_pair = [&](int e, u32x4 (&A)[3]) {
     const float v0 = __builtin_fmaf(csgn, tv[1][2 * e], tv[0][2 * e]);
     const float v1 = __builtin_fmaf(csgn, tv[1][2 * e + 1], tv[0][2 * e + 1]);
-    const unsigned q0 = pk_bf16(v0, v1);
-    const float r0 = v0 - lo_f32(q0), r1 = v1 - hi_f32(q0);
-    const unsigned q1 = pk_bf16(r0, r1);
-    const float s0 = r0 - lo_f32(q1), s1 = r1 - hi_f32(q1);
-    A[0][e] = q0; A[1][e] = q1;
-    A[2][e] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+    unsigned p_hi, p_mid, p_lo;
+    m4d_split3_pair(v0, v1, p_hi, p_mid, p_lo);                            // m4d_common.h
+    A[0][e] = p_hi; A[1][e] = p_mid; A[2][e] = p_lo;
   };
 
   // ---- B fragments: wu[chunk][CoutPad / 64][16 positions][2 N-tiles][3 parts][64 lanes][8 bf16] (pack_conv_weights_wino6)
