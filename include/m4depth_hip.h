@@ -191,6 +191,15 @@ int m4d_refiner_tail(const float* x32, const float* w6p, const float* b6, const 
                      const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
                      int b, int h, int w, float scale, float* parallax, float* depth, float* other,
                      float* depth_state, void* stream);
+/* The same tail with float32 operands split exactly into three bf16 terms on the bf16 matrix cores (csrc/m4d_tail6.hip; the
+ * arithmetic of m4d_conv3x3_wino6_bias_act), persistent workgroups over 14x10-pixel tiles.  w6f / w7f = the B fragments of
+ * network_ops.pack_refiner_tail_weights6: [9 taps][3 parts][64 lanes][8 bf16] with lane = (k-quarter, cout) holding input
+ * channels 8 kq .. 8 kq + 7, and [5 K-steps][3 parts][4 k-quarters][8 couts][8 bf16] with k-quarter kq holding channels
+ * 8 (kq & 1) .. + 7 of tap 2 j + (kq >> 1) (zeros for the tenth tap and couts 5..7). */
+int m4d_refiner_tail6(const float* x32, const void* w6f, const float* b6, const void* w7f, const float* b7,
+                      const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
+                      int b, int h, int w, float scale, float* parallax, float* depth, float* other,
+                      float* depth_state, void* stream);
 
 /* ---- gradients of the cost volumes (train_step, m4depth_network.py:371-399) ------ */
 

@@ -81,6 +81,8 @@ _SIGNATURES = {
                                     _c_f, _c_fp, _c_fp],
     "m4d_refiner_tail": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
                          _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
+    "m4d_refiner_tail6": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
+                          _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "m4d_depth_metrics": [_c_fp, _c_fp, ctypes.c_longlong, _c_f, _c_fp, _c_fp, _c_fp, _c_f, _c_fp, _c_fp],
     "m4d_level_pre": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int,
                       _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],

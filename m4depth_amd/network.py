@@ -69,6 +69,10 @@ _small_conv_split_env = _os.environ.get("M4D_SMALL_CONV_SPLIT", "1") == "1"
 small_conv_split = _small_conv_split_env and conv_arith == "bf16x3"
 
 
+# The fused level tail (conv 32->16, conv 16->5, level_post) in the same bf16-split arithmetic (csrc/m4d_tail6.hip) when
+# conv_arith is "bf16x3"; 0 = the fp32-MFMA tail (csrc/m4d_tail.hip) always.
+tail_split = _os.environ.get("M4D_TAIL_SPLIT", "1") == "1"
+
 import contextlib as _contextlib
 
 
@@ -541,16 +545,25 @@ class DepthEstimatorLevel(torch.nn.Module):
         self.depth_prev_t = None
         self._spare_f = None
 
-    def _tail_weights(self, convs):
-        """Packed weights of the fused level tail (conv 32->16, conv 16->5), built once per device."""
+    def _tail_weights(self, convs, split=False):
+        """Packed weights of the fused level tail (conv 32->16, conv 16->5), built once per device: the fp32-MFMA kernel's
+        (m4d_refiner_tail) or, ``split``, the bf16-split kernel's B fragments (m4d_refiner_tail6)."""
         def build():
             k6 = convs[5].weight.detach().permute(2, 3, 1, 0).cpu().numpy()
             k7 = convs[6].weight.detach().permute(2, 3, 1, 0).cpu().numpy()
             w6, w7 = nops.pack_refiner_tail_weights(k6, k7)
             dev = convs[5].weight.device
             return torch.from_numpy(w6).to(dev), torch.from_numpy(w7).to(dev)
+        def build6():
+            k6 = convs[5].weight.detach().permute(2, 3, 1, 0).cpu().numpy()
+            k7 = convs[6].weight.detach().permute(2, 3, 1, 0).cpu().numpy()
+            w6, w7 = nops.pack_refiner_tail_weights6(k6, k7)
+            dev = convs[5].weight.device
+            return torch.from_numpy(w6.view("int16")).to(dev), torch.from_numpy(w7.view("int16")).to(dev)
         if getattr(self, "_tail_cache", None) is None:
             self._tail_cache = _PackCache()
+        if split:
+            return self._tail_cache.get("tail6", _stamp(convs[5].weight, convs[6].weight), build6)
         return self._tail_cache.get("tail", _stamp(convs[5].weight, convs[6].weight), build)
 
     def _vector_processing(self, f_map, out=None):
@@ -676,8 +689,10 @@ class DepthEstimatorLevel(torch.nn.Module):
             x = f_input
             for conv in convs[:5]:
                 x = conv(x, slope=0.1)
-            w6p, w7p = self._tail_weights(convs)
-            para_curr_l, depth, other = _timed("tail", self.lvl_depth, lambda: nops.refiner_tail(
+            split = tail_split and conv_arith == "bf16x3"
+            w6p, w7p = self._tail_weights(convs, split)
+            tail_fn = nops.refiner_tail6 if split else nops.refiner_tail
+            para_curr_l, depth, other = _timed("tail", self.lvl_depth, lambda: tail_fn(
                 x, w6p, convs[5].bias, w7p, convs[6].bias, rot_t, tr, {"f": cf, "c": cc}, scale,
                 depth_state=self.depth_prev_t if not self.is_training else None))
         else:
@@ -908,7 +923,7 @@ class M4Depth(torch.nn.Module):
                     c0._packed_weights_wino6(cin_pad)
             if len(convs) == 7 and convs[5].weight is not None and convs[5].weight.is_cuda \
                     and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16):
-                lvl._tail_weights(convs)
+                lvl._tail_weights(convs, tail_split and conv_arith == "bf16x3")
         return self
 
     def invalidate_packed(self):

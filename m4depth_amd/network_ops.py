@@ -474,6 +474,45 @@ def pack_refiner_tail_weights(k6_hwio, k7_hwio):
     return w6, w7
 
 
+def pack_refiner_tail_weights6(k6_hwio, k7_hwio):
+    """Weights of the bf16-split fused level tail (m4d_refiner_tail6) as MFMA B fragments, every weight split exactly into
+    three bf16 terms: conv6 [3,3,32,16] -> [9 taps][3 parts][64 lanes = (k-quarter, cout)][8 channels 8 kq .. 8 kq + 7];
+    conv7 [3,3,16,5] -> [5 K-steps][3 parts][4 k-quarters][8 couts][8]: k-quarter kq = channels 8 (kq & 1) .. + 7 of tap
+    2 j + (kq >> 1), zeros for the tenth tap and couts 5..7.  numpy in, numpy uint16 out."""
+    import numpy as np
+    k6 = np.asarray(k6_hwio, np.float32)
+    k7 = np.asarray(k7_hwio, np.float32)
+    assert k6.shape == (3, 3, 32, 16) and k7.shape == (3, 3, 16, 5), (k6.shape, k7.shape)
+    p6 = split_bf16x3(k6.reshape(9, 4, 8, 16))                      # part, tap, kq, e, n
+    w6 = np.ascontiguousarray(p6.transpose(1, 0, 2, 4, 3)).reshape(9, 3, 64, 8)        # tap, part, (kq, n), e
+    full7 = np.zeros((10, 16, 8), np.float32)
+    full7[:9, :, :5] = k7.reshape(9, 16, 5)
+    p7 = split_bf16x3(full7.reshape(5, 2, 2, 8, 8))                 # part, j, tap parity, channel half, e, n
+    w7 = np.ascontiguousarray(p7.transpose(1, 0, 2, 3, 5, 4)).reshape(5, 3, 4, 8, 8)   # j, part, kq = (parity, half), n, e
+    return w6, w7
+
+
+def refiner_tail6(x32, w6f, b6, w7f, b7, rot, trans, camera, scale, depth_state=None):
+    """refiner_tail with float32 operands split into three bf16 terms on the bf16 matrix cores (csrc/m4d_tail6.hip);
+    w6f / w7f from pack_refiner_tail_weights6 (int16 views on the device)."""
+    x = as_f32(x32, "x32")
+    b, h, w, c = x.shape
+    if c != 32:
+        raise ValueError(f"refiner_tail6 expects the 32-channel refiner activation, got {c} channels")
+    rot = as_f32(rot, "rot")
+    tr = as_f32(trans, "trans").reshape(b, 3)
+    f = as_f32(camera["f"], "camera['f']").reshape(b, 2)
+    cc = as_f32(camera["c"], "camera['c']").reshape(b, 2)
+    para = torch.empty((b, h, w, 1), dtype=torch.float32, device=x.device)
+    depth = torch.empty_like(para)
+    other = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
+    check(lib.m4d_refiner_tail6(dptr(x, "x32"), dptr(w6f, "w6f", torch.int16), dptr(b6, "b6"), dptr(w7f, "w7f", torch.int16),
+                                dptr(b7, "b7"), dptr(rot, "rot"), rot.shape[1], dptr(tr), dptr(f), dptr(cc), b, h, w, float(scale),
+                                dptr(para), dptr(depth), dptr(other), dptr(depth_state, "depth_state"), stream_ptr()),
+          "m4d_refiner_tail6")
+    return para, depth, other
+
+
 def refiner_tail(x32, w6p, b6, w7p, b7, rot, trans, camera, scale, depth_state=None):
     """conv(32->16)+lrelu, conv(16->5) and the level tail (level_post) in one launch: returns (parallax, depth, other)."""
     x = as_f32(x32, "x32")

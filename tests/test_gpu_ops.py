@@ -475,10 +475,14 @@ def test_small_map_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
     assert torch.equal(got, nops.conv3x3_small6_bias_act(xd, wd, bd, cout, cpad, slope))
 
 
-@pytest.mark.parametrize("b,h,w,quat", [(2, 24, 40, True), (1, 37, 53, False), (1, 6, 20, True)])
-def test_fused_refiner_tail(M, dev, b, h, w, quat):
-    """conv(32->16)+lrelu, conv(16->5) and the level tail in one kernel vs the oracle's two convolutions + the oracle's
-    exp/clip/parallax2depth: refiner output within 1e-5, parallax 2e-6 relative (expf), depth through its conditioning."""
+@pytest.mark.parametrize("kernel", ["f32", "bf16x3"])
+@pytest.mark.parametrize("b,h,w,quat", [(2, 24, 40, True), (1, 37, 53, False), (1, 6, 20, True), (3, 96, 320, True), (1, 10, 14, True),
+                                        (1, 11, 15, False), (1, 3, 5, True)])
+def test_fused_refiner_tail(M, dev, b, h, w, quat, kernel):
+    """conv(32->16)+lrelu, conv(16->5) and the level tail in one kernel -- on the fp32 matrix cores (m4d_tail.hip) and in the
+    bf16-split arithmetic with persistent workgroups (m4d_tail6.hip) -- vs the oracle's two convolutions + the oracle's
+    exp/clip/parallax2depth: refiner output within 1e-5, parallax 3e-5 relative (exp of a value known to 1e-5), depth =
+    parallax2depth(parallax) bit for bit; ragged tiles, maps smaller than one tile, more tiles than workgroups, batch."""
     from m4depth_amd import network_ops as nops
     rng = np.random.default_rng(h * w)
     x = np.maximum(rng.standard_normal([b, h, w, 32]), -0.3).astype(F)
@@ -493,15 +497,32 @@ def test_fused_refiner_tail(M, dev, b, h, w, quat):
     mid = np.where(mid > 0, mid, mid * F(0.1)).astype(F)
     out5 = O.conv2d_same(mid, k7, b7, 1)
     para_ref = (np.exp(np.clip(out5[..., :1], F(-7), F(7))) / scale).astype(F)
-    w6, w7 = nops.pack_refiner_tail_weights(k6, k7)
     state = torch.zeros((b, h, w, 1), device=dev)
-    para, depth, other = nops.refiner_tail(to_dev(x, dev), to_dev(w6, dev), to_dev(b6, dev), to_dev(w7, dev), to_dev(b7, dev),
-                                           to_dev(rot, dev), to_dev(trans, dev), to_dev(cam, dev), float(scale), depth_state=state)
+    if kernel == "f32":
+        w6, w7 = nops.pack_refiner_tail_weights(k6, k7)
+        call = lambda: nops.refiner_tail(to_dev(x, dev), to_dev(w6, dev), to_dev(b6, dev), to_dev(w7, dev), to_dev(b7, dev),
+                                         to_dev(rot, dev), to_dev(trans, dev), to_dev(cam, dev), float(scale), depth_state=state)
+    else:
+        w6, w7 = nops.pack_refiner_tail_weights6(k6, k7)
+        w6d, w7d = torch.from_numpy(w6.view(np.int16)).to(dev), torch.from_numpy(w7.view(np.int16)).to(dev)
+        call = lambda: nops.refiner_tail6(to_dev(x, dev), w6d, to_dev(b6, dev), w7d, to_dev(b7, dev),
+                                          to_dev(rot, dev), to_dev(trans, dev), to_dev(cam, dev), float(scale), depth_state=state)
+    para, depth, other = call()
     assert np.max(np.abs(npy(other) - out5[..., 1:])) < 1e-5 * max(1.0, np.abs(out5).max())
     assert rel_err(npy(para), para_ref).max() < 3e-5                      # exp of a value known to 1e-5
     depth_from_gpu_para = O.parallax2depth(npy(para), rot, trans, cam)    # the converter itself is bit-exact elsewhere
     assert_bits_equal(npy(depth), depth_from_gpu_para, "depth = parallax2depth(parallax)")
     assert torch.equal(state, depth)
+    para2, depth2, other2 = call()                                        # deterministic
+    assert torch.equal(para, para2) and torch.equal(depth, depth2) and torch.equal(other, other2)
+    with O.float64_reference():                                           # error to float64: the class of the float32 oracle
+        mid64 = O.conv2d_same(x.astype(np.float64), k6.astype(np.float64), b6.astype(np.float64), 1)
+        mid64 = np.where(mid64 > 0, mid64, mid64 * 0.1)
+        out64 = O.conv2d_same(mid64, k7.astype(np.float64), b7.astype(np.float64), 1)
+    e_gpu = np.abs(npy(other).astype(np.float64) - out64[..., 1:]).mean()
+    e_oracle = np.abs(out5[..., 1:].astype(np.float64) - out64[..., 1:]).mean()
+    print(f"tail {kernel} {b}x{h}x{w}: mean |error| to float64 {e_gpu:.3e} (float32 oracle {e_oracle:.3e})")
+    assert e_gpu <= 3.0 * e_oracle + 1e-9
 
 
 def _trained_legacy_encoder_weights():

@@ -202,6 +202,25 @@ def test_small6_pack_layout():
     assert not full[:, cin:].any() and not full[:, :, cout:].any()
 
 
+def test_refiner_tail6_pack_layout():
+    """pack_refiner_tail_weights6: the MFMA B fragments of the bf16-split level tail (csrc/m4d_tail6.hip).  conv6: lane
+    (k-quarter kq, cout n) of tap t holds channels 8 kq .. 8 kq + 7; conv7: K-step j, k-quarter kq holds channels
+    8 (kq & 1) .. + 7 of tap 2 j + (kq >> 1); the three parts sum exactly to the weight, the tenth tap and couts 5..7 are zero."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(23)
+    k6 = rng.standard_normal([3, 3, 32, 16]).astype(F)
+    k7 = rng.standard_normal([3, 3, 16, 5]).astype(F)
+    w6, w7 = nops.pack_refiner_tail_weights6(k6, k7)
+    assert w6.shape == (9, 3, 64, 8) and w7.shape == (5, 3, 4, 8, 8) and w6.dtype == np.uint16 and w7.dtype == np.uint16
+    widen = lambda u: (u.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    r6 = widen(w6).sum(1).reshape(9, 4, 16, 8)                                        # [tap, kq, n, e]
+    assert np.array_equal(r6.transpose(0, 1, 3, 2).reshape(9, 32, 16), k6.reshape(9, 32, 16).astype(np.float64))
+    r7 = widen(w7).sum(1).reshape(5, 2, 2, 8, 8)                                      # [j, tap parity, channel half, n, e]
+    full = r7.transpose(0, 1, 2, 4, 3).reshape(10, 16, 8)                             # [tap, channel, n]
+    assert np.array_equal(full[:9, :, :5], k7.reshape(9, 16, 5).astype(np.float64))
+    assert not full[9].any() and not full[:, :, 5:].any()
+
+
 def test_convolution_dispatch_at_the_bench_pyramid():
     """network._use_winograd at the 384x1280 / 6-level pyramid, batch 1: which kernel family every refiner layer shape gets
     (6 = bf16-split Winograd, 2 = fp32-MFMA Winograd kernel 2 / 4, 0 = direct or small-map convolution) -- the dispatch the
