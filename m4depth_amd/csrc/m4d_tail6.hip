@@ -38,7 +38,7 @@ struct Tail6Args {
 
 constexpr int kTW = 14, kTH = 10;                                // output tile
 constexpr int kXW = kTW + 4, kXH = kTH + 4, kXP = kXW * kXH;     // input halo 18 x 14 = 252 pixels
-constexpr int kMW = kTW + 2, kMH = kTH + 2;                      // conv6 ring 16 x 12 positions
+constexpr int kMW = kTW + 2;                                     // conv6 ring: 16 wide (one M-tile per ring row) x 12 rows
 constexpr int kXPlane = 254 * 32;                                // bytes per (part, channel half) plane: 2032 dwords = 16 mod 32 (ds_write_b64 groups)
 constexpr int kXPart = 2 * kXPlane;
 constexpr int kMPart = 196 * 32;                                 // conv6 output: [part][position (192 + conv7's over-read)][2 x 16 B]

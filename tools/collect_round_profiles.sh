@@ -52,6 +52,11 @@ for B in 1 32; do
   need $OUT/roofline_layer_b${B}_rocprof_durations.txt $OUT/roofline_layer_b${B}_hip_events.txt
 done
 
+# the level tail: fp32-MFMA kernel (m4d_tail.hip) against the bf16-split persistent kernel (m4d_tail6.hip), graph-replayed launches
+{ for SZ in "" "--batch 32" "--h 96 --w 320" "--h 48 --w 160" "--h 12 --w 40"; do
+    timeout 120 python tools/bench_tail.py --iters 100 $SZ 2>&1 | grep "^refiner"; timeout 120 python tools/bench_tail.py --iters 100 $SZ --split 2>&1 | grep "^refiner"; done; } > $OUT/refiner_tail_split_vs_fp32.txt
+need $OUT/refiner_tail_split_vs_fp32.txt
+
 # the round-3 Winograd variants (wide / half-tile): per-layer times and bit equality
 timeout 300 python tools/bench_wino6w.py > $OUT/wino6_variants.txt 2>&1; need $OUT/wino6_variants.txt
 timeout 120 ./build_tmp/l2_stream_probe > $OUT/l2_stream_probe.txt 2>&1 || true
