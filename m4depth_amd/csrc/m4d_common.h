@@ -52,7 +52,8 @@ inline void m4d_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t l
 // stay unbiased); every accuracy test passes with it.  Measured (round 3, profiles/r03_split_truncation_ab.txt): the level-1
 // layers 1-2 % faster alone (144.2 -> 140.7 us), end to end nothing (1354 vs 1355 frames/s, 5 interleaved runs each) -- the
 // Winograd kernel is not bound by VALU issue slots alone -- so the more accurate split stays.  Packed words: element 0 in
-// the low half.
+// the low half.  A non-finite value has no split (Inf - Inf): the products it enters come out NaN, where float32 arithmetic
+// would have kept an Inf -- the host-side weight splitter refuses non-finite weights (network_ops.split_bf16x3).
 #ifndef M4D_SPLIT_RN
 #define M4D_SPLIT_RN 1
 #endif
