@@ -48,6 +48,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak (= fp32 vector peak), MI355X_MICROARCH.md
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity), MI355X_MICROARCH.md
+# What a bare register-only loop of v_mfma_f32_32x32x16_bf16 sustains on this pool with NON-trivial operand values, every CU
+# busy (tools/micro/mfma_operand_variety.hip, profiles/r03_mfma_rate_vs_operand_values.txt: 20.5 ns per MFMA and SIMD on
+# pseudo-random operands against 13.7-15.0 ns on all-ones -- the nominal rate is only reached on trivial data)
+BF16_MFMA_SUSTAINED_TFLOPS = round(1024 * 32768 / 20.5e-9 / 1e12, 0)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 HOT_KERNELS = ("pre", "front", "dscv", "sncv", "dscv_sncv", "tail", "post", "resize")     # network._timed names of the hot path
 
@@ -460,6 +464,8 @@ def main():
                 "pmc_mfma_busy_frac": None if key not in traffic else traffic[key].get("mfma_busy_frac"),
                 "traffic_kernel": None if key not in traffic else traffic[key].get("kernel"),
                 "executed_mfma_flops_per_launch": flops_exec,
+                "frac_of_sustained_mfma_rate": round(tf_exec / BF16_MFMA_SUSTAINED_TFLOPS, 4) if wino == 6 else None,
+                "sustained_mfma_tflops_on_random_operands": BF16_MFMA_SUSTAINED_TFLOPS if wino == 6 else None,
                 "note": "achieved / frac = MFMA flops the kernel executes / time against the dense peak of the MFMA type it issues "
                         "(bf16 2500 TFLOP/s for the split kernel: 6 bf16 products per float32 multiply-add of the Winograd form, "
                         "2*16*Cin*Cout per 2x2 output tile; fp32 MFMA 157.3 otherwise).  The split kernel is balanced between the "

@@ -31,6 +31,10 @@
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
 
+#ifndef M4D_W6_ABL
+#define M4D_W6_ABL 0       // timing ablations of the K loop (wrong results; tools/w6_ablate.sh): 1 no barrier, 2 no fragment DMA,
+#endif                     // 4 no raw-halo DMA, 8 no fragment LDS reads, 16 no A-operand generation, 32 no DMA waits
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -209,6 +213,8 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   auto frag = [&](int slot, int nt, int part) {
     return *reinterpret_cast<const bf16x8*>(bring_p + slot * 6144 + (nt * 3 + part) * 1024 + bl);
   };
+  auto frag_l = [&](bf16x8& dst, int slot, int nt, int part) { if (!(M4D_W6_ABL & 8)) dst = frag(slot, nt, part); };
+  auto gen_l = [&](int c, int e, u32x4 (&A)[3]) { if (!(M4D_W6_ABL & 16)) gen_pair(c, e, A); };
 #define M4D_W6_WAIT(nn) asm volatile("s_waitcnt vmcnt(" #nn ") lgkmcnt(0)" ::: "memory")
 
   f32x16 acc[4][2];
@@ -284,22 +290,22 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // soon as the part's last MFMA is issued (lo after block 0, mid after block 1); the hi part, needed until the end, is
   // double buffered.
 #define M4D_W6_BLOCK0(c, cn, next_slot, valu)                                                                          \
-  B0[((c) & 1) ^ 1][0] = frag(next_slot, 0, 0); B0[((c) & 1) ^ 1][1] = frag(next_slot, 1, 0);                          \
-  gen_pair(cn, 0, A[((c) & 1) ^ 1]); gen_pair(cn, 1, A[((c) & 1) ^ 1]);                                                \
+  frag_l(B0[((c) & 1) ^ 1][0], next_slot, 0, 0); frag_l(B0[((c) & 1) ^ 1][1], next_slot, 1, 0);                          \
+  gen_l(cn, 0, A[((c) & 1) ^ 1]); gen_l(cn, 1, A[((c) & 1) ^ 1]);                                                \
   M4D_W6_MFMA(c, 0, B2) M4D_W6_MFMA(c, 2, B0[(c) & 1])                                                                 \
   asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][0]), "+v"(A[((c) & 1) ^ 1][0][1]));                                       \
   M4D_W6_PIPE(4, valu)                                                                                                 \
   __builtin_amdgcn_sched_barrier(0);
 #define M4D_W6_BLOCK1(c, cn, next_slot, valu)                                                                          \
-  B2[0] = frag(next_slot, 0, 2); B2[1] = frag(next_slot, 1, 2);                                                        \
-  gen_pair(cn, 2, A[((c) & 1) ^ 1]);                                                                                   \
+  frag_l(B2[0], next_slot, 0, 2); frag_l(B2[1], next_slot, 1, 2);                                                        \
+  gen_l(cn, 2, A[((c) & 1) ^ 1]);                                                                                   \
   M4D_W6_MFMA(c, 1, B1) M4D_W6_MFMA(c, 0, B1)                                                                          \
   asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][2]));                                                                     \
   M4D_W6_PIPE(4, valu)                                                                                                 \
   __builtin_amdgcn_sched_barrier(0);
 #define M4D_W6_BLOCK2(c, cn, next_slot, valu)                                                                          \
-  B1[0] = frag(next_slot, 0, 1); B1[1] = frag(next_slot, 1, 1);                                                        \
-  gen_pair(cn, 3, A[((c) & 1) ^ 1]);                                                                                   \
+  frag_l(B1[0], next_slot, 0, 1); frag_l(B1[1], next_slot, 1, 1);                                                        \
+  gen_l(cn, 3, A[((c) & 1) ^ 1]);                                                                                   \
   M4D_W6_MFMA(c, 1, B0[(c) & 1]) M4D_W6_MFMA(c, 0, B0[(c) & 1])                                                        \
   pin_a(A[((c) & 1) ^ 1]);                                                                                             \
   M4D_W6_PIPE(4, valu)                                                                                                 \
@@ -314,61 +320,65 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   if constexpr (BAR2) { M4D_W6_WAIT(0); }          // raw(1) and B(2) of both waves land before position 0's barrier publishes them
   int stq = 0;
 #define M4D_W6_STAMP(k) if (STAMPS && st && stq < 32) st[stq * 4 + (k)] = __builtin_readcyclecounter();
+#define W6L_BARRIER() do { if (!(M4D_W6_ABL & 1)) __builtin_amdgcn_s_barrier(); } while (0)
+#define W6L_RAW(...) do { if (!(M4D_W6_ABL & 4)) raw_dma(__VA_ARGS__); } while (0)
+#define W6L_BDMA(...) do { if (!(M4D_W6_ABL & 2)) b_dma(__VA_ARGS__); } while (0)
+#define W6L_WAIT(nn) do { if (!(M4D_W6_ABL & 32)) { M4D_W6_WAIT(nn); } } while (0)
   for (int chunk = 0; chunk < n; ++chunk) {
     const unsigned char* wn = chunk < last ? wc + w_chunk : wc;                   // scalar select: B of the next chunk
     const int rnext_c = min(chunk + 2, last);
     const float4* rnext = raw + ((chunk + 1) & 1) * kRawSlots;
     // position 0: A(1) from t1, t2
-    __builtin_amdgcn_s_barrier();
+    W6L_BARRIER();
     M4D_W6_STAMP(0)
     M4D_W6_BLOCK0(0, 1, 1, 7)
-    raw_dma(rnext_c, chunk & 1, 0);
+    W6L_RAW(rnext_c, chunk & 1, 0);
     M4D_W6_BLOCK1(0, 1, 1, 4)
-    b_dma(wn, 0);
-    if constexpr (BAR2) b_dma(wc + 3 * w_pos, 3);                                 // position 3 of THIS chunk (slot 3 is free)
+    W6L_BDMA(wn, 0);
+    if constexpr (BAR2) W6L_BDMA(wc + 3 * w_pos, 3);                                 // position 3 of THIS chunk (slot 3 is free)
     M4D_W6_BLOCK2(0, 1, 1, 4)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2) { M4D_W6_WAIT(7); } else { M4D_W6_WAIT(7); }
+    if constexpr (BAR2) { W6L_WAIT(7); } else { W6L_WAIT(7); }
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 1: A(2) from t2, t1
-    if constexpr (!BAR2) __builtin_amdgcn_s_barrier();
+    if constexpr (!BAR2) W6L_BARRIER();
     M4D_W6_STAMP(0)
     M4D_W6_BLOCK0(1, 2, 2, 7)
-    raw_dma(rnext_c, chunk & 1, 1);
+    W6L_RAW(rnext_c, chunk & 1, 1);
     M4D_W6_BLOCK1(1, 2, 2, 4)
-    if constexpr (!BAR2) b_dma(wn + w_pos, 1);
+    if constexpr (!BAR2) W6L_BDMA(wn + w_pos, 1);
     M4D_W6_BLOCK2(1, 2, 2, 4)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2) { M4D_W6_WAIT(1); } else { M4D_W6_WAIT(8); }
+    if constexpr (BAR2) { W6L_WAIT(1); } else { W6L_WAIT(8); }
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 2: A(3) from t1, t3; columns 0, 2 of t(chunk + 1)
-    __builtin_amdgcn_s_barrier();
+    W6L_BARRIER();
     M4D_W6_STAMP(0)
     M4D_W6_BLOCK0(2, 3, 3, 7)
-    raw_dma(rnext_c, chunk & 1, 2);
+    W6L_RAW(rnext_c, chunk & 1, 2);
     read_t(rnext, 0);
     M4D_W6_BLOCK1(2, 3, 3, 6)
-    b_dma(wn + 2 * w_pos, 2);
-    if constexpr (BAR2) b_dma(wn + w_pos, 1);                                     // position 1 of the next chunk (slot 1 is free)
+    W6L_BDMA(wn + 2 * w_pos, 2);
+    if constexpr (BAR2) W6L_BDMA(wn + w_pos, 1);                                     // position 1 of the next chunk (slot 1 is free)
     pin_t(0);
     M4D_W6_BLOCK2(2, 3, 3, 6)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2) { M4D_W6_WAIT(7); } else { M4D_W6_WAIT(8); }
+    if constexpr (BAR2) { W6L_WAIT(7); } else { W6L_WAIT(8); }
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 3: columns 1, 3 of t(chunk + 1) first (A(chunk + 1, 0) = t0 - t2 needs column ... 0 and 2 only)
-    if constexpr (!BAR2) __builtin_amdgcn_s_barrier();
+    if constexpr (!BAR2) W6L_BARRIER();
     M4D_W6_STAMP(0)
     M4D_W6_BLOCK0(3, 0, 0, 7)
     read_t(rnext, 1);
     M4D_W6_BLOCK1(3, 0, 0, 6)
-    if constexpr (!BAR2) b_dma(wn + 3 * w_pos, 3);
+    if constexpr (!BAR2) W6L_BDMA(wn + 3 * w_pos, 3);
     pin_t(1);
     M4D_W6_BLOCK2(3, 0, 0, 6)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2) { M4D_W6_WAIT(0); } else { M4D_W6_WAIT(7); }
+    if constexpr (BAR2) { W6L_WAIT(0); } else { W6L_WAIT(7); }
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     wc = wn;
