@@ -20,9 +20,10 @@
 // wave of the SIMD covers the LDS / DMA / scalar instructions and every latency.  B operands (the split U, fragment order:
 // 1 KB per (position, N-tile, part)) and the raw halo both reach LDS by LDS-DMA (global_load_lds / buffer_load ... lds: no
 // staging registers, no ds_write pass): the two waves of a position row share a 4-position ring of B fragments (filled four
-// positions ahead, half by each), all waves share the double-buffered raw halo (23 KB each, [channel quad][row][column
-// parity][column / 2]: conflict-free 16-byte reads; pixels outside the image come back as zeros from the buffer descriptor's
-// range check).  The DMAs are inline asm with hand-counted s_waitcnt vmcnt(N) -- the compiler would drain every DMA in
+// positions ahead, half by each), all waves share the double-buffered raw halo (29 KB each, [row][column parity][column / 2]
+// [channel quad + 1 pad slot]: conflict-free 16-byte reads AND four consecutive DMA lanes = 64 contiguous bytes of one pixel --
+// round 3: the quad-major layout before it made every DMA lane fetch 16 bytes of a different pixel, 64 lines per instruction,
+// and cost 10 % of the kernel; pixels outside the image come back as zeros from the buffer descriptor's range check).  The DMAs are inline asm with hand-counted s_waitcnt vmcnt(N) -- the compiler would drain every DMA in
 // flight (vmcnt(0)) before any LDS read it cannot prove independent; one raw s_barrier per position makes the partner's
 // fragments visible.  The B registers are refilled part by part as the MFMAs of the current position retire them.
 // Epilogue as in kernel 4 of m4d_wino.hip: rows of A^T (M A) through LDS, bias + leaky_relu, 16-byte stores.
@@ -50,12 +51,30 @@ struct Wino6Args {
 };
 
 constexpr int kT = 16, kH = kT + 2;              // output tile, halo (pixels)
+#ifndef M4D_W6_RAWQ
+#define M4D_W6_RAWQ 1
+#endif
+#if M4D_W6_RAWQ
+// Raw halo in LDS, [row][column parity][column / 2][channel quad + 1 pad slot]: the four 16-byte channel quads of a pixel are
+// CONSECUTIVE slots, so four consecutive lanes of an LDS-DMA instruction fetch 64 contiguous bytes of one pixel (13 pixels =
+// 13 lines per instruction; the layout of rounds 2-3, quad-major, made every lane fetch 16 bytes of a different pixel: 64 lines
+// per instruction through a texture path that was busy 52-59 % of the kernel).  Pixel stride 5 slots, two rows = 200 slots =
+// 8 mod 16: the 16-lane groups of a ds_read_b128 (tiles (ty0, tx) -> 8 ty0 + 5 tx mod 16) still cover 16 distinct slots.
+constexpr int kJ = 10;                           // pixels per (row, column parity): 9 used
+constexpr int kPix = 5;                          // slots per pixel: 4 channel quads + 1 pad
+constexpr int kRow = 2 * kJ * kPix;              // slots per halo row (100)
+constexpr int kRawUsed = kH * kRow;              // per chunk of 16 channels: 1800 slots
+constexpr int kRawDma = 29;                      // LDS-DMA instructions per chunk: 64 slots each
+constexpr int kRawK = 4;                         // ... = up to 4 per wave
+#else
 constexpr int kJ = 10;                           // 16-byte slots per (row, column parity): 9 used; 2 * kJ = 20 = 4 mod 8 makes
 constexpr int kRow = 2 * kJ;                     //   two rows = 8 slots mod 16: every 16-lane read group covers 16 distinct slots
 constexpr int kQuad = kH * kRow;                 // slots per channel quad (360)
 constexpr int kRawUsed = 4 * kQuad;              // per chunk of 16 channels: 1440 slots
 constexpr int kRawDma = 23;                      // LDS-DMA instructions per chunk: 64 slots each (the last one half used)
-constexpr int kRawSlots = kRawDma * 64;          // 1472 slots = 23552 B per buffer
+constexpr int kRawK = 3;
+#endif
+constexpr int kRawSlots = kRawDma * 64;          // slots per buffer
 constexpr int kBRingBytes = 4 * 6 * 1024;        // per position row: 4 positions x 6 fragments of 1 KB
 constexpr int kBRingOff = 2 * kRawSlots * 16;    // byte offset of the B rings in LDS (47104)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -130,17 +149,26 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     rsrc[2] = a.h * a.w * a.Cin * 4;                                                     // num_records (bytes)
     rsrc[3] = 0x00020000;
   }
-  unsigned rvoff[3];
+  unsigned rvoff[kRawK];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < kRawK; ++k) {
     const int i = min(wv + 8 * k, kRawDma - 1);
     const int s = i * 64 + lane;
+#if M4D_W6_RAWQ
+    const int pix = s / kPix, q = s - pix * kPix;                    // q = 4: the pad slot
+    const int hy = pix / (2 * kJ), r2 = pix - hy * (2 * kJ);
+    const int e = r2 / kJ, j = r2 - e * kJ;
+    const int hx = 2 * j + e;
+    const int gy = tile_y - 1 + hy, gx = tile_x - 1 + hx;
+    const bool ok = s < kRawUsed && q < 4 && j < 9 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+#else
     const int q = s / kQuad, rem = s - q * kQuad;
     const int hy = rem / kRow, r2 = rem - hy * kRow;
     const int e = r2 / kJ, j = r2 - e * kJ;
     const int hx = 2 * j + e;
     const int gy = tile_y - 1 + hy, gx = tile_x - 1 + hx;
     const bool ok = s < kRawUsed && j < 9 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+#endif
     rvoff[k] = ok ? (unsigned)(((gy * a.w + gx) * a.Cin + q * 4) * 4) : 0x80000000u;
   }
   // DMA k of raw(chunk) into buffer `buf`: LDS destination (wave-uniform byte address) in M0, + lane * 16
@@ -158,8 +186,13 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   const int rb_ = pr == 0 ? 2 : (pr == 1 ? 2 : (pr == 2 ? 1 : 3));
   const float sgn = pr == 1 ? 1.f : -1.f;
   const int ty0 = m >> 3, tx = m & 7;
+#if M4D_W6_RAWQ
+  // slot of (raw row 0 of the tile, column 0, quad 2 kh); + row * kRow, + ((c & 1) * kJ + (c >> 1)) * kPix, + quad
+  const int src0 = (8 * mt + 2 * ty0) * kRow + tx * kPix + 2 * kh;
+#else
   // slot of (raw row 0 of the tile, column 0, quad 2 kh); + row * kRow, + (c & 1) * kJ + (c >> 1), + quad
   const int src0 = (2 * kh) * kQuad + (8 * mt + 2 * ty0) * kRow + tx;
+#endif
 
   float tv[4][8];                                  // t_c of the current chunk: [column c][channel]
   // columns c0, c0 + 2 of t for the chunk in rbuf (two calls per chunk: the registers of columns 0, 2 are free one
@@ -170,7 +203,11 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         const int c = c0 + 2 * cc;
+#if M4D_W6_RAWQ
+        const int s = src0 + qq + ((c & 1) * kJ + (c >> 1)) * kPix;
+#else
         const int s = src0 + qq * kQuad + (c & 1) * kJ + (c >> 1);
+#endif
         const float4 da = rbuf[s + ra * kRow], db = rbuf[s + rb_ * kRow];
         tv[c][4 * qq + 0] = __builtin_fmaf(sgn, db.x, da.x);           // exact product: one rounding, = da +- db
         tv[c][4 * qq + 1] = __builtin_fmaf(sgn, db.y, da.y);
@@ -242,17 +279,17 @@ conv3x3_wino6_kernel(const Wino6Args a) {
       bs[ont][e] = a.bias[min(co, a.Cout - 1)];
     }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) raw_dma(0, 0, k);
+  for (int k = 0; k < kRawK; ++k) raw_dma(0, 0, k);
   b_dma(wc, 0);
   b_dma(wc + w_pos, 1);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) raw_dma(min(1, last), 1, k);
+  for (int k = 0; k < kRawK; ++k) raw_dma(min(1, last), 1, k);
   b_dma(wc + 2 * w_pos, 2);
   if constexpr (!BAR2) {
     b_dma(wc + 3 * w_pos, 3);
-    M4D_W6_WAIT(9);                                // raw(0), B(0), B(1) landed; raw(1), B(2), B(3) (9 DMAs) still in flight:
+    if constexpr (kRawK == 4) { M4D_W6_WAIT(10); } else { M4D_W6_WAIT(9); }   // raw(0), B(0), B(1) landed; raw(1), B(2), B(3) still in flight
   } else {
-    M4D_W6_WAIT(6);                                // (position 3's fragments are fetched at position 0, as in every chunk)
+    if constexpr (kRawK == 4) { M4D_W6_WAIT(7); } else { M4D_W6_WAIT(6); }    // (position 3's fragments are fetched at position 0, as in every chunk)
   }
   __builtin_amdgcn_s_barrier();
   read_t(raw, 0);
@@ -338,7 +375,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     if constexpr (BAR2) W6L_BDMA(wc + 3 * w_pos, 3);                                 // position 3 of THIS chunk (slot 3 is free)
     M4D_W6_BLOCK2(0, 1, 1, 4)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2) { W6L_WAIT(7); } else { W6L_WAIT(7); }
+    if constexpr (BAR2 || kRawK == 3) { W6L_WAIT(7); } else { W6L_WAIT(8); }     // this position's DMAs + the previous position's
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 1: A(2) from t2, t1
@@ -372,13 +409,15 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     if constexpr (!BAR2) W6L_BARRIER();
     M4D_W6_STAMP(0)
     M4D_W6_BLOCK0(3, 0, 0, 7)
+    if constexpr (kRawK == 4) W6L_RAW(rnext_c, chunk & 1, 3);
     read_t(rnext, 1);
     M4D_W6_BLOCK1(3, 0, 0, 6)
     if constexpr (!BAR2) W6L_BDMA(wn + 3 * w_pos, 3);
     pin_t(1);
     M4D_W6_BLOCK2(3, 0, 0, 6)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2) { W6L_WAIT(0); } else { W6L_WAIT(7); }
+    if constexpr (BAR2) { if constexpr (kRawK == 4) { W6L_WAIT(1); } else { W6L_WAIT(0); } }
+    else if constexpr (kRawK == 4) { W6L_WAIT(8); } else { W6L_WAIT(7); }
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     wc = wn;
@@ -513,8 +552,10 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
   a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.n_chunks = Cin / 16; a.slope = slope;
   a.tiles_x = (w + kT - 1) / kT; a.tiles_y = (h + kT - 1) / kT;
   a.stamps = g_wino6_stamps;
-  constexpr size_t lds = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);                 // epilogue staging 147 KB (K loop: 142 KB)
-  static_assert(lds >= (size_t)kBRingOff + 4 * kBRingBytes, "epilogue staging must cover the K-loop buffers");
+  constexpr size_t lds_epi = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);             // epilogue staging 147 KB
+  constexpr size_t lds_loop = (size_t)kBRingOff + 4 * kBRingBytes;                      // K loop: raw halo x 2 + fragment rings (154 KB)
+  constexpr size_t lds = lds_epi > lds_loop ? lds_epi : lds_loop;
+  static_assert(lds <= 160 * 1024, "LDS budget of one CU");
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
   // more than 64 KB of dynamic LDS needs the opt-in, per kernel (both instantiations share one function-pointer type: set both)
   static const bool attr_set = [] {
