@@ -73,6 +73,10 @@ small_conv_split = _small_conv_split_env and conv_arith == "bf16x3"
 # conv_arith is "bf16x3"; 0 = the fp32-MFMA tail (csrc/m4d_tail.hip) always.
 tail_split = _os.environ.get("M4D_TAIL_SPLIT", "1") == "1"
 
+# The encoder's convolutions choose their kernel from the per-image grid x the sequence batch (1 = from the per-image grid alone:
+# rounds 1-3, which ran the coarse encoder levels of a batch-32 evaluation on the single-small-map latency kernels).
+encoder_batch_dispatch = _os.environ.get("M4D_ENCODER_BATCH_DISPATCH", "1") == "1"
+
 import contextlib as _contextlib
 
 
@@ -254,7 +258,8 @@ class _Conv3x3SameTF(torch.nn.Module):
         self._cache = _PackCache()
         self.tag = None                  # e.g. "lvl1.conv1": lets bench.py bracket one layer with HIP events
         self.small_maps_ok = False       # DispRefiner layers: may take the one-launch small-map kernel
-        self.per_image_dispatch = False  # encoder layers: kernel choice from the per-image grid (see forward)
+        self.per_image_dispatch = False  # encoder layers: kernel choice from the per-image grid x dispatch_batch (see forward)
+        self.dispatch_batch = 1
         if in_channels is not None:
             self._build(in_channels, None)
 
@@ -364,8 +369,11 @@ class _Conv3x3SameTF(torch.nn.Module):
         act = 1.0 if slope is None else slope
         # The encoder is run on frames stacked along the batch axis, and how many are stacked depends on the launch mode
         # (all T frames, two batches in the pipelined forward, one frame when streaming): its kernel choice must not
-        # depend on that, or the modes stop being bit-identical -- decide from the per-image grid.
-        wino = _use_winograd(1 if self.per_image_dispatch else b_, h_, w_, cin_, self.out_channels, self.stride)
+        # depend on that, or the modes stop being bit-identical -- decide from the per-image grid x the SEQUENCE batch
+        # (``dispatch_batch``, set by the model from its input: the same in every launch mode), so that a batch-32 evaluation
+        # does not run its coarse encoder levels on the latency kernels of a single small map.
+        eff_b = self.dispatch_batch if self.per_image_dispatch else b_
+        wino = _use_winograd(eff_b, h_, w_, cin_, self.out_channels, self.stride)
         if wino == 6:
             wu, cpad = self._packed_weights_wino6(cin_)
             return _timed("conv", self.tag, lambda: nops.conv3x3_wino6_bias_act(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
@@ -374,7 +382,7 @@ class _Conv3x3SameTF(torch.nn.Module):
             fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
             return _timed("conv", self.tag, lambda: fn(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
         wp, cpad = self._packed_weights(cin_)
-        if (self.small_maps_ok and self.stride == 1 and (1 if self.per_image_dispatch else b_) * h_ * w_ <= small_map_conv_pixels and 16 <= cin_ <= 256
+        if (self.small_maps_ok and self.stride == 1 and eff_b * h_ * w_ <= small_map_conv_pixels and 16 <= cin_ <= 256
                 and cin_ % 4 == 0):
             if small_conv_split:
                 wp6, cpad6 = self._packed_weights_small6(cin_)
@@ -383,7 +391,7 @@ class _Conv3x3SameTF(torch.nn.Module):
             return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(
                 x_nhwc, wp, self.bias, self.out_channels, cpad, act))
         if (self.small_maps_ok and self.stride == 2 and small_map_stride2 and 16 <= cin_ <= 256 and cin_ % 4 == 0
-                and (1 if self.per_image_dispatch else b_) * (-(-h_ // 2)) * (-(-w_ // 2)) <= small_map_conv_pixels):
+                and eff_b * (-(-h_ // 2)) * (-(-w_ // 2)) <= small_map_conv_pixels):
             return _timed("conv", self.tag, lambda: nops.conv3x3_small_bias_act(      # one launch instead of split-K + reduce
                 x_nhwc, wp, self.bias, self.out_channels, cpad, act, stride=2))
         return _timed("conv", self.tag, lambda: nops.conv3x3_bias_act(
@@ -440,6 +448,13 @@ class FeaturePyramid(torch.nn.Module):
         for conv in list(self.conv_layers_s1) + list(self.conv_layers_s2):
             conv.per_image_dispatch = True
             conv.small_maps_ok = True            # the stride-1 layers of the coarsest levels: one launch instead of split-K + reduce
+
+    def set_sequence_batch(self, b):
+        """The sequence batch the stacked frames belong to: the convolutions choose their kernel from the per-image grid x this
+        (not from how many frames a launch mode stacks)."""
+        b = max(int(b), 1) if encoder_batch_dispatch else 1
+        for conv in list(self.conv_layers_s1) + list(self.conv_layers_s2):
+            conv.dispatch_batch = b
 
     def forward(self, images):
         """``images``: [b,H,W,3], or a ``network_ops.FrameStack`` (the frames of a sequence batch, encoded in one pass)."""
@@ -993,6 +1008,7 @@ class M4Depth(torch.nn.Module):
         n_fr = len(traj_samples)
         dev = camera["f"].device
         same_shape = all(s['RGB_im'].shape == traj_samples[0]['RGB_im'].shape for s in traj_samples)
+        self.encoder.set_sequence_batch(traj_samples[0]['RGB_im'].shape[0])
         if pipeline_encoder_per_frame and self.d_estimator.pipeline_streams_for(traj_samples, dev) >= 2:
             f_maps_pyrs = None                     # encoded per frame, on the frame's stream, inside the decoder pipeline
         elif pipeline_encoder_split > 0 and n_fr > pipeline_encoder_split and same_shape \
@@ -1315,6 +1331,7 @@ class TapedSequence:
     def _encode(self, a, b):
         samples = self._samples()
         bsz = samples[0]["RGB_im"].shape[0]
+        self.model.encoder.set_sequence_batch(bsz)
         out = self.model.encoder(_stack_frames(samples[a:b]))
         for j, t in enumerate(range(a, b)):
             self.ctx[("f", t)] = [lvl[j * bsz:(j + 1) * bsz] for lvl in out]

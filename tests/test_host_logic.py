@@ -202,6 +202,23 @@ def test_small6_pack_layout():
     assert not full[:, cin:].any() and not full[:, :, cout:].any()
 
 
+def test_encoder_kernel_choice_follows_the_sequence_batch(monkeypatch):
+    """FeaturePyramid.set_sequence_batch: the encoder's convolutions take their kernel from the per-image grid x the SEQUENCE
+    batch -- the same number in every launch mode, however many frames a mode stacks -- so a batch-32 evaluation moves the
+    coarse levels (24x80 and smaller: single-small-map latency kernels at batch 1) onto the chip-filling kernels."""
+    fp = N.FeaturePyramid({"ablation": N.M4depthAblationParameters(), "nbre_lvls": 6})
+    convs = list(fp.conv_layers_s1) + list(fp.conv_layers_s2)
+    assert all(c.per_image_dispatch and c.dispatch_batch == 1 for c in convs)
+    fp.set_sequence_batch(32)
+    assert all(c.dispatch_batch == 32 for c in convs)
+    # level 4's stride-1 layer (24x80, 128 -> 128): small-map kernel at batch 1, the bf16-split Winograd kernel at batch 32
+    assert 1 * 24 * 80 <= N.small_map_conv_pixels < 32 * 24 * 80
+    assert N._use_winograd(1, 24, 80, 128, 128, 1) != 6 and N._use_winograd(32, 24, 80, 128, 128, 1) == 6
+    monkeypatch.setattr(N, "encoder_batch_dispatch", False)
+    fp.set_sequence_batch(32)
+    assert all(c.dispatch_batch == 1 for c in convs)
+
+
 def test_refiner_tail6_pack_layout():
     """pack_refiner_tail_weights6: the MFMA B fragments of the bf16-split level tail (csrc/m4d_tail6.hip).  conv6: lane
     (k-quarter kq, cout n) of tap t holds channels 8 kq .. 8 kq + 7; conv7: K-step j, k-quarter kq holds channels
