@@ -99,3 +99,21 @@ def test_two_rank_bench_leg_over_gloo():
         assert abs(head["ms_per_step"] - 1e3 * dt0 / 3) < 1e-2
     # Keras-Mean over both ranks' per-batch values: AbsRel of est = gt (1 + 0.01 (r + 1)) -> mean of 0.01 and 0.02
     assert met0 == met1 and abs(met0[0] - 0.015) < 1e-4
+
+
+def test_event_timer_leaves_hiccups_out_of_the_mean():
+    """bench.EventTimer.summary(): a launch more than twice as long as the median of its group is a box hiccup, not the
+    kernel: it is left out of the average and counted (one such launch doubled a batch-32 roofline average in round 3)."""
+    import bench
+
+    class Ev:
+        def __init__(self, t): self.t = t
+        def elapsed_time(self, other): return other.t - self.t
+
+    timer = bench.EventTimer(torch=None)
+    timer.events[("conv", "lvl1.conv1")] = [(Ev(0.0), Ev(3.5))] * 14 + [(Ev(0.0), Ev(58.0))]
+    timer.events[("front", 1)] = [(Ev(0.0), Ev(1.0)), (Ev(0.0), Ev(1.2)), (Ev(0.0), Ev(0.9))]
+    summ = timer.summary()
+    n, sec = summ[("conv", "lvl1.conv1")]
+    assert n == 14 and abs(sec - 3.5e-3) < 1e-12 and timer.outliers[("conv", "lvl1.conv1")] == 1
+    assert summ[("front", 1)][0] == 3 and timer.outliers[("front", 1)] == 0
