@@ -475,9 +475,11 @@ def main():
                 "sustained_mfma_tflops_on_random_operands": BF16_MFMA_SUSTAINED_TFLOPS if wino == 6 else None,
                 "note": "achieved / frac = MFMA flops the kernel executes / time against the dense peak of the MFMA type it issues "
                         "(bf16 2500 TFLOP/s for the split kernel: 6 bf16 products per float32 multiply-add of the Winograd form, "
-                        "2*16*Cin*Cout per 2x2 output tile; fp32 MFMA 157.3 otherwise).  The split kernel is balanced between the "
-                        "matrix core and the VALU work of the exact 3-way operand split (7.5 instructions per transformed input "
-                        "element), so its MFMA fraction is low by design; float32_equivalent_tflops = the float32 multiply-adds of "
+                        "2*16*Cin*Cout per 2x2 output tile; fp32 MFMA 157.3 otherwise).  frac_of_sustained_mfma_rate = the same against what "
+                        "a bare MFMA loop sustains on real operand values on this pool (0.66 of nominal, "
+                        "profiles/r03_mfma_rate_vs_operand_values.txt).  Timing ablations of the kernel (DESIGN.md section 6): MFMAs + "
+                        "row-transform reads + prologue / epilogue 73 % of the launch, LDS-DMA traffic 13 %, the exact 3-way operand "
+                        "split + input transform 8.5 %, fragment reads 5 %; float32_equivalent_tflops = the float32 multiply-adds of "
                         "the Winograd form it replaces / time (fp32-MFMA peak 157.3), algorithmic_* = the layer's "
                         "direct-convolution flops / time",
                 "float32_equivalent_tflops": round(flops_wino / sec / 1e12, 2) if wino else round(tf_exec, 2),
