@@ -268,8 +268,13 @@ conv3x3_wino6_kernel(const Wino6Args a) {
                                ? a.stamps + (long long)blockIdx.x * 1280 + wv * 128 : nullptr;
   if (STAMPS && st && wv == 0) st[1024 + 0] = __builtin_readcyclecounter();
 
-  // ---- prologue: epilogue operands; raw(0), raw(1), B(0..3) by DMA in the order the K loop's vmcnt counts assume (the end
-  // of position 0 waits for everything but B(3) and its own 4); then t(0), A(0, 0), B(0) in registers
+  // ---- prologue: epilogue operands; raw(0), B(0), B(1) | B(2), raw(1), B(3) by DMA in the order the K loop's vmcnt counts
+  // assume: every end-of-position wait of the K loop is vmcnt(4 + 4) = "this position's and the previous position's DMAs may
+  // still fly".  First chunk, DMAs in flight oldest first (kRawK = 4, pieces in brackets):
+  //   after the prologue wait (10):  B(2)[3] raw(1)[4] B(3)[3]
+  //   end of position 0 (+4, wait 8): retires B(2)[3] raw(1)[3]      -> position 1 reads slot 2: landed
+  //   end of position 1 (+4, wait 8): retires raw(1)[1] B(3)[3]      -> position 2 reads slot 3 and raw(1): landed
+  // then t(0), A(0, 0), B(0) in registers
   float bs[2][4];                                  // this thread's output-channel quad of the bias, per N-tile (oldest loads)
 #pragma unroll
   for (int ont = 0; ont < 2; ++ont)
@@ -282,12 +287,17 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   for (int k = 0; k < kRawK; ++k) raw_dma(0, 0, k);
   b_dma(wc, 0);
   b_dma(wc + w_pos, 1);
+  // B(2) BEFORE raw(1): position 1 reads slot 2, position 2 reads raw(1).  The end-of-position waits of the first chunk retire
+  // the prologue's DMAs oldest first, six per position: with raw(1) issued first (rounds 2-3) the wait that closes position 0
+  // retired raw(1) and only TWO of B(2)'s three pieces, and position 1 read the third (the lo part of N-tile 0 / 1) with
+  // nothing but elapsed time between the DMA and the read -- stale LDS under a loaded memory system, i.e. the
+  // non-deterministic replicas of round 3's driver run.
+  b_dma(wc + 2 * w_pos, 2);
 #pragma unroll
   for (int k = 0; k < kRawK; ++k) raw_dma(min(1, last), 1, k);
-  b_dma(wc + 2 * w_pos, 2);
   if constexpr (!BAR2) {
     b_dma(wc + 3 * w_pos, 3);
-    if constexpr (kRawK == 4) { M4D_W6_WAIT(10); } else { M4D_W6_WAIT(9); }   // raw(0), B(0), B(1) landed; raw(1), B(2), B(3) still in flight
+    if constexpr (kRawK == 4) { M4D_W6_WAIT(10); } else { M4D_W6_WAIT(9); }   // raw(0), B(0), B(1) landed; B(2), raw(1), B(3) still in flight
   } else {
     if constexpr (kRawK == 4) { M4D_W6_WAIT(7); } else { M4D_W6_WAIT(6); }    // (position 3's fragments are fetched at position 0, as in every chunk)
   }
@@ -355,6 +365,9 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // with the A operands of the next; then vmcnt(N) leaves exactly the DMAs of this and the previous position in flight
   // (N = 6 + their raw pieces), i.e. everything the barrier of the next position publishes has landed.
   if constexpr (BAR2) { M4D_W6_WAIT(0); }          // raw(1) and B(2) of both waves land before position 0's barrier publishes them
+  // every LDS read of the prologue (raw buffer 0, ring slot 0) has returned before this wave passes position 0's barrier,
+  // behind which the other waves' DMAs start refilling that buffer and that slot (the K loop's waits include lgkmcnt(0) too)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int stq = 0;
 #define M4D_W6_STAMP(k) if (STAMPS && st && stq < 32) st[stq * 4 + (k)] = __builtin_readcyclecounter();
 #define W6L_BARRIER() do { if (!(M4D_W6_ABL & 1)) __builtin_amdgcn_s_barrier(); } while (0)

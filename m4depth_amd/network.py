@@ -35,6 +35,9 @@ import os as _os
 # bench.py installs an object with ``run(name, level, thunk)`` here to bracket the
 # hand-written kernels with HIP events on the launch stream; None = no overhead.
 kernel_timer = None
+# tools/determinism_stress.py installs ``tap(name, level, tensor)`` here to keep copies of intermediate activations (the
+# encoder maps and the refiner layers, which nothing else retains); None = no overhead.
+debug_tap = None
 # Winograd F(2x2,3x3) for the wide stride-1 layers (csrc/m4d_wino.hip): 2.25x fewer MFMA flops, equal to the direct
 # convolution up to float32 rounding (max difference ~1e-6 of the output range).  Measured per layer (tools/bench_wino.py):
 # 1.26-1.49x at batch 1, 1.16-1.39x at batch 8 for 64/128 output channels; the 96- and 32-wide layers (one N-tile per
@@ -697,13 +700,18 @@ class DepthEstimatorLevel(torch.nn.Module):
         self.last_f_input = f_input if F_st == F_in else f_input[..., :F_in]      # the reference-width view (inspection / tests)
         self.last_cv_inputs = (curr_f, prev_f, para_prev_t, para_prev_l, rot_t, tr, cf, cc)   # for tools/bench_kernels.py
         self.last_front_inputs = (curr_f_maps, prev_l_est, prev_t_depth)
+        if debug_tap is not None:
+            debug_tap("encoder_map", self.lvl_depth, curr_f_maps)
+            debug_tap("f_input", self.lvl_depth, self.last_f_input)
         # "depth_estimator" (:244-260)
         convs = list(self.disp_refiner.prep_conv_layers) + list(self.disp_refiner.est_d_conv_layers)
         if (fused_refiner_tail and dev.type == "cuda" and len(convs) == 7 and convs[5].weight is not None
                 and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16)):
             x = f_input
-            for conv in convs[:5]:
+            for ci, conv in enumerate(convs[:5]):
                 x = conv(x, slope=0.1)
+                if debug_tap is not None:
+                    debug_tap(f"refiner_conv{ci + 1}", self.lvl_depth, x)
             split = tail_split and conv_arith == "bf16x3"
             w6p, w7p = self._tail_weights(convs, split)
             tail_fn = nops.refiner_tail6 if split else nops.refiner_tail
