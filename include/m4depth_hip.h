@@ -17,8 +17,14 @@
  *   - the caller allocates every buffer; kernels never allocate, never retain
  *     pointers, write every output element (no memset dependency) and are
  *     enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL =
- *     the default stream).  No host synchronisation, no global state: the calls
- *     are re-entrant and hipGraph-capturable;
+ *     the default stream).  No host synchronisation; the calls are re-entrant,
+ *     safe from several host threads on different streams, and hipGraph-capturable.
+ *     The ONLY process-wide state is the profiling / debugging hooks named
+ *     m4d_*_set_* (cycle-stamp buffers, the DSCV kernel selector, ablation masks):
+ *     all off by default, not meant to be flipped while another thread launches,
+ *     and never touched by the product's dispatch (m4depth_amd/network.py).  The
+ *     measured-and-not-dispatched alternative kernels and the launch tape are not
+ *     in this library: `make EXPERIMENTS=1`, include/m4depth_hip_experiments.h;
  *   - return value: 0 on success, otherwise a hipError_t code (1 =
  *     hipErrorInvalidValue for bad arguments).  Never exits the process (the
  *     reference launcher does `exit(-1)`, backproject_op_gpu.cu.cc:95-100);
@@ -169,20 +175,8 @@ void m4d_wino_set_stamps(unsigned long long* device_buffer);
  * Replaces the same tf.keras Conv2D + leaky_relu pairs as m4d_conv3x3_wino2_bias_act (m4depth_network.py:101-131). */
 int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
+/* Profiling only (tools/wino6_phases.py): per-position cycle stamps of the first 64 workgroups; NULL switches it off. */
 void m4d_wino6_set_stamps(unsigned long long* device_buffer);
-/* Which kernel serves m4d_conv3x3_wino6_bias_act (results are bit-identical): 0 (default) and 1 = the 16x16-pixel x 64-cout
- * workgroups of m4d_wino6.hip, 2 = the wide kernel of m4d_wino6w.hip (16x16 pixels x all 96 / 128 couts, two passes over the
- * Winograd position rows) wherever it applies (64 < Cout <= 128, Cout % 4 == 0) -- measured not faster end to end,
- * kept selectable.  Test / profiling hook. */
-void m4d_wino6_set_variant(int variant);
-/* Variant 3 = the half-tile kernel of m4d_wino6h.hip (16x8 pixels x 64 couts per workgroup) everywhere; under variant 0 it
- * serves the launches whose m4d_wino6.hip grid would have at most `max_wg` workgroups (default 0 = none: faster alone on small
- * grids, no gain inside the frame pipeline).  Same bits. */
-void m4d_wino6_set_half_tile_max_workgroups(int max_wg);
-/* Variant 4 = m4d_wino6.hip's kernel with ONE barrier per TWO Winograd positions (fragment DMAs issued in pairs, tighter
- * waits) everywhere; under variant 0 it serves the launches of at least `min_wg` workgroups (default: never = negative;
- * 1.03-1.05x per layer alone on chip-filling grids, 0.8 % slower end to end).  Same bits. */
-void m4d_wino6_set_two_position_barrier_min_workgroups(int min_wg);
 
 /* The tail of a level in one kernel: the last two DispRefiner convolutions (32 -> 16 + leaky_relu(0.1), 16 -> 5;
  * m4depth_network.py:109-135) and m4d_level_post (:247-260).  x32 [b,h,w,32]; w6p [9][16][32] = kernel[ky][kx][k][n] as
@@ -454,19 +448,6 @@ int m4d_decode_rgb8_resize(const uint8_t* images, int n, int ih, int iw, int oh,
  *         is exactly black are zeroed (tartanair.py:37-45). */
 int m4d_decode_depth_resize(const void* raw, int kind, int n, int ih, int iw, int oh, int ow,
                             const float* rgb_resized, const int crop[4], float* out, void* stream);
-
-/* ---- launch tape (csrc/m4d_tape.hip): a recorded sequence of this library's kernel launches, replayed as PLAIN STREAM
- * LAUNCHES from one host loop -- the host-side cost of a hipGraph replay without its effect on concurrent small kernels
- * (kernels issued by graph replays make each other's small launches crawl: DESIGN.md section 6).  Between m4d_tape_begin()
- * and m4d_tape_end() every entry point called BY THE SAME THREAD records its launches (function, grid, block, LDS, a copy of
- * every argument) instead of executing them; the recording pass must run on the buffers the replays will use.
- * m4d_tape_begin returns the tape id (-1: already recording), m4d_tape_end the number of launches recorded,
- * m4d_tape_replay issues them on `stream` in order (0 or a hipError_t). */
-int m4d_tape_begin(void);
-int m4d_tape_end(void);
-int m4d_tape_length(int tape);
-int m4d_tape_replay(int tape, void* stream);
-int m4d_tape_free(int tape);
 
 #ifdef __cplusplus
 }

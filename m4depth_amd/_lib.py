@@ -99,9 +99,12 @@ _SIGNATURES = {
                        _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
 }
 
-# launch tape (csrc/m4d_tape.hip): int-returning, no stream implied
-_SIGNATURES.update({"m4d_tape_begin": [], "m4d_tape_end": [], "m4d_tape_length": [_c_int], "m4d_tape_replay": [_c_int, _c_fp],
-                    "m4d_tape_free": [_c_int]})
+# include/m4depth_hip_experiments.h: present only in a `make EXPERIMENTS=1` build of the library (the launch tape and the
+# selectors of the not-dispatched Winograd kernels); bound when the library has them, ``has_experiments`` says whether
+_EXPERIMENT_SIGNATURES = {"m4d_tape_begin": [], "m4d_tape_end": [], "m4d_tape_length": [_c_int], "m4d_tape_replay": [_c_int, _c_fp],
+                          "m4d_tape_free": [_c_int]}
+_EXPERIMENT_VOID_SIGNATURES = {"m4d_wino6_set_variant": [_c_int], "m4d_wino6_set_half_tile_max_workgroups": [_c_int]}
+EXPERIMENT_SYMBOLS = list(_EXPERIMENT_SIGNATURES) + list(_EXPERIMENT_VOID_SIGNATURES)
 
 _LL_SIGNATURES = {"m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
                   "m4d_dinl_workspace_floats": [_c_int, _c_int], "m4d_metrics_workspace_bytes": [],
@@ -109,9 +112,7 @@ _LL_SIGNATURES = {"m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_in
                   "m4d_conv3x3_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]}
 _VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
                     "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp], "m4d_wino_set_stamps": [_c_fp],
-                    "m4d_front_set_stamps": [_c_fp], "m4d_wino6_set_stamps": [_c_fp], "m4d_wino6_set_variant": [_c_int],
-                    "m4d_wino6_set_half_tile_max_workgroups": [_c_int],
-                    "m4d_wino6_set_two_position_barrier_min_workgroups": [_c_int]}
+                    "m4d_front_set_stamps": [_c_fp], "m4d_wino6_set_stamps": [_c_fp]}
 
 EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES) + list(_VOID_SIGNATURES) + list(_LL_SIGNATURES)
 
@@ -139,12 +140,29 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = None
         fn.argtypes = args
+    if hasattr(lib, "m4d_tape_begin"):
+        for name, args in _EXPERIMENT_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = _c_int
+            fn.argtypes = args
+        for name, args in _EXPERIMENT_VOID_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = None
+            fn.argtypes = args
     if lib.m4d_abi_version() != ABI_VERSION:
         raise ImportError(f"m4depth_amd: ABI mismatch, library reports {lib.m4d_abi_version()}, binding expects {ABI_VERSION}")
     return lib
 
 
 lib = _load()
+has_experiments = hasattr(lib, "m4d_tape_begin")      # a `make EXPERIMENTS=1` build (include/m4depth_hip_experiments.h)
+
+
+def require_experiments(what):
+    if not has_experiments:
+        raise RuntimeError(f"{what} needs the experiments build of the library: make -C m4depth_amd/csrc clean && "
+                           "make -C m4depth_amd/csrc EXPERIMENTS=1 (include/m4depth_hip_experiments.h); the product "
+                           "library exports only the kernels it dispatches")
 
 
 def build_info() -> str:

@@ -14,12 +14,15 @@
 
 static inline int m4d_blocks(long long n, int threads) { return (int)((n + threads - 1) / threads); }
 
-// ---- launch tape (m4d_tape.hip) ------------------------------------------------------------------------------------
-// Every kernel of the library is launched through m4d_launch().  Normally it IS hipLaunchKernelGGL.  While the calling
-// thread records a tape (m4d_tape_begin .. m4d_tape_end) the launch is not executed but appended -- function, grid, block,
-// dynamic LDS and a private copy of every argument -- to the tape, which m4d_tape_replay() later issues as plain stream
-// launches (hipLaunchKernel) from one tight host loop: a replayable launch sequence WITHOUT hipGraph (kernels issued by
-// graph replays starve each other's small launches).
+// ---- m4d_launch(): every kernel of the library is launched through it ----------------------------------------------------
+// In the product library it IS hipLaunchKernelGGL.  `make EXPERIMENTS=1` adds the launch tape (m4d_tape.hip,
+// include/m4depth_hip_experiments.h): while the calling thread records (m4d_tape_begin .. m4d_tape_end) the launch is not
+// executed but appended -- function, grid, block, dynamic LDS and a private copy of every argument -- to the tape, which
+// m4d_tape_replay() later issues as plain stream launches from one host loop (DESIGN_HISTORY.md: not faster than hipGraph).
+#ifndef M4D_EXPERIMENTS
+#define M4D_EXPERIMENTS 0
+#endif
+#if M4D_EXPERIMENTS
 #include <tuple>
 #include <utility>
 bool m4d_tape_recording();
@@ -31,14 +34,17 @@ inline void m4d_tape_push_tuple(const void* fn, dim3 grid, dim3 block, unsigned 
   const size_t sizes[sizeof...(I) + 1] = {sizeof(std::tuple_element_t<I, Tuple>)...};
   m4d_tape_push(fn, grid, block, lds, params, sizes, (int)sizeof...(I));
 }
+#endif
 
 template <class... KArgs, class... Args>
 inline void m4d_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args&&... args) {
+#if M4D_EXPERIMENTS
   if (m4d_tape_recording()) {
     std::tuple<std::remove_cv_t<std::remove_reference_t<KArgs>>...> vals(static_cast<KArgs>(args)...);
     m4d_tape_push_tuple(reinterpret_cast<const void*>(kernel), grid, block, (unsigned)lds, vals, std::index_sequence_for<KArgs...>{});
     return;
   }
+#endif
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
 }
 

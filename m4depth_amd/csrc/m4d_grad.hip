@@ -238,6 +238,9 @@ extern "C" int m4d_dscv_bwd(const float* c1, const float* c2, const float* disp_
   M4D_CHECK_ARG(((((uintptr_t)c1 | (uintptr_t)c2 | (uintptr_t)g_c1 | (uintptr_t)g_c2)) & 15u) == 0);
   hipStream_t s = (hipStream_t)stream;
   const size_t fbytes = (size_t)b * h * w * C * sizeof(float);
+#if M4D_EXPERIMENTS
+  if (m4d_tape_recording()) return (int)hipErrorNotSupported;      // a memset is not a kernel launch: it would be lost from the replay
+#endif
   hipError_t e = hipMemsetAsync(g_c2, 0, fbytes, s);
   if (e != hipSuccess) return (int)e;
   if (g_disp_prev_t) {

@@ -15,6 +15,7 @@
 #include <vector>
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
+#include "../../include/m4depth_hip_experiments.h"
 
 namespace {
 
@@ -80,12 +81,12 @@ extern "C" int m4d_tape_replay(int tape, void* stream) {
     t = g_tapes[tape];
   }
   if (t == t_rec) return (int)hipErrorInvalidValue;                  // still recording
-  void* params[32];
+  std::vector<void*> params;                                         // sized per launch: no argument-count limit
   for (TapeOp& op : t->ops) {
-    const int n = (int)op.offs.size();
-    if (n > 32) return (int)hipErrorInvalidValue;
-    for (int i = 0; i < n; ++i) params[i] = op.blob.data() + op.offs[i];
-    const hipError_t e = hipLaunchKernel(op.fn, op.grid, op.block, params, op.lds, (hipStream_t)stream);
+    const size_t n = op.offs.size();
+    params.resize(n + 1);
+    for (size_t i = 0; i < n; ++i) params[i] = op.blob.data() + op.offs[i];
+    const hipError_t e = hipLaunchKernel(op.fn, op.grid, op.block, params.data(), op.lds, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
   return 0;

@@ -172,6 +172,9 @@ extern "C" int m4d_backproject_bwd(const float* grad, const float* input, const 
   const long long items = (long long)dims[0] * dims[1] * dims[2] * dims[3] * dims[4];
   const long long total = items * dims[5];
   const size_t in_bytes = sizeof(float) * (size_t)dims[0] * dims[1] * dims[2] * dims[4] * dims[5];
+#if M4D_EXPERIMENTS
+  if (m4d_tape_recording()) return (int)hipErrorNotSupported;      // a memset is not a kernel launch: it would be lost from the replay
+#endif
   hipError_t e = hipMemsetAsync(input_grad, 0, in_bytes, (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   m4d_launch(backproject_bwd_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,

@@ -51,10 +51,6 @@ struct Wino6Args {
 };
 
 constexpr int kT = 16, kH = kT + 2;              // output tile, halo (pixels)
-#ifndef M4D_W6_RAWQ
-#define M4D_W6_RAWQ 1
-#endif
-#if M4D_W6_RAWQ
 // Raw halo in LDS, [row][column parity][column / 2][channel quad + 1 pad slot]: the four 16-byte channel quads of a pixel are
 // CONSECUTIVE slots, so four consecutive lanes of an LDS-DMA instruction fetch 64 contiguous bytes of one pixel (13 pixels =
 // 13 lines per instruction; the layout of rounds 2-3, quad-major, made every lane fetch 16 bytes of a different pixel: 64 lines
@@ -66,14 +62,6 @@ constexpr int kRow = 2 * kJ * kPix;              // slots per halo row (100)
 constexpr int kRawUsed = kH * kRow;              // per chunk of 16 channels: 1800 slots
 constexpr int kRawDma = 29;                      // LDS-DMA instructions per chunk: 64 slots each
 constexpr int kRawK = 4;                         // ... = up to 4 per wave
-#else
-constexpr int kJ = 10;                           // 16-byte slots per (row, column parity): 9 used; 2 * kJ = 20 = 4 mod 8 makes
-constexpr int kRow = 2 * kJ;                     //   two rows = 8 slots mod 16: every 16-lane read group covers 16 distinct slots
-constexpr int kQuad = kH * kRow;                 // slots per channel quad (360)
-constexpr int kRawUsed = 4 * kQuad;              // per chunk of 16 channels: 1440 slots
-constexpr int kRawDma = 23;                      // LDS-DMA instructions per chunk: 64 slots each (the last one half used)
-constexpr int kRawK = 3;
-#endif
 constexpr int kRawSlots = kRawDma * 64;          // slots per buffer
 constexpr int kBRingBytes = 4 * 6 * 1024;        // per position row: 4 positions x 6 fragments of 1 KB
 constexpr int kBRingOff = 2 * kRawSlots * 16;    // byte offset of the B rings in LDS (47104)
@@ -101,15 +89,7 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& a0, bf16x8& a1, b
   a0 = __builtin_bit_cast(bf16x8, p0); a1 = __builtin_bit_cast(bf16x8, p1); a2 = __builtin_bit_cast(bf16x8, p2);
 }
 
-// BAR2 (round 3, m4d_wino6_set_variant(4)): ONE barrier per TWO positions.  The per-position barrier does two things for the
-// fragment ring two waves share: it publishes the partner's half of the next position's fragments and it frees the slot of
-// the position just consumed.  With the fragment DMAs issued in pairs right after the barrier of every even position
-// (positions q + 3 and q + 4 at position q) and every end-of-position wait tightened to "only this position's DMAs in
-// flight", the same guarantees hold with half the barriers; same instruction stream per accumulator: same bits.
-// Measured: 1.03-1.05x per layer ALONE on chip-filling grids (129.5 -> 123.7 us on the level-1 128 -> 128 layer), 0.95-0.99x on
-// small grids, and 0.8 % SLOWER end to end (1365 against 1377 frames/s, 10 interleaved runs each): the tighter waits meet
-// longer DMA latencies when other frames' kernels share the memory system.  Not dispatched by default.
-template <bool STAMPS, bool BAR2 = false>
+template <bool STAMPS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3x3_wino6_kernel(const Wino6Args a) {
   extern __shared__ __align__(16) float lds[];
@@ -139,7 +119,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   const float* ximg = a.x + (long long)bi * a.h * a.w * a.Cin;
 
   // ---- raw halo by LDS-DMA: instruction i fills slots 64 i .. 64 i + 63 (lane = slot); wave wv issues i = wv, wv + 8,
-  // wv + 16 (the 24th repeats the 23rd).  Per lane: the byte offset of its slot's (pixel, channel quad) in the image, or an
+  // wv + 16, wv + 24 (29 pieces: waves 5-7 repeat the 29th, same bytes to the same slots).  Per lane: the byte offset of its slot's (pixel, channel quad) in the image, or an
   // offset past the buffer's num_records for pixels outside the image and pad slots: the range check returns zeros.
   i32x4 rsrc;
   {
@@ -154,21 +134,12 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   for (int k = 0; k < kRawK; ++k) {
     const int i = min(wv + 8 * k, kRawDma - 1);
     const int s = i * 64 + lane;
-#if M4D_W6_RAWQ
     const int pix = s / kPix, q = s - pix * kPix;                    // q = 4: the pad slot
     const int hy = pix / (2 * kJ), r2 = pix - hy * (2 * kJ);
     const int e = r2 / kJ, j = r2 - e * kJ;
     const int hx = 2 * j + e;
     const int gy = tile_y - 1 + hy, gx = tile_x - 1 + hx;
     const bool ok = s < kRawUsed && q < 4 && j < 9 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-#else
-    const int q = s / kQuad, rem = s - q * kQuad;
-    const int hy = rem / kRow, r2 = rem - hy * kRow;
-    const int e = r2 / kJ, j = r2 - e * kJ;
-    const int hx = 2 * j + e;
-    const int gy = tile_y - 1 + hy, gx = tile_x - 1 + hx;
-    const bool ok = s < kRawUsed && j < 9 && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-#endif
     rvoff[k] = ok ? (unsigned)(((gy * a.w + gx) * a.Cin + q * 4) * 4) : 0x80000000u;
   }
   // DMA k of raw(chunk) into buffer `buf`: LDS destination (wave-uniform byte address) in M0, + lane * 16
@@ -186,13 +157,8 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   const int rb_ = pr == 0 ? 2 : (pr == 1 ? 2 : (pr == 2 ? 1 : 3));
   const float sgn = pr == 1 ? 1.f : -1.f;
   const int ty0 = m >> 3, tx = m & 7;
-#if M4D_W6_RAWQ
   // slot of (raw row 0 of the tile, column 0, quad 2 kh); + row * kRow, + ((c & 1) * kJ + (c >> 1)) * kPix, + quad
   const int src0 = (8 * mt + 2 * ty0) * kRow + tx * kPix + 2 * kh;
-#else
-  // slot of (raw row 0 of the tile, column 0, quad 2 kh); + row * kRow, + (c & 1) * kJ + (c >> 1), + quad
-  const int src0 = (2 * kh) * kQuad + (8 * mt + 2 * ty0) * kRow + tx;
-#endif
 
   float tv[4][8];                                  // t_c of the current chunk: [column c][channel]
   // columns c0, c0 + 2 of t for the chunk in rbuf (two calls per chunk: the registers of columns 0, 2 are free one
@@ -203,11 +169,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
         const int c = c0 + 2 * cc;
-#if M4D_W6_RAWQ
         const int s = src0 + qq + ((c & 1) * kJ + (c >> 1)) * kPix;
-#else
-        const int s = src0 + qq * kQuad + (c & 1) * kJ + (c >> 1);
-#endif
         const float4 da = rbuf[s + ra * kRow], db = rbuf[s + rb_ * kRow];
         tv[c][4 * qq + 0] = __builtin_fmaf(sgn, db.x, da.x);           // exact product: one rounding, = da +- db
         tv[c][4 * qq + 1] = __builtin_fmaf(sgn, db.y, da.y);
@@ -295,12 +257,9 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   b_dma(wc + 2 * w_pos, 2);
 #pragma unroll
   for (int k = 0; k < kRawK; ++k) raw_dma(min(1, last), 1, k);
-  if constexpr (!BAR2) {
-    b_dma(wc + 3 * w_pos, 3);
-    if constexpr (kRawK == 4) { M4D_W6_WAIT(10); } else { M4D_W6_WAIT(9); }   // raw(0), B(0), B(1) landed; B(2), raw(1), B(3) still in flight
-  } else {
-    if constexpr (kRawK == 4) { M4D_W6_WAIT(7); } else { M4D_W6_WAIT(6); }    // (position 3's fragments are fetched at position 0, as in every chunk)
-  }
+  b_dma(wc + 3 * w_pos, 3);
+  static_assert(kRawK == 4, "the vmcnt counts below assume 4 raw-halo pieces + 3 fragment pieces per position");
+  M4D_W6_WAIT(10);                                 // raw(0), B(0), B(1) landed; B(2), raw(1), B(3) still in flight
   __builtin_amdgcn_s_barrier();
   read_t(raw, 0);
   read_t(raw, 1);
@@ -364,7 +323,6 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // DMAs (one raw piece at columns 0-2, this wave's half of B four positions ahead); the MFMAs of this position interleaved
   // with the A operands of the next; then vmcnt(N) leaves exactly the DMAs of this and the previous position in flight
   // (N = 6 + their raw pieces), i.e. everything the barrier of the next position publishes has landed.
-  if constexpr (BAR2) { M4D_W6_WAIT(0); }          // raw(1) and B(2) of both waves land before position 0's barrier publishes them
   // every LDS read of the prologue (raw buffer 0, ring slot 0) has returned before this wave passes position 0's barrier,
   // behind which the other waves' DMAs start refilling that buffer and that slot (the K loop's waits include lgkmcnt(0) too)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -385,22 +343,21 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     W6L_RAW(rnext_c, chunk & 1, 0);
     M4D_W6_BLOCK1(0, 1, 1, 4)
     W6L_BDMA(wn, 0);
-    if constexpr (BAR2) W6L_BDMA(wc + 3 * w_pos, 3);                                 // position 3 of THIS chunk (slot 3 is free)
     M4D_W6_BLOCK2(0, 1, 1, 4)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2 || kRawK == 3) { W6L_WAIT(7); } else { W6L_WAIT(8); }     // this position's DMAs + the previous position's
+    W6L_WAIT(8);                                                                  // this position's DMAs + the previous position's
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 1: A(2) from t2, t1
-    if constexpr (!BAR2) W6L_BARRIER();
+    W6L_BARRIER();
     M4D_W6_STAMP(0)
     M4D_W6_BLOCK0(1, 2, 2, 7)
     W6L_RAW(rnext_c, chunk & 1, 1);
     M4D_W6_BLOCK1(1, 2, 2, 4)
-    if constexpr (!BAR2) W6L_BDMA(wn + w_pos, 1);
+    W6L_BDMA(wn + w_pos, 1);
     M4D_W6_BLOCK2(1, 2, 2, 4)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2) { W6L_WAIT(1); } else { W6L_WAIT(8); }
+    W6L_WAIT(8);
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 2: A(3) from t1, t3; columns 0, 2 of t(chunk + 1)
@@ -411,26 +368,24 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     read_t(rnext, 0);
     M4D_W6_BLOCK1(2, 3, 3, 6)
     W6L_BDMA(wn + 2 * w_pos, 2);
-    if constexpr (BAR2) W6L_BDMA(wn + w_pos, 1);                                     // position 1 of the next chunk (slot 1 is free)
     pin_t(0);
     M4D_W6_BLOCK2(2, 3, 3, 6)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2) { W6L_WAIT(7); } else { W6L_WAIT(8); }
+    W6L_WAIT(8);
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 3: columns 1, 3 of t(chunk + 1) first (A(chunk + 1, 0) = t0 - t2 needs column ... 0 and 2 only)
-    if constexpr (!BAR2) W6L_BARRIER();
+    W6L_BARRIER();
     M4D_W6_STAMP(0)
     M4D_W6_BLOCK0(3, 0, 0, 7)
-    if constexpr (kRawK == 4) W6L_RAW(rnext_c, chunk & 1, 3);
+    W6L_RAW(rnext_c, chunk & 1, 3);
     read_t(rnext, 1);
     M4D_W6_BLOCK1(3, 0, 0, 6)
-    if constexpr (!BAR2) W6L_BDMA(wn + 3 * w_pos, 3);
+    W6L_BDMA(wn + 3 * w_pos, 3);
     pin_t(1);
     M4D_W6_BLOCK2(3, 0, 0, 6)
     M4D_W6_STAMP(2)
-    if constexpr (BAR2) { if constexpr (kRawK == 4) { W6L_WAIT(1); } else { W6L_WAIT(0); } }
-    else if constexpr (kRawK == 4) { W6L_WAIT(8); } else { W6L_WAIT(7); }
+    W6L_WAIT(8);
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     wc = wn;
@@ -514,24 +469,27 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   if (STAMPS && st && wv == 0) st[1024 + 2] = __builtin_readcyclecounter();
 }
 
-unsigned long long* g_wino6_stamps = nullptr;
-long long g_wino6_bar2_min_wg = 1ll << 40;          // grids of at least this many workgroups run with one barrier per two positions (default: none)
+unsigned long long* g_wino6_stamps = nullptr;       // profiling hook (m4d_wino6_set_stamps): process-wide, NULL = off
+#if M4D_EXPERIMENTS
 int g_wino6_half_max_wg = 0;                       // grids of at most this many workgroups take the half-tile kernel under variant 0 (default: none)
-int g_wino6_variant = 0;                           // 0 / 1 = this file's kernel, 2 = the wide kernel (m4d_wino6w.hip) wherever it applies
+int g_wino6_variant = 0;                           // 0 / 1 = this file's kernel, 2 = the wide kernel (m4d_wino6w.hip), 3 = the half-tile kernel
+#endif
 
 }  // namespace
 
-// m4d_wino6w.hip: 16x16 pixels x all 96 / 128 output channels per workgroup, two passes over the position rows; bit-identical
+extern "C" void m4d_wino6_set_stamps(unsigned long long* device_buffer) { g_wino6_stamps = device_buffer; }
+
+#if M4D_EXPERIMENTS
+// include/m4depth_hip_experiments.h: bit-identical alternatives, measured not faster end to end (DESIGN_HISTORY.md)
+// m4d_wino6w.hip: 16x16 pixels x all 96 / 128 output channels per workgroup, two passes over the position rows
 int m4d_wino6w_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
                       float slope, float* out, void* stream);
-// m4d_wino6h.hip: 16x8 pixels x 64 couts per workgroup (half the tile: twice the workgroups) for small grids; bit-identical
+// m4d_wino6h.hip: 16x8 pixels x 64 couts per workgroup (half the tile: twice the workgroups) for small grids
 int m4d_wino6h_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
                       float slope, float* out, void* stream);
-
-extern "C" void m4d_wino6_set_stamps(unsigned long long* device_buffer) { g_wino6_stamps = device_buffer; }
 extern "C" void m4d_wino6_set_variant(int variant) { g_wino6_variant = variant; }
 extern "C" void m4d_wino6_set_half_tile_max_workgroups(int max_wg) { g_wino6_half_max_wg = max_wg; }
-extern "C" void m4d_wino6_set_two_position_barrier_min_workgroups(int min_wg) { g_wino6_bar2_min_wg = min_wg < 0 ? (1ll << 40) : min_wg; }
+#endif
 
 extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                           int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
@@ -539,27 +497,17 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
   M4D_CHECK_ARG(CoutPad % 64 == 0 && CoutPad >= Cout && Cin % 16 == 0);
   M4D_CHECK_ARG(((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu6) & 15u) == 0));
   M4D_CHECK_ARG((long long)h * w * Cin * 4 < (1ll << 31));                              // one image = one buffer descriptor
+#if M4D_EXPERIMENTS
   {
-    // The wide kernel (m4d_wino6w.hip, same bits): one workgroup per pixel tile instead of one per (tile, 64 couts), every
-    // transformed input element split once for all output channels: ~3 VALU instructions per MFMA instead of 8.7.  Measured
-    // (round 3, DESIGN section 5 / DESIGN_HISTORY): its K loop is 15-25 % shorter per unit of work, but two passes over the
-    // position rows cost two prologues and two LDS-write-bound epilogues per tile -- per layer 0.9x (128 couts) / 1.05x (96
-    // couts) of this kernel alone, 0 % (96-wide layers only) / -11 % (everywhere) end to end.  NOT dispatched by default:
-    // m4d_wino6_set_variant(2) / M4D_WINO6_VARIANT=2 selects it wherever it applies (tests, profiling).
     const bool wide_ok = CoutPad == 128 && Cout > 64 && (Cout & 3) == 0 && ((((uintptr_t)bias) | ((uintptr_t)out)) & 15u) == 0 &&
                          g_wino6_stamps == nullptr;
     if (wide_ok && g_wino6_variant == 2)
       return m4d_wino6w_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
-    // The half-tile kernel (m4d_wino6h.hip, same bits) where this kernel's grid leaves most of the chip idle: level 3 of the
-    // 384x1280 pyramid at batch 1 is 60 workgroups here, 120 there.  Measured (round 3): alone it is 1.05-1.24x faster per layer
-    // on <= 128-workgroup grids (20.4 vs 23.8 us on level 3's 128 -> 128), but it spends 1.7x the CU-time on the same work
-    // (twice the fragment bytes per MFMA), and inside the frame pipeline, where other frames' kernels fill the idle CUs, the
-    // step does not get shorter (1334.6 / 1334.9 / 1329.2 frames/s with the threshold at 0 / 64 / 128 workgroups).  Default
-    // threshold 0 = never; m4d_wino6_set_half_tile_max_workgroups / variant 3 select it.
     const long long wgs = (long long)b * ((w + kT - 1) / kT) * ((h + kT - 1) / kT) * (CoutPad / 64);
     if (g_wino6_stamps == nullptr && (g_wino6_variant == 3 || (g_wino6_variant == 0 && wgs <= g_wino6_half_max_wg)))
       return m4d_wino6h_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
   }
+#endif
   Wino6Args a;
   a.x = x; a.wu = reinterpret_cast<const unsigned char*>(wu6); a.bias = bias; a.out = out;
   a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.n_chunks = Cin / 16; a.slope = slope;
@@ -570,17 +518,14 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
   constexpr size_t lds = lds_epi > lds_loop ? lds_epi : lds_loop;
   static_assert(lds <= 160 * 1024, "LDS budget of one CU");
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
-  // more than 64 KB of dynamic LDS needs the opt-in, per kernel (both instantiations share one function-pointer type: set both)
+  // more than 64 KB of dynamic LDS needs the opt-in, per kernel
   static const bool attr_set = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();                                             // function-local static: initialised once, thread-safe (C++11)
   (void)attr_set;
   if (a.stamps) m4d_launch(conv3x3_wino6_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, a);
-  else if (g_wino6_variant == 4 || (g_wino6_variant == 0 && (long long)grid.x * grid.y >= g_wino6_bar2_min_wg))
-    m4d_launch((conv3x3_wino6_kernel<false, true>), grid, dim3(512), lds, (hipStream_t)stream, a);
   else m4d_launch(conv3x3_wino6_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

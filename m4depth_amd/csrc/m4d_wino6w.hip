@@ -25,6 +25,7 @@
 #include <type_traits>
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
+#include "../../include/m4depth_hip_experiments.h"
 
 namespace {
 

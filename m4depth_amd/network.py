@@ -57,14 +57,15 @@ winograd2_min_workgroups = int(_os.environ.get("M4D_WINO2_MIN_WG", "60"))
 # MFMA kernels, tools/bench_wino6.py -- at 2.67x less matrix-core time); "f32" = the fp32-MFMA kernels everywhere.
 conv_arith = _os.environ.get("M4D_CONV_ARITH", "bf16x3")
 wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
-# Which kernel serves the bf16-split layers (same bits either way; include/m4depth_hip.h m4d_wino6_set_variant): 0 / 1 =
-# m4d_wino6.hip (default), 2 = the wide kernel m4d_wino6w.hip wherever it applies (measured: not faster end to end)
-if _os.environ.get("M4D_WINO6_VARIANT"):
-    lib.m4d_wino6_set_variant(int(_os.environ["M4D_WINO6_VARIANT"]))
-if _os.environ.get("M4D_WINO6_BAR2_MIN_WG"):           # grids from this many workgroups on: one barrier per two positions (default: never)
-    lib.m4d_wino6_set_two_position_barrier_min_workgroups(int(_os.environ["M4D_WINO6_BAR2_MIN_WG"]))
-if _os.environ.get("M4D_WINO6_HALF_MAX_WG"):           # grids up to this many workgroups take the half-tile kernel m4d_wino6h.hip (default 0 = none)
-    lib.m4d_wino6_set_half_tile_max_workgroups(int(_os.environ["M4D_WINO6_HALF_MAX_WG"]))
+# (experiments build only, include/m4depth_hip_experiments.h) which kernel serves the bf16-split layers -- same bits either
+# way: 2 = the wide kernel m4d_wino6w.hip wherever it applies, 3 = the half-tile kernel m4d_wino6h.hip
+if _os.environ.get("M4D_WINO6_VARIANT") or _os.environ.get("M4D_WINO6_HALF_MAX_WG"):
+    from ._lib import require_experiments as _require_experiments
+    _require_experiments("M4D_WINO6_VARIANT / M4D_WINO6_HALF_MAX_WG")
+    if _os.environ.get("M4D_WINO6_VARIANT"):
+        lib.m4d_wino6_set_variant(int(_os.environ["M4D_WINO6_VARIANT"]))
+    if _os.environ.get("M4D_WINO6_HALF_MAX_WG"):       # grids up to this many workgroups take the half-tile kernel (default 0 = none)
+        lib.m4d_wino6_set_half_tile_max_workgroups(int(_os.environ["M4D_WINO6_HALF_MAX_WG"]))
 # The one-launch small-map convolution in the same arithmetic (csrc/m4d_conv.hip conv3x3_small6_kernel).  These launches are
 # bound by how fast ONE CU streams its slice of the weights, not by the matrix core: -2 us per layer on the 240-channel first
 # layers, nothing elsewhere (tools/bench_small_convs.py); +0.8 % frames/s at batch 1.  0 = the fp32-MFMA small-map kernel.
@@ -1251,10 +1252,13 @@ class TapedSequence:
     launches.  Measured (round 3): a chain of small kernels is NOT slowed by chip-filling kernels when
     both are plain stream launches (340 us against ~700 us as soon as either side is a hipGraph replay;
     profiles/r03_stream_vs_graph_probe.txt), yet the whole step is 3 % slower this way than as ONE hipGraph (1326-1338 against
-    1379 frames/s): the step is bound by chip-time, not by the chains.  Kept as the graph-free launcher (same kernels in the
-    same per-stream order: bit-identical results, tests/test_gpu_model.py); ``bench.py --schedule tape``."""
+    1379 frames/s): the step is bound by chip-time, not by the chains.  An EXPERIMENT since round 4: needs a
+    ``make EXPERIMENTS=1`` build of the library (raises otherwise); same kernels in the same per-stream order: bit-identical
+    results (tests/test_gpu_model.py, skipped on the product library); ``bench.py --schedule tape``."""
 
     def __init__(self, model, example, warmup=2, encoder_split=None):
+        from ._lib import require_experiments
+        require_experiments("network.TapedSequence (the launch tape, csrc/m4d_tape.hip)")
         self.model = model
         nt = example["new_traj"]
         self.new_traj = nt.clone() if isinstance(nt, torch.Tensor) else torch.as_tensor(np.asarray(nt))

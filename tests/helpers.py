@@ -124,3 +124,45 @@ def make_fake_dataset(root, kind, n_traj=2, n_frames=7, size=(48, 64), seed=0):
         with open(os.path.join(rec, f"set_{t}", f"traj_{t:04d}.csv"), "w") as fh:
             fh.write("\n".join(lines) + "\n")
     return db, rec
+
+
+class hbm_pressure:
+    """Streaming HBM traffic beside the kernels under test: ``queue(n)`` enqueues ``n`` device-to-device copies of ``mb`` MB on
+    a side stream.  A kernel whose correctness leans on a memory latency (round 3: a hand-counted ``s_waitcnt vmcnt`` one
+    DMA too loose in m4d_wino6.hip) passes on a quiet chip and fails beside this -- the regime of three concurrent
+    batch-32 frame streams, and of the driver's box."""
+
+    def __init__(self, dev, mb=512):
+        import torch
+        self.stream = torch.cuda.Stream(device=dev)
+        n = mb * (1 << 20) // 4
+        self.src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+        self.dst = torch.empty_like(self.src)
+        torch.cuda.synchronize()
+
+    def queue(self, n):
+        import torch
+        with torch.cuda.stream(self.stream):
+            for _ in range(n):
+                self.dst.copy_(self.src)
+
+
+def image_checksums(t):
+    """One int64 per image of a [b, ...] float32 tensor: the sum of its bit patterns."""
+    import torch
+    return t.contiguous().view(torch.int32).reshape(t.shape[0], -1).sum(dim=1, dtype=torch.int64)
+
+
+def assert_replicas_bitwise(t, uniq, what):
+    """Images i and i + k * uniq of ``t`` ([b, ...], b a multiple of ``uniq``) carry the same bits; the message names the
+    tensor, the replicas that differ and where the first one does."""
+    import torch
+    b = t.shape[0]
+    want = t[:uniq].repeat(b // uniq, *([1] * (t.dim() - 1)))
+    if torch.equal(t, want):
+        return
+    ne = (t.contiguous().view(torch.int32) != want.contiguous().view(torch.int32))
+    bad = ne.reshape(b, -1).any(dim=1).nonzero().flatten().tolist()
+    first = ne.nonzero()[0].tolist()
+    raise AssertionError(f"{what}: replicas {bad[:8]}{'...' if len(bad) > 8 else ''} differ from their originals "
+                         f"({int(ne.sum())} elements; first at {first})")

@@ -20,7 +20,8 @@ import torch
 
 from oracle import m4depth_oracle as O
 from m4depth_amd import synthetic as S
-from helpers import F, camera_np, motion_np, to_dev, npy, assert_bits_equal, rel_err
+from helpers import (F, camera_np, motion_np, to_dev, npy, assert_bits_equal, rel_err, assert_replicas_bitwise, hbm_pressure,
+                     image_checksums)
 from test_gpu_model import check_depth_and_parallax
 
 pytestmark = pytest.mark.gpu
@@ -236,12 +237,18 @@ def test_batch32_fullsize_properties(dev):
     ds, dc = to_dev(ts, dev), to_dev(tcam, dev)
     out = model([ds, dc])["depth"].clone()
     assert out.shape == (b, H, Wd, 1) and torch.isfinite(out).all()
-    assert torch.equal(out, out[:uniq].repeat(reps, 1, 1, 1))
+    # replicas, in COMPUTATION order (coarse -> fine; refiner input before the estimates): the first assertion that fails is
+    # where a difference entered, and its message names the level, the tensor and the replicas
+    for l in reversed(range(L)):
+        fin = model.d_estimator.levels[l].last_f_input
+        assert_replicas_bitwise(fin, uniq, f"level {l + 1}: refiner input (encoder / cost volumes)")
+        for key in ("parallax", "depth", "other"):
+            assert_replicas_bitwise(model.last_estimates[-1][l][key], uniq, f"level {l + 1}: {key} (refiner / tail)")
+    assert_replicas_bitwise(out, uniq, "model output")
     for l in range(L):
         k = 2 ** ((l + 1) // 2)
         fin = model.d_estimator.levels[l].last_f_input
         assert fin.shape == (b, H >> (l + 1), Wd >> (l + 1), 58 * k + 6) and torch.isfinite(fin).all()
-        assert torch.equal(fin, fin[:uniq].repeat(reps, 1, 1, 1)), f"level {l}: refiner input replicas differ"
         est = model.last_estimates[-1][l]
         cam_l = {"f": dc["f"] / float(2 ** (l + 1)), "c": dc["c"] / float(2 ** (l + 1))}
         assert torch.equal(est["depth"], M.parallax2depth(est["parallax"], ds[-1]["rot"], ds[-1]["trans"], cam_l))
@@ -259,6 +266,44 @@ def test_batch32_fullsize_properties(dev):
         c = npy(model.last_estimates[-1][l]["parallax"][:uniq])
         rp = rel_err(a, c, 1e-12)
         assert rp.max() < 1e-4 and np.median(rp) < 2e-6, (l, rp.max(), np.median(rp))
+
+
+def test_batch32_determinism_under_memory_pressure(dev):
+    """The forward is a pure function of its inputs (m4depth_network.py:351-369) -- also when its kernels share HBM with a
+    streaming load.  configs[2]'s geometry (384x1280, 6 levels, batch 32 = 2 sequences x 16), four forwards, each queued
+    behind 200 x 1 GB of device-to-device copy traffic on a side stream: every retained tensor's per-image checksum equal
+    across replicas and across runs.  Round 3's library fails this in ~40 % of the forwards (tools/determinism_stress.py,
+    profiles/r04_determinism_stress_old_vs_fixed.txt): m4d_wino6.hip's prologue issued raw(1) before B(2), and position 1 of
+    the first chunk read a fragment piece that no wait covered."""
+    import m4depth_amd as M
+    L, H, Wd, T, uniq, reps = 6, 384, 1280, 3, 2, 16
+    W = S.init_weights(L, seed=21, last_layer_gain=S.WELL_CONDITIONED_GAIN)
+    samples, cam = S.make_sequence(uniq, T, H, Wd, seed=78, motion="lateral")
+    ts, tcam = _tiled(samples, cam, reps)
+    model = _model(dev, L, W)
+    ds, dc = to_dev(ts, dev), to_dev(tcam, dev)
+    load = hbm_pressure(dev)
+    first = None
+    for run in range(4):
+        model.reset_state()
+        load.queue(200)
+        out = model([ds, dc])["depth"]
+        sums = []
+        for l in reversed(range(L)):
+            sums.append((f"level {l + 1} refiner input", image_checksums(model.d_estimator.levels[l].last_f_input)))
+            for key in ("parallax", "depth", "other"):
+                sums.append((f"level {l + 1} {key}", image_checksums(model.last_estimates[-1][l][key])))
+        sums.append(("model output", image_checksums(out)))
+        torch.cuda.synchronize()
+        sums = [(n, c.cpu().numpy()) for n, c in sums]
+        for n, c in sums:
+            bad = np.nonzero(c != np.tile(c[:uniq], reps))[0]
+            assert len(bad) == 0, f"run {run}, {n}: replicas {bad.tolist()[:8]} differ from their originals"
+        if first is None:
+            first = sums
+        for (n, c), (_, c0) in zip(sums, first):
+            bad = np.nonzero(c != c0)[0]
+            assert len(bad) == 0, f"run {run}, {n}: images {bad.tolist()[:8]} differ from run 0"
 
 
 # ------------------------------------------------------------------------------- float64 truth

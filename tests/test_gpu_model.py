@@ -403,7 +403,11 @@ def test_taped_sequence_is_bitwise_the_graphed_sequence(dev):
     against network.GraphedSequence (one hipGraph) and the eager forward: the same depth bits, stable over replays, new input
     batches picked up through the static buffers; the recorded tapes hold every launch of the step."""
     import m4depth_amd as M
-    from m4depth_amd import network as net
+    from m4depth_amd import network as net, _lib
+    if not _lib.has_experiments:
+        with pytest.raises(RuntimeError, match="experiments build"):
+            net.TapedSequence(None, None)
+        pytest.skip("the launch tape is an experiment: make EXPERIMENTS=1 (include/m4depth_hip_experiments.h)")
     L, H, Wd, T, b = 4, 96, 160, 4, 2
     W = S.init_weights(L, seed=12)
     samples, cam = S.make_sequence(b, T, H, Wd, seed=55)

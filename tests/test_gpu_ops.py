@@ -447,6 +447,39 @@ def test_winograd_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
     assert torch.equal(got, nops.conv3x3_wino6_bias_act(xd, wd, bd, cout, cpad, slope))          # deterministic
 
 
+@pytest.mark.parametrize("cin", [128, 32, 16])
+def test_winograd_bf16_split_determinism_under_memory_pressure(M, dev, cin):
+    """Regression test of round 3's non-determinism: the level-1 refiner layer geometry at batch 32,
+    200 launches each queued behind streaming HBM copy traffic on a side stream, against the quiet run, bit for bit.  The
+    round-3 library differs in ~4 % of such launches (whole output tiles of 32 couts wrong): the prologue of
+    conv3x3_wino6_kernel issued raw(1) before B(2), so the wait that closes position 0 of the first chunk left B(2)'s third
+    piece in flight and position 1 read it from LDS covered by elapsed time only.  Cin = 32 / 16: two / one K chunk, where
+    the K loop's surplus DMAs (chunks past the last) are in flight when the epilogue reuses the LDS."""
+    from m4depth_amd import network_ops as nops
+    from helpers import hbm_pressure
+    torch.manual_seed(5)
+    b, h, w, cout = 32, 192, 640, 128
+    if cin != 128:
+        b = 8
+    x = torch.randn(b, h, w, cin, device=dev)
+    k = (torch.randn(3, 3, cin, cout) * (2.0 / (9 * cin)) ** 0.5).numpy()
+    bias = torch.randn(cout, device=dev) * 0.1
+    wu, cpad = nops.pack_conv_weights_wino6(k)
+    wd = torch.from_numpy(wu.view(np.int16)).to(dev)
+    quiet = nops.conv3x3_wino6_bias_act(x, wd, bias, cout, cpad, 0.1).clone()
+    torch.cuda.synchronize()
+    load = hbm_pressure(dev)
+    out = torch.empty_like(quiet)
+    n_bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for it in range(200 if cin == 128 else 60):
+        if it % 4 == 0:
+            load.queue(12)
+        out = nops.conv3x3_wino6_bias_act(x, wd, bias, cout, cpad, 0.1)
+        n_bad += (out.view(torch.int32) != quiet.view(torch.int32)).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert int(n_bad) == 0, f"{int(n_bad)} launches under memory pressure differ from the quiet launch"
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout,slope", [(1, 6, 20, 472, 128, 0.1), (2, 12, 40, 240, 128, 0.1), (1, 24, 80, 128, 96, 0.1),
                                                   (1, 7, 9, 100, 40, 1.0), (3, 5, 33, 16, 32, 0.1), (1, 13, 17, 64, 5, 1.0)])
 def test_small_map_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
@@ -821,7 +854,10 @@ def test_wide_bf16_split_winograd_is_bit_identical(dev, b, h, w, cin, cout):
     on whole / ragged / odd-sized maps, batches, 3 and 4 N-tiles, channel counts that are not multiples of 32; and the
     same bits again through the default dispatch."""
     from m4depth_amd import network_ops as nops
+    from m4depth_amd import _lib
     from m4depth_amd._lib import lib
+    if not _lib.has_experiments:
+        pytest.skip("m4d_wino6w.hip / m4d_wino6h.hip are experiments: make EXPERIMENTS=1 (include/m4depth_hip_experiments.h)")
     rng = np.random.default_rng(b * 1000 + h + cin + cout)
     x = to_dev(rng.standard_normal([b, h, w, cin]).astype(F), dev)
     k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
@@ -836,8 +872,6 @@ def test_wide_bf16_split_winograd_is_bit_identical(dev, b, h, w, cin, cout):
         wide2 = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
         lib.m4d_wino6_set_variant(3)                # the half-tile kernel (m4d_wino6h.hip): 16x8 pixels x 64 couts per workgroup
         half = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
-        lib.m4d_wino6_set_variant(4)                # m4d_wino6.hip with one barrier per two positions
-        bar2 = [nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1) for _ in range(5)]
         lib.m4d_wino6_set_variant(0)
         lib.m4d_wino6_set_half_tile_max_workgroups(1 << 20)       # ... and through the grid-size rule of the default variant
         half2 = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1)
@@ -848,7 +882,6 @@ def test_wide_bf16_split_winograd_is_bit_identical(dev, b, h, w, cin, cout):
     assert torch.equal(wide, narrow), f"{int((wide != narrow).sum())} of {narrow.numel()} elements differ"
     assert torch.equal(half, narrow), f"half-tile kernel: {int((half != narrow).sum())} of {narrow.numel()} elements differ"
     assert torch.equal(wide2, wide) and torch.equal(auto, narrow) and torch.equal(half2, half)
-    assert all(torch.equal(o, narrow) for o in bar2), "one barrier per two positions: a race would show as differing repeats"
     ref = O.leaky_relu(O.conv2d_same(npy(x), k, npy(bias), 1), 0.1)
     assert np.max(np.abs(npy(wide) - ref)) < 1e-5 * max(1.0, np.abs(ref).max())
 
@@ -857,7 +890,10 @@ def test_wide_bf16_split_winograd_level1_layer(dev):
     """The 96-wide layer of level 1 (192x640: 480 tiles, 3 N-tiles) through the wide kernel (variant 2): bits equal to the
     default kernel's."""
     from m4depth_amd import network_ops as nops
+    from m4depth_amd import _lib
     from m4depth_amd._lib import lib
+    if not _lib.has_experiments:
+        pytest.skip("m4d_wino6w.hip is an experiment: make EXPERIMENTS=1 (include/m4depth_hip_experiments.h)")
     rng = np.random.default_rng(5)
     x = to_dev(rng.standard_normal([1, 192, 640, 128]).astype(F), dev)
     k = (rng.standard_normal([3, 3, 128, 96]) * np.sqrt(2.0 / (9 * 128))).astype(F)

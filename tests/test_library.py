@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "m4depth_hip.h")).read()
+def header_symbols(name="m4depth_hip.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(m4d_[a-z0-9_]+)\s*\(", txt)))
 
@@ -26,6 +26,27 @@ def test_header_symbols_exported():
     assert sorted(_lib.EXPORTED_SYMBOLS) == syms, "ctypes binding and header disagree"
     assert _lib.lib.m4d_abi_version() == _lib.ABI_VERSION == 3
     assert "gfx950" in _lib.build_info()
+    # the experiments header: its symbols are exported by an EXPERIMENTS=1 build and ONLY by it, and the binding knows them all
+    exp = header_symbols("m4depth_hip_experiments.h")
+    assert sorted(_lib.EXPERIMENT_SYMBOLS) == exp and not set(exp) & set(syms)
+    assert _lib.has_experiments == ("+experiments" in _lib.build_info())
+    for s in exp:
+        assert hasattr(raw, s) == _lib.has_experiments, f"{s}: experiments symbol {'missing from' if _lib.has_experiments else 'present in'} this build"
+
+
+def test_product_library_exports_only_the_header(tmp_path):
+    """Every m4d_* symbol the shared library exports is declared in include/m4depth_hip.h (or, in an experiments build, in
+    include/m4depth_hip_experiments.h): no undeclared entry points, no experiment kernels behind global setters in the
+    product library."""
+    import subprocess
+    from m4depth_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("m4d_")})
+    allowed = set(header_symbols())
+    if _lib.has_experiments:
+        allowed |= set(header_symbols("m4depth_hip_experiments.h"))
+    extra = [e for e in exported if e not in allowed]
+    assert not extra, f"exported but not declared: {extra}"
 
 
 def test_argument_validation_without_gpu():
@@ -61,7 +82,10 @@ def test_cpu_tensor_is_rejected():
 def test_launch_tape_bookkeeping_without_gpu():
     """m4d_tape_begin / _end / _length / _free (csrc/m4d_tape.hip): an empty recording is a valid tape of length 0, nested
     recordings are refused, unknown ids are errors -- no device involved."""
+    from m4depth_amd import _lib
     from m4depth_amd._lib import lib
+    if not _lib.has_experiments:
+        pytest.skip("the launch tape is an experiment: make EXPERIMENTS=1 (include/m4depth_hip_experiments.h)")
     t = lib.m4d_tape_begin()
     assert t >= 0
     assert lib.m4d_tape_begin() == -1                       # this thread is already recording

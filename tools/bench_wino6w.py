@@ -4,6 +4,8 @@ import argparse, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from m4depth_amd import network_ops as nops
+from m4depth_amd._lib import require_experiments
+require_experiments("tools/bench_wino6w.py")
 from m4depth_amd._lib import lib
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=1); ap.add_argument("--iters", type=int, default=20)
 a = ap.parse_args()

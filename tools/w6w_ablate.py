@@ -4,6 +4,8 @@ import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from m4depth_amd import network_ops as nops
+from m4depth_amd._lib import require_experiments
+require_experiments("tools/w6w_ablate.py")
 from m4depth_amd._lib import lib
 raw = ctypes.CDLL(os.path.join(ROOT, "m4depth_amd", "libm4depth_hip.so"))
 dev = torch.device("cuda:0")
