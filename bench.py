@@ -71,6 +71,8 @@ def parse():
     p.add_argument("--sncv-range", type=int, default=3)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--no-configs2", action="store_true", help="skip the batch-32 (BASELINE configs[2]) leg of the default run")
+    p.add_argument("--configs2-steps", type=int, default=5)
     p.add_argument("--eager", action="store_true", help="do not replay the step from a hipGraph")
     p.add_argument("--host-input", action="store_true",
                    help="also report the PCIe-inclusive rate: the RGB / pose batch starts in pinned host memory every step (never `value`)")
@@ -104,15 +106,22 @@ class EventTimer:
         return r
 
     def summary(self):
-        """{(name, level): (launches, mean seconds)}.  A launch that took more than twice the median of its group (a box
-        hiccup: one such launch doubled a batch-32 average in round 3) is left out of the mean and counted in ``self.outliers``."""
-        out, self.outliers = {}, {}
+        """{(name, level): (launches, mean seconds)} -- the RAW mean over every launch (the "average launch duration" of the
+        roofline contract).  ``self.stats[key]`` carries the median, the mean without launches slower than twice the median
+        (a box hiccup: one such launch doubled a batch-32 average in round 3) and how many those were, for every group."""
+        out, self.stats, self.outliers = {}, {}, {}
         for k, v in self.events.items():
             d = np.array([a.elapsed_time(b) for a, b in v], np.float64)
             keep = d <= 2.0 * np.median(d)
             self.outliers[k] = int((~keep).sum())
-            out[k] = (int(keep.sum()), float(d[keep].mean()) * 1e-3)
+            self.stats[k] = {"mean_us": round(float(d.mean()) * 1e3, 2), "median_us": round(float(np.median(d)) * 1e3, 2),
+                             "trimmed_mean_us": round(float(d[keep].mean()) * 1e3, 2), "launches": int(d.size),
+                             "slower_than_2x_median": int((~keep).sum())}
+            out[k] = (int(d.size), float(d.mean()) * 1e-3)
         return out
+
+    def reset(self):
+        self.events = {}
 
 
 def make_batch(args, rank, dev, torch):
@@ -230,6 +239,152 @@ def cpu_baseline(height, width, levels, rd, rs, seq_len=4, repeats=3, seed=1235,
                      f"dscv_range={rd} sncv_range={rs}; numpy float32 oracle (a restatement, not TensorFlow); 1 warm-up + "
                      f"{repeats} timed runs, median; BLAS limited to {cores} threads, elementwise numpy single-threaded"}
     return res, ((W, samples, cam, out, seq) if keep else None)
+
+
+def kernel_rooflines(args, batch, timer, net, eager_steps):
+    """The roofline objects of one batch size from the HIP-event brackets of ``eager_steps`` eager steps: the dominant kernel
+    (level-1 128 -> 128 refiner convolution) against the MFMA peak, the level-1 cost-volume kernels and the whole hand-written
+    hot path of a full frame against the HBM peak."""
+    rep = {}
+    summ = timer.summary()
+    traffic, traffic_note = load_traffic(batch)
+    rep["traffic_note"] = traffic_note
+
+    def tr(name):
+        ent = traffic.get(name)
+        return None if ent is None else ent["bytes"]
+
+    # -- the dominant kernel of the step: the level-1 128->128 refiner convolution
+    conv = summ.get(("conv", "lvl1.conv1"))
+    h1, w1 = args.height >> 1, args.width >> 1
+    if conv is not None:
+        n, sec = conv
+        wino = net._use_winograd(batch, h1, w1, 128, 128, 1)
+        flops_direct = 2.0 * 9 * 128 * 128 * h1 * w1 * batch
+        flops_wino = 2.0 * 16 * 128 * 128 * ((h1 + 1) // 2) * ((w1 + 1) // 2) * batch      # one multiply-add per (position, cin, cout)
+        if wino == 6:           # float32 operands as 3 bf16 terms each: 6 bf16 MFMA products per float32 multiply
+            flops_exec, peak, key = 6.0 * flops_wino, BF16_MFMA_PEAK_TFLOPS, "wino6_l1_128_128"
+            kname = ("conv3x3_wino6_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3), float32 operands split into 3 bf16 "
+                     "terms, 6 bf16 MFMA products each, float32 accumulate; bias+leaky-relu fused)")
+        elif wino:
+            flops_exec, peak, key = flops_wino, FP32_MFMA_PEAK_TFLOPS, "wino_l1_128_128"
+            kname = "conv3x3_wino4_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3) on fp32 MFMA, bias+leaky-relu fused)"
+        else:
+            flops_exec, peak, key = flops_direct, FP32_MFMA_PEAK_TFLOPS, "conv_l1_128_128"
+            kname = "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)"
+        tf_exec = flops_exec / sec / 1e12
+        rep["roofline"] = {
+            "kernel": kname, "bound": "mfma", "achieved": round(tf_exec, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(tf_exec / peak, 4), "traffic": tr(key),
+            "pmc_mfma_busy_frac": None if key not in traffic else traffic[key].get("mfma_busy_frac"),
+            "traffic_kernel": None if key not in traffic else traffic[key].get("kernel"),
+            "executed_mfma_flops_per_launch": flops_exec,
+            "frac_of_sustained_mfma_rate": round(tf_exec / BF16_MFMA_SUSTAINED_TFLOPS, 4) if wino == 6 else None,
+            "sustained_mfma_tflops_on_random_operands": BF16_MFMA_SUSTAINED_TFLOPS if wino == 6 else None,
+            "note": "achieved / frac = MFMA flops the kernel executes / time against the dense peak of the MFMA type it issues "
+                    "(bf16 2500 TFLOP/s for the split kernel: 6 bf16 products per float32 multiply-add of the Winograd form, "
+                    "2*16*Cin*Cout per 2x2 output tile; fp32 MFMA 157.3 otherwise).  frac_of_sustained_mfma_rate = the same against what "
+                    "a bare MFMA loop sustains on real operand values on this pool (0.66 of nominal, "
+                    "profiles/r03_mfma_rate_vs_operand_values.txt).  Timing ablations of the kernel (DESIGN.md section 6): MFMAs + "
+                    "row-transform reads + prologue / epilogue 73 % of the launch, LDS-DMA traffic 13 %, the exact 3-way operand "
+                    "split + input transform 8.5 %, fragment reads 5 %; float32_equivalent_tflops = the float32 multiply-adds of "
+                    "the Winograd form it replaces / time (fp32-MFMA peak 157.3), algorithmic_* = the layer's "
+                    "direct-convolution flops / time",
+            "float32_equivalent_tflops": round(flops_wino / sec / 1e12, 2) if wino else round(tf_exec, 2),
+            "float32_equivalent_frac_of_fp32_mfma_peak": round((flops_wino if wino else flops_direct) / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_flops_per_launch": flops_direct,
+            "algorithmic_tflops": round(flops_direct / sec / 1e12, 2),
+            "algorithmic_bytes_per_launch": 4 * (2 * 128 * h1 * w1 * batch + 9 * 128 * 128),
+            "avg_launch_us": round(sec * 1e6, 2), "launches": n,
+            "launch_time_stats": timer.stats.get(("conv", "lvl1.conv1"))}
+    # -- the level-1 cost-volume kernels alone
+    bytes_l1 = level_bytes(args, batch, 1)
+    for name in ("front", "dscv", "sncv"):
+        ent = summ.get((name, 1))
+        if ent is None:
+            continue
+        n, sec = ent
+        gbs = bytes_l1[name] / sec / 1e9
+        rep[f"roofline_{name}"] = {"kernel": f"{name}_level1", "bound": "hbm", "achieved": round(gbs, 1),
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                   "traffic": tr(name),
+                                   "traffic_kernel": None if name not in traffic else traffic[name].get("kernel"),
+                                   "algorithmic_bytes_per_launch": bytes_l1[name],
+                                   "avg_launch_us": round(sec * 1e6, 2), "launches": n,
+                                   "launch_time_stats": timer.stats.get((name, 1))}
+    # -- SURVEY 8(d): the whole hand-written hot path of one full frame against the HBM roofline
+    full_frames = eager_steps * (args.seq_len - 1)
+    per_kernel = {}
+    for (name, lvl), (n, sec) in summ.items():
+        if name in HOT_KERNELS and name != "resize" and lvl != "reset":
+            per_kernel[name] = per_kernel.get(name, 0.0) + n * sec / max(full_frames, 1)
+    if per_kernel:
+        hp_bytes, resize_bytes = hotpath_bytes_per_frame(args, batch)
+        t_all = sum(per_kernel.values())
+        t_no_tail = sum(v for k, v in per_kernel.items() if k != "tail")
+        gbs = hp_bytes / t_all / 1e9
+        rep["roofline_hotpath"] = {
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_frame": hp_bytes, "us_per_frame": round(t_all * 1e6, 1),
+            "us_per_frame_by_kernel": {k: round(v * 1e6, 1) for k, v in sorted(per_kernel.items())},
+            "us_per_launch_by_kernel_and_level": {f"{k[0]}.{k[1]}": round(v[1] * 1e6, 1) for k, v in sorted(summ.items(), key=lambda kv: str(kv[0]))
+                                                  if k[0] in HOT_KERNELS},
+            "frac_excluding_tail": round(hp_bytes / t_no_tail / 1e9 / HBM_PEAK_GBS, 4) if t_no_tail > 0 else None,
+            "note": "SURVEY 8(d) bytes of one full frame (all levels; x batch) / the summed HIP-event time of the hand-written "
+                    "level kernels of that frame (level_pre + normalise, DSCV, SNCV, refiner tail) / 8 TB/s.  The tail kernel "
+                    "also contains the last two refiner convolutions (32->16, 16->5), so `frac` is a lower bound for the "
+                    "path proper; frac_excluding_tail drops that kernel's time but keeps its level_post bytes.  Eager "
+                    "launches: levels <= 6000 pixels run DSCV and SNCV as two launches here, one merged launch in the graph"}
+    if "roofline" not in rep and "roofline_hotpath" in rep:
+        rep["roofline"] = rep["roofline_hotpath"]
+    return rep
+
+
+def eager_timed_steps(model, data, timer, batch, steps, torch):
+    """``steps`` eager test_steps with the kernel timer on, each queued behind a GPU-side spin (see main)."""
+    timer.enabled = True
+    spin_cycles = int(60e6 * max(1, batch) ** 0.5)
+    for _ in range(steps):
+        torch.cuda._sleep(spin_cycles)
+        model.test_step(data)
+        torch.cuda.synchronize()
+    timer.enabled = False
+    return steps
+
+
+def configs2_leg(args, weights, dev, timer, torch, M, net, D):
+    """BASELINE configs[2] ("384x1280 6-level seq_len=4, batch 32, 1xMI355X (HBM-roofline run)") inside the default run: the
+    same test_step at batch 32 -- own model (own recurrent state), hipGraph replay, ``--configs2-steps`` timed replays between
+    synchronisations, then two eager steps under the kernel timer for the roofline fractions.  Returns the ``configs2``
+    object of the JSON line (same definitions as the top-level keys)."""
+    import argparse
+    a2 = argparse.Namespace(**vars(args))
+    a2.batch, a2.steps = 32, args.configs2_steps
+    model = M.M4Depth(nbre_levels=args.levels, dscv_range=args.dscv_range, sncv_range=args.sncv_range)
+    model.load_numpy_weights(weights, dev)
+    model.compile(metrics=M.default_metrics())
+    data = make_batch(a2, 0, dev, torch)
+    was = net.kernel_timer
+    net.kernel_timer = None
+    model.test_step(data)                                # eager warm-up: state and scratch allocation
+    runner = net.GraphedSequence(model, data)
+    data.update({k: v for k, v in runner.input_buffers().items()})
+    step = lambda: model.graphed_test_step(data, runner)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    dt, _ = timed_region(step, a2.steps, D, dev, torch.cuda.synchronize)
+    frames = a2.batch * a2.seq_len * a2.steps
+    rep = {"workload": "BASELINE configs[2]: 384x1280, 6 levels, seq_len 4 (frame 0 = new_traj), batch 32, one GPU, hipGraph replay",
+           "value": round(frames / dt, 2), "unit": "frames/s", "steps": a2.steps, "ms_per_step": round(dt / a2.steps * 1e3, 3),
+           "full_frames_per_s": round(frames * (a2.seq_len - 1) / a2.seq_len / dt, 2)}
+    if was is not None:
+        net.kernel_timer = timer
+        timer.reset()
+        n = eager_timed_steps(model, data, timer, a2.batch, 2, torch)
+        rep.update(kernel_rooflines(a2, a2.batch, timer, net, n))
+    net.kernel_timer = was
+    return rep
 
 
 def _free_port():
@@ -399,14 +554,16 @@ def main():
     # Every timed eager step is queued behind a GPU-side spin (torch.cuda._sleep): the host enqueues the step's launches and
     # event records while the GPU spins, so an event pair brackets the kernel's execution, not the host's launch latency
     # (without it the small kernels of the coarse levels read 3-10x too long: the GPU runs ahead of the eager host loop).
+    n_eager = 0
     if not args.no_kernel_timing:
-        timer.enabled = True
-        spin_cycles = int(60e6 * max(1, args.batch) ** 0.5)
-        for _ in range(min(args.steps, 5)):
-            torch.cuda._sleep(spin_cycles)
-            model.test_step(data)
-            torch.cuda.synchronize()
-        timer.enabled = False
+        n_eager = eager_timed_steps(model, data, timer, args.batch, min(args.steps, 5), torch)
+
+    roof1 = kernel_rooflines(args, args.batch, timer, net, n_eager) if (timer.events and rank == 0) else {}
+    # BASELINE configs[2] beside the default configs[1] line (one GPU, default workload only): the same step at batch 32
+    configs2 = None
+    if (world == 1 and args.batch == 1 and not args.no_configs2 and not args.eager and args.in_flight == 1 and args.schedule == "graph"
+            and (args.height, args.width, args.levels, args.seq_len) == (384, 1280, 6, 4)):
+        configs2 = configs2_leg(args, weights, dev, timer, torch, M, net, D)
 
     if rank != 0:
         return
@@ -420,7 +577,9 @@ def main():
                       "tools/bench_wino6.py; parity.vs_float64_oracle below) -- not a reduced-precision path; "
                       "M4D_CONV_ARITH=f32 runs the fp32-MFMA kernels instead",
         "metric_note": "value counts every frame of the sequence the reference's test_step processes, including frame 0, "
-                       "which carries new_traj and only runs the encoder + state reset; full_frames_per_s excludes it",
+                       "which carries new_traj and only runs the encoder + state reset; full_frames_per_s excludes it.  "
+                       "north_star's target (>= 500 frames/s/GPU at 6 levels) is compared with full_frames_per_s -- the "
+                       "stricter reading: frames that run the whole cost-volume path",
         "AbsRel": round(metrics[0], 6), "sequence_batches_in_flight": args.in_flight,
         "launch": "eager" if args.eager else ("launch tapes (csrc/m4d_tape.hip) replayed as plain stream launches, one HIP stream per frame"
                                                   if args.schedule == "tape" else
@@ -437,97 +596,9 @@ def main():
         "hot_path": "libm4depth_hip.so (HIP, gfx950)"})
     if host_rate is not None:
         out["host_input_frames_per_s"] = round(host_rate, 2)
-    if timer.events:
-        summ = timer.summary()
-        traffic, traffic_note = load_traffic(args.batch)
-        out["traffic_note"] = traffic_note
-
-        def tr(name):
-            ent = traffic.get(name)
-            return None if ent is None else ent["bytes"]
-
-        # -- the dominant kernel of the step: the level-1 128->128 refiner convolution
-        conv = summ.get(("conv", "lvl1.conv1"))
-        h1, w1 = args.height >> 1, args.width >> 1
-        if conv is not None:
-            n, sec = conv
-            wino = net._use_winograd(args.batch, h1, w1, 128, 128, 1)
-            flops_direct = 2.0 * 9 * 128 * 128 * h1 * w1 * args.batch
-            flops_wino = 2.0 * 16 * 128 * 128 * ((h1 + 1) // 2) * ((w1 + 1) // 2) * args.batch      # one multiply-add per (position, cin, cout)
-            if wino == 6:           # float32 operands as 3 bf16 terms each: 6 bf16 MFMA products per float32 multiply
-                flops_exec, peak, key = 6.0 * flops_wino, BF16_MFMA_PEAK_TFLOPS, "wino6_l1_128_128"
-                kname = ("conv3x3_wino6_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3), float32 operands split into 3 bf16 "
-                         "terms, 6 bf16 MFMA products each, float32 accumulate; bias+leaky-relu fused)")
-            elif wino:
-                flops_exec, peak, key = flops_wino, FP32_MFMA_PEAK_TFLOPS, "wino_l1_128_128"
-                kname = "conv3x3_wino4_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3) on fp32 MFMA, bias+leaky-relu fused)"
-            else:
-                flops_exec, peak, key = flops_direct, FP32_MFMA_PEAK_TFLOPS, "conv_l1_128_128"
-                kname = "conv3x3_mfma_kernel<4,3,1> (level-1 refiner 128->128, bias+leaky-relu fused)"
-            tf_exec = flops_exec / sec / 1e12
-            out["roofline"] = {
-                "kernel": kname, "bound": "mfma", "achieved": round(tf_exec, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(tf_exec / peak, 4), "traffic": tr(key),
-                "pmc_mfma_busy_frac": None if key not in traffic else traffic[key].get("mfma_busy_frac"),
-                "traffic_kernel": None if key not in traffic else traffic[key].get("kernel"),
-                "executed_mfma_flops_per_launch": flops_exec,
-                "frac_of_sustained_mfma_rate": round(tf_exec / BF16_MFMA_SUSTAINED_TFLOPS, 4) if wino == 6 else None,
-                "sustained_mfma_tflops_on_random_operands": BF16_MFMA_SUSTAINED_TFLOPS if wino == 6 else None,
-                "note": "achieved / frac = MFMA flops the kernel executes / time against the dense peak of the MFMA type it issues "
-                        "(bf16 2500 TFLOP/s for the split kernel: 6 bf16 products per float32 multiply-add of the Winograd form, "
-                        "2*16*Cin*Cout per 2x2 output tile; fp32 MFMA 157.3 otherwise).  frac_of_sustained_mfma_rate = the same against what "
-                        "a bare MFMA loop sustains on real operand values on this pool (0.66 of nominal, "
-                        "profiles/r03_mfma_rate_vs_operand_values.txt).  Timing ablations of the kernel (DESIGN.md section 6): MFMAs + "
-                        "row-transform reads + prologue / epilogue 73 % of the launch, LDS-DMA traffic 13 %, the exact 3-way operand "
-                        "split + input transform 8.5 %, fragment reads 5 %; float32_equivalent_tflops = the float32 multiply-adds of "
-                        "the Winograd form it replaces / time (fp32-MFMA peak 157.3), algorithmic_* = the layer's "
-                        "direct-convolution flops / time",
-                "float32_equivalent_tflops": round(flops_wino / sec / 1e12, 2) if wino else round(tf_exec, 2),
-                "float32_equivalent_frac_of_fp32_mfma_peak": round((flops_wino if wino else flops_direct) / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                "algorithmic_flops_per_launch": flops_direct,
-                "algorithmic_tflops": round(flops_direct / sec / 1e12, 2),
-                "algorithmic_bytes_per_launch": 4 * (2 * 128 * h1 * w1 * args.batch + 9 * 128 * 128),
-                "avg_launch_us": round(sec * 1e6, 2), "launches": n,
-                "launches_left_out_as_outliers": timer.outliers.get(("conv", "lvl1.conv1"), 0)}
-        # -- the level-1 cost-volume kernels alone
-        bytes_l1 = level_bytes(args, args.batch, 1)
-        for name in ("front", "dscv", "sncv"):
-            ent = summ.get((name, 1))
-            if ent is None:
-                continue
-            n, sec = ent
-            gbs = bytes_l1[name] / sec / 1e9
-            out[f"roofline_{name}"] = {"kernel": f"{name}_level1", "bound": "hbm", "achieved": round(gbs, 1),
-                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                       "traffic": tr(name),
-                                       "traffic_kernel": None if name not in traffic else traffic[name].get("kernel"),
-                                       "algorithmic_bytes_per_launch": bytes_l1[name],
-                                       "avg_launch_us": round(sec * 1e6, 2), "launches": n}
-        # -- the whole hand-written hot path of one full frame against the HBM roofline
-        full_frames = min(args.steps, 5) * (args.seq_len - 1)
-        per_kernel = {}
-        for (name, lvl), (n, sec) in summ.items():
-            if name in HOT_KERNELS and name != "resize" and lvl != "reset":
-                per_kernel[name] = per_kernel.get(name, 0.0) + n * sec / max(full_frames, 1)
-        if per_kernel:
-            hp_bytes, resize_bytes = hotpath_bytes_per_frame(args, args.batch)
-            t_all = sum(per_kernel.values())
-            t_no_tail = sum(v for k, v in per_kernel.items() if k != "tail")
-            gbs = hp_bytes / t_all / 1e9
-            out["roofline_hotpath"] = {
-                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_frame": hp_bytes, "us_per_frame": round(t_all * 1e6, 1),
-                "us_per_frame_by_kernel": {k: round(v * 1e6, 1) for k, v in sorted(per_kernel.items())},
-                "us_per_launch_by_kernel_and_level": {f"{k[0]}.{k[1]}": round(v[1] * 1e6, 1) for k, v in sorted(summ.items(), key=lambda kv: str(kv[0]))
-                                                      if k[0] in HOT_KERNELS},
-                "frac_excluding_tail": round(hp_bytes / t_no_tail / 1e9 / HBM_PEAK_GBS, 4) if t_no_tail > 0 else None,
-                "note": "SURVEY 8(d) bytes of one full frame (all levels; x batch) / the summed HIP-event time of the hand-written "
-                        "level kernels of that frame (level_pre + normalise, DSCV, SNCV, refiner tail) / 8 TB/s.  The tail kernel "
-                        "also contains the last two refiner convolutions (32->16, 16->5), so `frac` is a lower bound for the "
-                        "path proper; frac_excluding_tail drops that kernel's time but keeps its level_post bytes.  Eager "
-                        "launches: levels <= 6000 pixels run DSCV and SNCV as two launches here, one merged launch in the graph"}
-        if "roofline" not in out and "roofline_hotpath" in out:
-            out["roofline"] = out["roofline_hotpath"]
+    out.update(roof1)
+    if configs2 is not None:
+        out["configs2"] = configs2
     if not args.no_cpu_baseline and world == 1:
         cb, (W, samples, cam, ref, ref_seq) = cpu_baseline(args.height, args.width, args.levels, args.dscv_range, args.sncv_range,
                                                            seq_len=args.seq_len, keep=True)
