@@ -175,6 +175,12 @@ void m4d_wino_set_stamps(unsigned long long* device_buffer);
  * Replaces the same tf.keras Conv2D + leaky_relu pairs as m4d_conv3x3_wino2_bias_act (m4depth_network.py:101-131). */
 int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                int Cin, int Cout, int CoutPad, float slope, float* out, void* stream);
+/* The same call with the kernel named: 0 = chosen from the grid (what m4d_conv3x3_wino6_bias_act does), 1 = one workgroup
+ * per (16x16-pixel tile, 64 output channels) (csrc/m4d_wino6.hip), 2 = persistent workgroups, one per CU, each walking a
+ * contiguous range of (tile, cout group) units with the DMA stream continuing across unit boundaries (csrc/m4d_wino6p.hip;
+ * Cin >= 32).  Bit-identical results; an argument, not process state: tests and A/B timing use it. */
+int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, const float* bias, int b, int h, int w,
+                                 int Cin, int Cout, int CoutPad, float slope, float* out, int kernel, void* stream);
 /* Profiling only (tools/wino6_phases.py): per-position cycle stamps of the first 64 workgroups; NULL switches it off. */
 void m4d_wino6_set_stamps(unsigned long long* device_buffer);
 

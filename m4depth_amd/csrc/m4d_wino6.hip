@@ -469,6 +469,13 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   if (STAMPS && st && wv == 0) st[1024 + 2] = __builtin_readcyclecounter();
 }
 
+// Grids of at least this many (tile, 64-cout) units run on the persistent kernel (m4d_wino6p.hip): 8 per CU of the 256.  Measured
+// (round 4, profiles/r04_wino6_persistent.txt): alone it is 1.05-1.07x on the level-1 layers at batch 1 (960 units), 1.09-1.21x
+// at batch 8 (7680), 0.93-0.97x where a workgroup gets a single unit (its four-pass epilogue in two ring slots is slower than
+// the one-shot epilogue); inside the frame pipeline the batch-1 step does not get shorter with it (1396 vs 1401 frames/s, 4
+// interleaved runs: static unit ranges against the dispatcher's dynamic placement beside other frames' kernels), the batch-32
+// step does (+3.6 %, 1988 -> 2060 frames/s).
+constexpr long long kPersistentMinUnits = 2048;
 unsigned long long* g_wino6_stamps = nullptr;       // profiling hook (m4d_wino6_set_stamps): process-wide, NULL = off
 #if M4D_EXPERIMENTS
 int g_wino6_half_max_wg = 0;                       // grids of at most this many workgroups take the half-tile kernel under variant 0 (default: none)
@@ -491,12 +498,31 @@ extern "C" void m4d_wino6_set_variant(int variant) { g_wino6_variant = variant; 
 extern "C" void m4d_wino6_set_half_tile_max_workgroups(int max_wg) { g_wino6_half_max_wg = max_wg; }
 #endif
 
+// m4d_wino6p.hip: the same arithmetic with persistent workgroups (one per CU) walking (tile, cout group) units; bit-identical
+int m4d_wino6p_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
+                      float slope, float* out, void* stream);
+
 extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                           int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
+  return m4d_conv3x3_wino6_bias_act_k(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, 0, stream);
+}
+
+extern "C" int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, const float* bias, int b, int h, int w,
+                                            int Cin, int Cout, int CoutPad, float slope, float* out, int kernel, void* stream) {
   M4D_CHECK_ARG(x && wu6 && bias && out && b > 0 && h > 0 && w > 0 && Cin >= 16 && Cout > 0);
   M4D_CHECK_ARG(CoutPad % 64 == 0 && CoutPad >= Cout && Cin % 16 == 0);
   M4D_CHECK_ARG(((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu6) & 15u) == 0));
   M4D_CHECK_ARG((long long)h * w * Cin * 4 < (1ll << 31));                              // one image = one buffer descriptor
+  M4D_CHECK_ARG(kernel >= 0 && kernel <= 2 && (kernel != 2 || Cin >= 32));
+  {
+    // kernel 0 = by grid size: the persistent kernel (m4d_wino6p.hip) on grids of many units per CU -- there it saves the
+    // per-unit prologue, fetches a tile's halo once for its cout groups and stores 256-byte runs; smaller grids keep this
+    // file's kernel (a cheaper epilogue, and the dispatcher places its workgroups dynamically beside other frames' kernels)
+    const long long units = (long long)b * ((w + kT - 1) / kT) * ((h + kT - 1) / kT) * (CoutPad / 64);
+    const bool persistent = kernel == 2 || (kernel == 0 && Cin >= 32 && units >= kPersistentMinUnits);
+    if (persistent && g_wino6_stamps == nullptr)
+      return m4d_wino6p_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
+  }
 #if M4D_EXPERIMENTS
   {
     const bool wide_ok = CoutPad == 128 && Cout > 64 && (Cout & 3) == 0 && ((((uintptr_t)bias) | ((uintptr_t)out)) & 15u) == 0 &&

@@ -57,6 +57,10 @@ winograd2_min_workgroups = int(_os.environ.get("M4D_WINO2_MIN_WG", "60"))
 # MFMA kernels, tools/bench_wino6.py -- at 2.67x less matrix-core time); "f32" = the fp32-MFMA kernels everywhere.
 conv_arith = _os.environ.get("M4D_CONV_ARITH", "bf16x3")
 wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
+# Which kernel serves those layers (an ARGUMENT of m4d_conv3x3_wino6_bias_act_k, same bits either way): 0 = the library chooses
+# from the grid (persistent workgroups, csrc/m4d_wino6p.hip, wherever a CU gets more than one (tile, 64-cout) unit), 1 = one
+# workgroup per unit always (csrc/m4d_wino6.hip), 2 = persistent always.  A/B timing only.
+wino6_kernel = int(_os.environ.get("M4D_WINO6_KERNEL", "0"))
 # (experiments build only, include/m4depth_hip_experiments.h) which kernel serves the bf16-split layers -- same bits either
 # way: 2 = the wide kernel m4d_wino6w.hip wherever it applies, 3 = the half-tile kernel m4d_wino6h.hip
 if _os.environ.get("M4D_WINO6_VARIANT") or _os.environ.get("M4D_WINO6_HALF_MAX_WG"):
@@ -380,7 +384,8 @@ class _Conv3x3SameTF(torch.nn.Module):
         wino = _use_winograd(eff_b, h_, w_, cin_, self.out_channels, self.stride)
         if wino == 6:
             wu, cpad = self._packed_weights_wino6(cin_)
-            return _timed("conv", self.tag, lambda: nops.conv3x3_wino6_bias_act(x_nhwc, wu, self.bias, self.out_channels, cpad, act))
+            return _timed("conv", self.tag, lambda: nops.conv3x3_wino6_bias_act(x_nhwc, wu, self.bias, self.out_channels, cpad, act,
+                                                                                kernel=wino6_kernel))
         if wino:
             wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8, cin_)     # cin_ > Cin: zero-padded input
             fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act

@@ -356,15 +356,16 @@ def conv3x3_small6_bias_act(x, wp6, bias, cout, cout_pad, slope=0.1):
     return out
 
 
-def conv3x3_wino6_bias_act(x, wu6, bias, cout, cout_pad, slope=0.1):
+def conv3x3_wino6_bias_act(x, wu6, bias, cout, cout_pad, slope=0.1, kernel=0):
     """3x3 stride-1 TF-'SAME' convolution + bias + leaky_relu(slope): Winograd F(2x2,3x3), float32 operands split into
-    three bf16 terms, six bf16 MFMA products per term pair, float32 accumulation (csrc/m4d_wino6.hip)."""
+    three bf16 terms, six bf16 MFMA products per term pair, float32 accumulation.  ``kernel``: 0 = chosen from the grid,
+    1 = one workgroup per (tile, 64 couts) (csrc/m4d_wino6.hip), 2 = persistent workgroups (csrc/m4d_wino6p.hip); same bits."""
     x = as_f32(x, "x")
     b, h, w, cin = x.shape
     out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
-    check(lib.m4d_conv3x3_wino6_bias_act(dptr(x, "x"), dptr(wu6, "wu6", torch.int16), dptr(bias, "bias"), b, h, w, cin,
-                                         int(cout), int(cout_pad), float(slope), dptr(out), stream_ptr()),
-          "m4d_conv3x3_wino6_bias_act")
+    check(lib.m4d_conv3x3_wino6_bias_act_k(dptr(x, "x"), dptr(wu6, "wu6", torch.int16), dptr(bias, "bias"), b, h, w, cin,
+                                           int(cout), int(cout_pad), float(slope), dptr(out), int(kernel), stream_ptr()),
+          "m4d_conv3x3_wino6_bias_act_k")
     return out
 
 

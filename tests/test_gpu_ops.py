@@ -447,6 +447,40 @@ def test_winograd_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
     assert torch.equal(got, nops.conv3x3_wino6_bias_act(xd, wd, bd, cout, cpad, slope))          # deterministic
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,slope", [
+    (1, 192, 640, 128, 128, 0.1),     # the level-1 layer: 960 units on 256 workgroups (3-4 per workgroup, 8 K chunks)
+    (1, 192, 640, 64, 128, 0.1),      # 4 chunks
+    (1, 192, 640, 128, 96, 0.1),      # a quarter-empty second cout group
+    (1, 192, 640, 96, 64, 0.1),       # one cout group per tile: 480 units, 6 chunks
+    (4, 100, 130, 48, 120, 0.1),      # odd chunk count (the raw-buffer parity flips per unit), ragged tiles, unit ranges crossing images
+    (3, 100, 130, 32, 192, 1.0),      # two chunks (the shortest unit: both raw prefetches are the next unit's), three cout groups
+    (2, 70, 150, 240, 66, 0.1),       # 15 chunks, Cout % 4 != 0: scalar stores
+    (1, 40, 40, 64, 64, 0.1),         # 9 units: fewer than CUs, one unit per workgroup
+    (9, 33, 17, 80, 70, 0.1),         # many small images
+])
+def test_persistent_winograd_is_bitwise_the_one_tile_kernel(M, dev, b, h, w, cin, cout, slope):
+    """m4d_wino6p.hip (persistent workgroups walking (tile, cout group) units, the K loop's DMA stream continuing across
+    unit boundaries, four-pass epilogue in two ring slots) against m4d_wino6.hip (one workgroup per unit): the same float32
+    bits -- same products, same accumulation order, same association in the output transform -- through the explicit
+    kernel argument of m4d_conv3x3_wino6_bias_act_k and through the default dispatch; repeated launches agree."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(b * 1000 + h + cin + cout)
+    x = to_dev(rng.standard_normal([b, h, w, cin]).astype(F), dev)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = to_dev((0.1 * rng.standard_normal([cout])).astype(F), dev)
+    wu6, cpad = nops.pack_conv_weights_wino6(k)
+    wud = torch.from_numpy(wu6.view("int16")).to(dev)
+    one = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, slope, kernel=1)
+    per = [nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, slope, kernel=2) for _ in range(3)]
+    auto = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, slope)
+    for o in per:
+        ne = o.view(torch.int32) != one.view(torch.int32)
+        assert not bool(ne.any()), f"{int(ne.sum())} of {one.numel()} elements differ; first at (b,y,x,c) {ne.nonzero()[0].tolist()}"
+    assert torch.equal(auto, one)
+    ref = O.leaky_relu(O.conv2d_same(npy(x), k, npy(bias), 1), slope) if slope != 1.0 else O.conv2d_same(npy(x), k, npy(bias), 1)
+    assert np.max(np.abs(npy(per[0]) - ref)) < 1e-5 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("cin", [128, 32, 16])
 def test_winograd_bf16_split_determinism_under_memory_pressure(M, dev, cin):
     """Regression test of round 3's non-determinism: the level-1 refiner layer geometry at batch 32,
@@ -466,18 +500,18 @@ def test_winograd_bf16_split_determinism_under_memory_pressure(M, dev, cin):
     bias = torch.randn(cout, device=dev) * 0.1
     wu, cpad = nops.pack_conv_weights_wino6(k)
     wd = torch.from_numpy(wu.view(np.int16)).to(dev)
-    quiet = nops.conv3x3_wino6_bias_act(x, wd, bias, cout, cpad, 0.1).clone()
+    quiet = nops.conv3x3_wino6_bias_act(x, wd, bias, cout, cpad, 0.1, kernel=1).clone()
     torch.cuda.synchronize()
     load = hbm_pressure(dev)
-    out = torch.empty_like(quiet)
-    n_bad = torch.zeros((), dtype=torch.int64, device=dev)
-    for it in range(200 if cin == 128 else 60):
-        if it % 4 == 0:
-            load.queue(12)
-        out = nops.conv3x3_wino6_bias_act(x, wd, bias, cout, cpad, 0.1)
-        n_bad += (out.view(torch.int32) != quiet.view(torch.int32)).any().to(torch.int64)
-    torch.cuda.synchronize()
-    assert int(n_bad) == 0, f"{int(n_bad)} launches under memory pressure differ from the quiet launch"
+    for kernel in ((1, 2) if cin >= 32 else (1,)):       # one workgroup per unit (m4d_wino6.hip), persistent (m4d_wino6p.hip)
+        n_bad = torch.zeros((), dtype=torch.int64, device=dev)
+        for it in range(200 if cin == 128 else 60):
+            if it % 4 == 0:
+                load.queue(12)
+            out = nops.conv3x3_wino6_bias_act(x, wd, bias, cout, cpad, 0.1, kernel=kernel)
+            n_bad += (out.view(torch.int32) != quiet.view(torch.int32)).any().to(torch.int64)
+        torch.cuda.synchronize()
+        assert int(n_bad) == 0, f"kernel {kernel}: {int(n_bad)} launches under memory pressure differ from the quiet launch"
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,slope", [(1, 6, 20, 472, 128, 0.1), (2, 12, 40, 240, 128, 0.1), (1, 24, 80, 128, 96, 0.1),

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 declare -A vals
 for ((i = 0; i < R; ++i)); do
   for cfg in "$@"; do
-    v=$(env $cfg python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-kernel-timing 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
+    v=$(env $cfg python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-configs2 $AB_BENCH_ARGS 2>/dev/null | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])")
     vals["$cfg"]+="$v "
   done
 done
