@@ -89,6 +89,13 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& a0, bf16x8& a1, b
   a0 = __builtin_bit_cast(bf16x8, p0); a1 = __builtin_bit_cast(bf16x8, p1); a2 = __builtin_bit_cast(bf16x8, p2);
 }
 
+// one 16-byte store as inline asm: the compiler can neither split it nor merge it with the general path's element stores
+__device__ __forceinline__ void w6_store16(float* p, const float (&v)[4]) {
+  typedef float w6_f32x4 __attribute__((ext_vector_type(4)));
+  const w6_f32x4 d = {v[0], v[1], v[2], v[3]};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");   // s_nop: the store-data hazard hipcc covers for its own stores
+}
+
 template <bool STAMPS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3x3_wino6_kernel(const Wino6Args a) {
@@ -420,6 +427,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
   const bool vec_ok = (a.Cout & 3) == 0;
   const bool whole = tile_x + kT <= a.w && tile_y + kT <= a.h;      // uniform: no per-store bounds tests on interior tiles
+  const bool fast = whole && vec_ok && ng * 64 + 64 <= a.Cout;      // ... and every cout quad of the group is real
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int item = it * 512 + t;                 // (N-tile, M-tile, tile in M-tile, cout quad)
@@ -448,12 +456,14 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     }
     const int ox = tile_x + 2 * tx2, oy = tile_y + 2 * ty2;
     float* op = oimg + ((long long)oy * a.w + ox) * a.Cout + co;
-    if (whole && vec_ok && co + 3 < a.Cout) {
+    if (fast) {
+      // UNIFORM condition and nothing but 16-byte stores in this arm (inline asm): under the per-lane condition of rounds 2-3
+      // hipcc merged this arm with the guarded one below and stored three of the four pixels as separate dwords -- 128-byte
+      // runs in 4-byte pieces, the slowest pattern of tools/micro/store_issue_probe.hip
 #pragma unroll
       for (int l = 0; l < 2; ++l)
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-          *reinterpret_cast<float4*>(op + ((long long)l * a.w + k) * a.Cout) = make_float4(y[k][l][0], y[k][l][1], y[k][l][2], y[k][l][3]);
+        for (int k = 0; k < 2; ++k) w6_store16(op + ((long long)l * a.w + k) * a.Cout, y[k][l]);
     } else if (co < a.Cout) {
 #pragma unroll
       for (int l = 0; l < 2; ++l)
@@ -461,7 +471,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
         for (int k = 0; k < 2; ++k)
           if (ox + k < a.w && oy + l < a.h) {
             float* o2 = op + ((long long)l * a.w + k) * a.Cout;
-            if (vec_ok && co + 3 < a.Cout) *reinterpret_cast<float4*>(o2) = make_float4(y[k][l][0], y[k][l][1], y[k][l][2], y[k][l][3]);
+            if (vec_ok && co + 3 < a.Cout) w6_store16(o2, y[k][l]);
             else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) o2[e] = y[k][l][e]; }
           }
     }

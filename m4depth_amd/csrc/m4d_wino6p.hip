@@ -72,6 +72,14 @@ static_assert(pLds <= 160 * 1024, "LDS budget of one CU");
 
 __host__ __device__ constexpr int p_slot_off(int slot) { return slot < 2 ? pOffSlot01 + slot * pSlotBytes : pOffSlot23 + (slot - 2) * pSlotBytes; }
 
+// one 16-byte store, as inline asm: the compiler can neither split it nor merge it with the guarded element stores of the
+// general path (a VM op the K loop's vmcnt counts tolerate: an older store only makes a wait stricter)
+__device__ __forceinline__ void p6_store16(float* p, const float (&v)[4]) {
+  typedef float p6_f32x4 __attribute__((ext_vector_type(4)));
+  const p6_f32x4 d = {v[0], v[1], v[2], v[3]};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");   // s_nop: the store-data hazard hipcc covers for its own stores
+}
+
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3x3_wino6p_kernel(const Wino6PArgs a) {
   extern __shared__ __align__(16) float lds[];
@@ -247,6 +255,9 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
   if (NEXT) { pin_a(A[((c) & 1) ^ 1]); P6_PIPE(4, valu) }                                                              \
   __builtin_amdgcn_sched_barrier(0);
 
+  if (M4D_W6P_ABL & 16) {                           // experiment: de-phase the CUs (their epilogue store bursts coincide otherwise)
+    for (int i = 0; i < (int)(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // ---- true prologue (once per workgroup): raw(0), B(0), B(1), raw(1) | B(2), B(3) -- the state every later unit starts from
   Unit cur = decode(u0);
   set_raw_source(cur);
@@ -368,6 +379,7 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
       float* oimg = a.out + (long long)cur.bi * a.h * a.w * a.Cout;
       const bool vec_ok = (a.Cout & 3) == 0;
       const bool whole = cur.tile_x + pT <= a.w && cur.tile_y + pT <= a.h;      // uniform: no per-store bounds tests on interior tiles
+      const bool fast = whole && vec_ok && cur.ng * 64 + 64 <= a.Cout;
       int te = t;
       asm volatile("" : "+v"(te));                                              // the epilogue's addressing is computed here, not kept live across the K loop
       const int cq = te & 15, tl = te >> 4;                                     // this thread's item: tile 0..31 of the pass's M-tile, cout quad 0..15
@@ -392,16 +404,18 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
         float* op = oimg + ((long long)oy * a.w + ox) * a.Cout + co;
         if (M4D_W6P_ABL & 2) {
           if (y[0][0] + y[1][1] + y[0][2] + y[1][3] == 123.456f) op[0] = 1.f;      // keeps the arithmetic alive
-        } else if (whole && vec_ok && co + 3 < a.Cout) {
-#pragma unroll
-          for (int l = 0; l < 2; ++l)
-            *reinterpret_cast<float4*>(op + (long long)l * a.w * a.Cout) = make_float4(y[l][0], y[l][1], y[l][2], y[l][3]);
+        } else if (fast) {
+          // UNIFORM condition (whole tile, every cout quad of the group real, 16-byte rows) and nothing but the two 16-byte
+          // stores in this arm: under a per-lane condition hipcc merged this arm with the guarded one below and stored the
+          // second row as four separate dwords (the 12.8-B/clk pattern of tools/micro/store_issue_probe.hip, 4x slower)
+          p6_store16(op, y[0]);
+          p6_store16(op + (long long)a.w * a.Cout, y[1]);
         } else if (co < a.Cout && ox < a.w) {
 #pragma unroll
           for (int l = 0; l < 2; ++l)
             if (oy + l < a.h) {
               float* o2 = op + (long long)l * a.w * a.Cout;
-              if (vec_ok && co + 3 < a.Cout) *reinterpret_cast<float4*>(o2) = make_float4(y[l][0], y[l][1], y[l][2], y[l][3]);
+              if (vec_ok && co + 3 < a.Cout) p6_store16(o2, y[l]);
               else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) o2[e] = y[l][e]; }
             }
         }

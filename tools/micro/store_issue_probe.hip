@@ -7,6 +7,7 @@
 // hipcc -O3 --offload-arch=gfx950 tools/micro/store_issue_probe.hip -o /tmp/store_probe && /tmp/store_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 template <int PATTERN>
@@ -34,8 +35,8 @@ __global__ void __launch_bounds__(512) probe(float* out, long long per_wg_floats
   if (t == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-int main() {
-  const int wgs = 256, nu = 32;
+int main(int argc, char** argv) {
+  const int wgs = argc > 1 ? atoi(argv[1]) : 256, nu = 32;      // fewer workgroups than CUs: the per-CU store path without the HBM write limit
   const long long per_wg = 16384ll * nu;
   float* out; unsigned long long* cyc;
   hipMalloc(&out, sizeof(float) * per_wg * wgs);
