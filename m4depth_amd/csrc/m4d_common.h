@@ -48,6 +48,18 @@ inline void m4d_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t l
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
 }
 
+// ---- one 16-byte global store that stays ONE instruction ------------------------------------------------------------------
+// hipcc if-converts `if (vector_ok) *(float4*)p = v; else for (e) if (c + e < C) p[e] = v[e];` into guarded ELEMENT stores
+// for both arms (dword / dwordx2 / dwordx3 pieces): a CU issues 128-byte runs of 4-byte pieces at 16 B/clk against ~100 B/clk
+// for 16-byte pieces (tools/micro/store_issue_probe.hip, profiles/r04_wino6_persistent.txt).  As inline asm the store can
+// neither be split nor merged with the element arm; the s_nop covers the store-data hazard hipcc handles for its own stores
+// (the data VGPRs of a > 8-byte store must not be overwritten in the next wait states).
+__device__ __forceinline__ void m4d_store16(float* p, float v0, float v1, float v2, float v3) {
+  typedef float m4d_f32x4 __attribute__((ext_vector_type(4)));
+  const m4d_f32x4 d = {v0, v1, v2, v3};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
+}
+
 // ---- exact 3-way bf16 split of a pair of float32 values (m4d_wino6*.hip) ---------------------------------------------------
 // Default (M4D_SPLIT_RN = 1): round to nearest -- hi = bf16(v), mid = bf16(v - hi), lo = (v - hi) - mid (exact, 8 significant
 // bits left: its upper half IS the conversion); 13 VALU instructions per pair, two of them v_cvt_pk_bf16_f32 (8 issue

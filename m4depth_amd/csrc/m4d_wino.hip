@@ -258,7 +258,7 @@ conv3x3_wino_kernel(const WinoArgs a) {
               if (oy + l < a.h) {
                 float* op = oimg + ((long long)(oy + l) * a.w + ox) * a.Cout + co;
                 const float* y = l ? y1 : y0;
-                if (vec_ok) *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+                if (vec_ok) m4d_store16(op, y[0], y[1], y[2], y[3]);   // (m4d_common.h: one instruction, not guarded pieces)
                 else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) op[e] = y[e]; }
               }
             }
@@ -494,7 +494,7 @@ conv3x3_wino2_kernel(const WinoArgs a) {
               if (oy + l < a.h) {
                 float* op = oimg + ((long long)(oy + l) * a.w + ox) * a.Cout + co;
                 const float* y = l ? y1 : y0;
-                if (vec_ok) *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+                if (vec_ok) m4d_store16(op, y[0], y[1], y[2], y[3]);   // (m4d_common.h: one instruction, not guarded pieces)
                 else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) op[e] = y[e]; }
               }
             }
@@ -793,7 +793,7 @@ conv3x3_wino4_kernel(const WinoArgs a) {
             if (oy + l < a.h) {
               float* op = oimg + ((long long)(oy + l) * a.w + ox) * a.Cout + co;
               const float* y = l ? y1 : y0;
-              if (vec_ok) *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+              if (vec_ok) m4d_store16(op, y[0], y[1], y[2], y[3]);   // (m4d_common.h: one instruction, not guarded pieces)
               else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) op[e] = y[e]; }
             }
           }

@@ -89,13 +89,6 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& a0, bf16x8& a1, b
   a0 = __builtin_bit_cast(bf16x8, p0); a1 = __builtin_bit_cast(bf16x8, p1); a2 = __builtin_bit_cast(bf16x8, p2);
 }
 
-// one 16-byte store as inline asm: the compiler can neither split it nor merge it with the general path's element stores
-__device__ __forceinline__ void w6_store16(float* p, const float (&v)[4]) {
-  typedef float w6_f32x4 __attribute__((ext_vector_type(4)));
-  const w6_f32x4 d = {v[0], v[1], v[2], v[3]};
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");   // s_nop: the store-data hazard hipcc covers for its own stores
-}
-
 template <bool STAMPS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3x3_wino6_kernel(const Wino6Args a) {
@@ -463,7 +456,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 #pragma unroll
       for (int l = 0; l < 2; ++l)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) w6_store16(op + ((long long)l * a.w + k) * a.Cout, y[k][l]);
+        for (int k = 0; k < 2; ++k) m4d_store16(op + ((long long)l * a.w + k) * a.Cout, y[k][l][0], y[k][l][1], y[k][l][2], y[k][l][3]);
     } else if (co < a.Cout) {
 #pragma unroll
       for (int l = 0; l < 2; ++l)
@@ -471,7 +464,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
         for (int k = 0; k < 2; ++k)
           if (ox + k < a.w && oy + l < a.h) {
             float* o2 = op + ((long long)l * a.w + k) * a.Cout;
-            if (vec_ok && co + 3 < a.Cout) w6_store16(o2, y[k][l]);
+            if (vec_ok && co + 3 < a.Cout) m4d_store16(o2, y[k][l][0], y[k][l][1], y[k][l][2], y[k][l][3]);
             else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) o2[e] = y[k][l][e]; }
           }
     }

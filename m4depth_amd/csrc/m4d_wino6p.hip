@@ -72,14 +72,6 @@ static_assert(pLds <= 160 * 1024, "LDS budget of one CU");
 
 __host__ __device__ constexpr int p_slot_off(int slot) { return slot < 2 ? pOffSlot01 + slot * pSlotBytes : pOffSlot23 + (slot - 2) * pSlotBytes; }
 
-// one 16-byte store, as inline asm: the compiler can neither split it nor merge it with the guarded element stores of the
-// general path (a VM op the K loop's vmcnt counts tolerate: an older store only makes a wait stricter)
-__device__ __forceinline__ void p6_store16(float* p, const float (&v)[4]) {
-  typedef float p6_f32x4 __attribute__((ext_vector_type(4)));
-  const p6_f32x4 d = {v[0], v[1], v[2], v[3]};
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");   // s_nop: the store-data hazard hipcc covers for its own stores
-}
-
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3x3_wino6p_kernel(const Wino6PArgs a) {
   extern __shared__ __align__(16) float lds[];
@@ -408,14 +400,14 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
           // UNIFORM condition (whole tile, every cout quad of the group real, 16-byte rows) and nothing but the two 16-byte
           // stores in this arm: under a per-lane condition hipcc merged this arm with the guarded one below and stored the
           // second row as four separate dwords (the 12.8-B/clk pattern of tools/micro/store_issue_probe.hip, 4x slower)
-          p6_store16(op, y[0]);
-          p6_store16(op + (long long)a.w * a.Cout, y[1]);
+          m4d_store16(op, y[0][0], y[0][1], y[0][2], y[0][3]);
+          m4d_store16(op + (long long)a.w * a.Cout, y[1][0], y[1][1], y[1][2], y[1][3]);
         } else if (co < a.Cout && ox < a.w) {
 #pragma unroll
           for (int l = 0; l < 2; ++l)
             if (oy + l < a.h) {
               float* o2 = op + (long long)l * a.w * a.Cout;
-              if (vec_ok && co + 3 < a.Cout) p6_store16(o2, y[l]);
+              if (vec_ok && co + 3 < a.Cout) m4d_store16(o2, y[l][0], y[l][1], y[l][2], y[l][3]);
               else { for (int e = 0; e < 4; ++e) if (co + e < a.Cout) o2[e] = y[l][e]; }
             }
         }
