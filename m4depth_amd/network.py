@@ -169,6 +169,14 @@ fused_refiner_tail = _os.environ.get("M4D_FUSED_TAIL", "1") == "1"
 # capture in which two streams wait on each other's events alternately (tools/debug_multistream_capture.py).
 # 0 disables (single stream).
 level_pipeline_streams = int(_os.environ.get("M4D_LEVEL_PIPELINE", "8"))
+# Redundant (transitively implied) cross-stream waits of the pipelined forward.  They change how ROCm's hipGraph executor lays the
+# captured graph out on its streams, so they are knobs, measured (profiles/r04_graph_executor.txt):
+#   M4D_PIPE_FORK_FRAMES = frames (beside frame 0 and the late encoder's first frame) whose stream waits for the fork event
+#   explicitly: "all" (rounds 1-3) or a list like "1,2"; M4D_PIPE_SKIP_ENC_WAIT=1: a frame of the late encoder batch does not
+#   wait for that batch's event when the previous frame (same batch) is waited for anyway.
+_pf = _os.environ.get("M4D_PIPE_FORK_FRAMES", "1,2")
+pipeline_fork_frames = None if _pf == "all" else {int(v) for v in _pf.split(",") if v.strip() != ""}
+pipeline_skip_implied_encoder_wait = _os.environ.get("M4D_PIPE_SKIP_ENC_WAIT", "1") == "1"
 # Encoding every frame on its own stream too (instead of one encoder pass batched over the frames, before the
 # decoder) was measured slightly slower (633 vs 643 frames/s at batch 1): the batched pass has 4x fewer launches.
 # Encoder level 0 (conv 3->16, DINL, conv 16->16 stride 2) as m4d_enc_level0_fwd: three passes that recompute the first
@@ -810,11 +818,23 @@ class DepthEstimatorPyramid(torch.nn.Module):
         fork = torch.cuda.Event()
         fork.record(main)
         keep.append(fork)
-        for st in streams:
-            st.wait_event(fork)                       # encoder outputs / inputs are produced on the main stream
+        n_fr = len(traj_samples)
+
+        def needs_fork(f):
+            """Does the stream whose first frame is ``f`` wait for the fork event itself?  Frame 0 and a frame that launches
+            an encoder pass must; for the others the wait is implied by their wait for the previous frame's level -- but the
+            redundant edge is not neutral: ROCm 7.2's hipGraph executor assigns nodes to its four streams from the edges it
+            sees.  ``pipeline_fork_frames`` = the frames that keep the explicit wait."""
+            if f == 0 or f >= n_fr or f_maps_pyrs is None:
+                return True
+            if f_maps_pyrs[f] is None and f_maps_pyrs[f - 1] is not None:          # the first frame of the late encoder batch
+                return True
+            return pipeline_fork_frames is None or f in pipeline_fork_frames
+        for i_st, st in enumerate(streams):
+            if needs_fork(i_st):
+                st.wait_event(fork)                   # encoder outputs / inputs are produced on the main stream
         done = {}
         late_encoder = None
-        n_fr = len(traj_samples)
         f_pyrs = [None] * n_fr
         d_est = [None] * n_fr                         # per frame: estimates so far, coarse -> fine
         # (Measured, tools/step_profile.py + tools/ab_bench.sh: the late encoder batch below is independent of the first
@@ -845,7 +865,9 @@ class DepthEstimatorPyramid(torch.nn.Module):
                             enc_done.record(st)
                             keep.append(enc_done)
                             late_encoder = (seq_i, enc_done)
-                        else:                            # a later frame of that batch: its features come from another stream
+                        elif not (pipeline_skip_implied_encoder_wait and seq_i - 1 >= late_encoder[0]):
+                            # a later frame of that batch: its features come from another stream (implied by the wait on the
+                            # previous frame's level below when that frame is of the same encoder batch)
                             st.wait_event(late_encoder[1])
                     if seq_i > 0:
                         st.wait_event(done[(seq_i - 1, lvl)])
@@ -1281,8 +1303,13 @@ class TapedSequence:
         self.n_lvls = L = len(model.d_estimator.levels)
         self.split = min(max(1, pipeline_encoder_split if encoder_split is None else int(encoder_split)), T)
         model.prepack()
-        self.streams = [torch.cuda.Stream() for _ in range(T)]        # [0]: encoder batch a + reset frame; [t]: full frame t
-        self.s_enc = torch.cuda.Stream()
+        # Stream priorities (plain streams honour them, a hipGraph's executor streams do not): the frames are consumed in
+        # order, so frame t's kernels go ahead of frame t + 1's whenever both have workgroups waiting for a CU.
+        # M4D_TAPE_PRIORITIES = comma list for streams[0..T-1] + the late-encoder stream (torch: lower = more urgent).
+        prio = [int(v) for v in _os.environ.get("M4D_TAPE_PRIORITIES", "").split(",") if v.strip() != ""]
+        pr = lambda i: prio[min(i, len(prio) - 1)] if prio else 0
+        self.streams = [torch.cuda.Stream(priority=pr(t)) for t in range(T)]   # [0]: encoder batch a + reset frame; [t]: full frame t
+        self.s_enc = torch.cuda.Stream(priority=pr(T))
         self.ctx = {}
         segs = [("enc_a", self.streams[0], self._seg_enc_a)]
         if self.split < T:
