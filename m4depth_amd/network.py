@@ -843,9 +843,13 @@ class DepthEstimatorPyramid(torch.nn.Module):
         # Issue order = anti-diagonals of the (frame, level) grid: level l of frame t right after level l of frame
         # t-1.  Every stream still sees its own frame coarse -> fine, but the launch (and hipGraph node) order puts
         # the next frame's coarse levels ahead of the current frame's fine ones.
-        for diag in range(n_fr + n_lvls - 1):
-            for seq_i in range(max(0, diag - n_lvls + 1), min(n_fr, diag + 1)):
-                l = diag - seq_i
+        # (The capture order matters to ROCm's hipGraph executor: a node's FIRST-captured child continues its parent's node list
+        # on the same executor stream.  Frame-major order gives the same layout as this one; later-frame-first inside a diagonal
+        # or level-major order turn the lists level-major and cost 16 %: profiles/r04_graph_executor.txt.)
+        order = [(seq_i, diag - seq_i) for diag in range(n_fr + n_lvls - 1)
+                 for seq_i in range(max(0, diag - n_lvls + 1), min(n_fr, diag + 1))]
+        for seq_i, l in order:
+            if True:
                 lvl = n_lvls - 1 - l
                 sample = traj_samples[seq_i]
                 st = streams[seq_i % n_streams]
