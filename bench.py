@@ -264,7 +264,11 @@ def kernel_rooflines(args, batch, timer, net, eager_steps):
         flops_wino = 2.0 * 16 * 128 * 128 * ((h1 + 1) // 2) * ((w1 + 1) // 2) * batch      # one multiply-add per (position, cin, cout)
         if wino == 6:           # float32 operands as 3 bf16 terms each: 6 bf16 MFMA products per float32 multiply
             flops_exec, peak, key = 6.0 * flops_wino, BF16_MFMA_PEAK_TFLOPS, "wino6_l1_128_128"
-            kname = ("conv3x3_wino6_kernel (level-1 refiner 128->128, Winograd F(2x2,3x3), float32 operands split into 3 bf16 "
+            units = batch * ((h1 + 15) // 16) * ((w1 + 15) // 16) * 2
+            persistent = net.wino6_kernel == 2 or (net.wino6_kernel == 0 and units >= 2048)      # csrc/m4d_wino6.hip kPersistentMinUnits
+            kname = (("conv3x3_wino6p_kernel (persistent workgroups, csrc/m4d_wino6p.hip; " if persistent else
+                      "conv3x3_wino6_kernel (one workgroup per (tile, 64 couts), csrc/m4d_wino6.hip; ") +
+                     "level-1 refiner 128->128, Winograd F(2x2,3x3), float32 operands split into 3 bf16 "
                      "terms, 6 bf16 MFMA products each, float32 accumulate; bias+leaky-relu fused)")
         elif wino:
             flops_exec, peak, key = flops_wino, FP32_MFMA_PEAK_TFLOPS, "wino_l1_128_128"

@@ -9,7 +9,8 @@ ap.add_argument("--batch", type=int, default=1); ap.add_argument("--cin", type=i
 ap.add_argument("--cout", type=int, default=128); ap.add_argument("--h", type=int, default=192)
 ap.add_argument("--w", type=int, default=640); ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--winograd", type=int, default=0, help="0 = direct MFMA kernel, 1 / 2 = fp32-MFMA Winograd kernel 1 / 2(4), 6 = the bf16-split Winograd kernel")
-ap.add_argument("--variant", type=int, default=0, help="m4d_wino6_set_variant: 0 / 1 = m4d_wino6.hip, 2 = the wide kernel, 3 = the half-tile kernel")
+ap.add_argument("--variant", type=int, default=0, help="(experiments build) m4d_wino6_set_variant: 2 = the wide kernel, 3 = the half-tile kernel")
+ap.add_argument("--kernel", type=int, default=0, help="m4d_conv3x3_wino6_bias_act_k: 0 = the library's choice, 1 = one workgroup per unit, 2 = persistent")
 a = ap.parse_args()
 if a.variant:
     from m4depth_amd._lib import lib
@@ -20,7 +21,7 @@ k = torch.randn(3, 3, a.cin, a.cout) * (2.0 / (9 * a.cin)) ** 0.5
 bias = torch.randn(a.cout, device=dev) * 0.1
 if a.winograd == 6:
     wp, cpad = nops.pack_conv_weights_wino6(k.numpy()); wp = wp.view("int16")
-    fn = nops.conv3x3_wino6_bias_act
+    fn = lambda *args_: nops.conv3x3_wino6_bias_act(*args_, kernel=a.kernel)
 elif a.winograd:
     wp, cpad = nops.pack_conv_weights_winograd(k.numpy(), chunk=8 if a.winograd == 2 else 16)
     fn = nops.conv3x3_wino2_bias_act if a.winograd == 2 else nops.conv3x3_wino_bias_act

@@ -5,9 +5,9 @@
 #   kernel-trace durations of the roofline layer alone (level-1 refiner 128->128, batch 1 and 32); PMC passes (counters
 #   only, one rocprofv3 run per counter group): HBM traffic (profiles/pmc_traffic.json) and the matrix-core / issue counters
 #   of the roofline kernel.
-# usage (GPU box, repo root): bash tools/collect_round_profiles.sh r03   -> gpurun_out/<tag>/ ; copy what is cited into profiles/
+# usage (GPU box, repo root): bash tools/collect_round_profiles.sh r04   -> gpurun_out/<tag>/ ; copy what is cited into profiles/
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -57,12 +57,14 @@ done
     timeout 120 python tools/bench_tail.py --iters 100 $SZ 2>&1 | grep "^refiner"; timeout 120 python tools/bench_tail.py --iters 100 $SZ --split 2>&1 | grep "^refiner"; done; } > $OUT/refiner_tail_split_vs_fp32.txt
 need $OUT/refiner_tail_split_vs_fp32.txt
 
-# the round-3 Winograd variants (wide / half-tile): per-layer times and bit equality
-timeout 300 python tools/bench_wino6w.py > $OUT/wino6_variants.txt 2>&1; need $OUT/wino6_variants.txt
-timeout 120 ./build_tmp/l2_stream_probe > $OUT/l2_stream_probe.txt 2>&1 || true
-# plain stream launches vs hipGraph replays of small kernels beside chip-filling ones; the graph-free launcher end to end
-timeout 300 python tools/stream_vs_graph_probe.py > $OUT/stream_vs_graph_probe.txt 2>&1; need $OUT/stream_vs_graph_probe.txt
-timeout 600 python bench.py --steps 20 --schedule tape --no-cpu-baseline --no-kernel-timing > $OUT/bench_b1_tape.json 2> $OUT/bench_b1_tape.err; need $OUT/bench_b1_tape.json
+# the persistent bf16-split Winograd kernel against the one-unit kernel: per-layer times and bit equality (batch 1 and 8)
+{ timeout 300 python tools/bench_wino6p.py; timeout 300 python tools/bench_wino6p.py --batch 8 --iters 5; } > $OUT/wino6_persistent_vs_one_unit.txt 2>&1; need $OUT/wino6_persistent_vs_one_unit.txt
+# queue-annotated timeline of one step (the hipGraph executor's layout)
+rm -rf /tmp/prof_${TAG}_q
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${TAG}_q -o t -- python bench.py --steps 20 --no-cpu-baseline --no-kernel-timing --no-configs2 > /dev/null 2>&1
+TRACE=$(find /tmp/prof_${TAG}_q -name "*kernel_trace.csv" | head -1)
+[ -n "$TRACE" ] && python tools/queue_trace.py "$TRACE" > $OUT/queue_trace_b1_graph.txt 2> /dev/null
+need $OUT/queue_trace_b1_graph.txt
 
 timeout 600 python tools/bench_train.py > $OUT/bench_train.json 2>/dev/null; need $OUT/bench_train.json
 head -c 400 $OUT/bench_b1.json; echo

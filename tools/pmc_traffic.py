@@ -39,8 +39,8 @@ TARGETS = {
                 [CS + "m4d_sncv.hip", CS + "m4d_sncv_small.h", CS + "m4d_common.h"]),
     "wino_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "2"], ["conv3x3_wino4_kernel"],
                         [CS + "m4d_wino.hip"]),
-    "wino6_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "6"], ["conv3x3_wino6_kernel"],
-                         [CS + "m4d_wino6.hip"]),
+    "wino6_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "6"], ["conv3x3_wino6_kernel", "conv3x3_wino6p_kernel"],
+                         [CS + "m4d_wino6.hip", CS + "m4d_wino6p.hip"]),
     "conv_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "0"], ["conv3x3_mfma_kernel"],
                         [CS + "m4d_conv.hip"]),
 }
