@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libm4depth_hip.so")
 
-ABI_VERSION = 3               # M4D_ABI_VERSION of include/m4depth_hip.h this binding was written for
+ABI_VERSION = 4               # M4D_ABI_VERSION of include/m4depth_hip.h this binding was written for
 
 _c_fp = ctypes.c_void_p       # device pointers travel as void*
 _c_int = ctypes.c_int
