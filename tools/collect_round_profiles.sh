@@ -31,7 +31,7 @@ for B in 1 32; do
   rm -rf /tmp/prof_${TAG}_b$B
   STEPS=20; [ $B = 32 ] && STEPS=4
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_b$B -o t -- \
-      python bench.py --steps $STEPS --batch $B --no-cpu-baseline --no-kernel-timing > $OUT/bench_b${B}_under_rocprof.json 2> $OUT/bench_b${B}_under_rocprof.err
+      python bench.py --steps $STEPS --batch $B --no-cpu-baseline --no-kernel-timing --no-configs2 > $OUT/bench_b${B}_under_rocprof.json 2> $OUT/bench_b${B}_under_rocprof.err
   STATS=$(find /tmp/prof_${TAG}_b$B -name "*kernel_stats.csv" | head -1); TRACE=$(find /tmp/prof_${TAG}_b$B -name "*kernel_trace.csv" | head -1)
   if [ -z "$STATS" ] || [ -z "$TRACE" ]; then echo "[collect] rocprofv3 wrote no kernel stats / trace for batch $B" >&2; FAILED="$FAILED rocprof_b$B"; continue; fi
   python tools/summarize_rocprof.py "$STATS" 45 > $OUT/bench_b${B}_kernel_stats_summary.txt
