@@ -47,7 +47,7 @@ typedef int p6_i32x4 __attribute__((ext_vector_type(4)));
 
 struct Wino6PArgs {
   const float* x; const unsigned char* wu; const float* bias; float* out;
-  int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y, units;
+  int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y, units, team;
   float slope;
 };
 
@@ -85,14 +85,34 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
   const int n_tiles = a.tiles_x * a.tiles_y, n_groups = a.CoutPad / 64;
   const int n = a.n_chunks;
 
-  // ---- this workgroup's units: a contiguous range of the tile-major list (image, tile, cout group)
-  const int u0 = (int)((long long)blockIdx.x * a.units / gridDim.x), u1 = (int)((long long)(blockIdx.x + 1) * a.units / gridDim.x);
-  if (u0 >= u1) return;
+  // ---- this workgroup's units.  TEAM mode (large grids): the n_groups workgroups of a team sit on ONE XCD (workgroup b runs
+  // on XCD b % 8) and walk the SAME run of pixel tiles, each for its own 64-cout group, in step -- a tile's halo chunk is
+  // fetched into that XCD's L2 once and read by the team's members at about the same time, and a workgroup's consecutive units
+  // reuse one group's weights; the XCD's teams share a contiguous band of the tile list.  (Round 4, first form: one workgroup
+  // ran a tile's groups back to back -- by then the 4-MB L2 had seen 7 MB of the other workgroups' halos: FETCH_SIZE 1.58x
+  // the one-unit kernel's at batch 32.)  Otherwise: a contiguous range of the tile-major (tile, group) list.
   struct Unit { int bi, tile_y, tile_x, ng; };
+  int i0, i1, member = -1;                         // unit indices [i0, i1): tiles of the team (team mode) or (tile, group) units
+  if (a.team) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int teams_per_xcd = per_xcd / n_groups;
+    member = k % n_groups;
+    const int team_in_xcd = k / n_groups;
+    if (team_in_xcd >= teams_per_xcd) return;      // (per_xcd not a multiple of n_groups: the leftover workgroups idle)
+    const int n_teams = 8 * teams_per_xcd, team = xcd * teams_per_xcd + team_in_xcd;
+    const int n_bt = a.units / n_groups;           // pixel tiles of the whole batch
+    i0 = (int)((long long)team * n_bt / n_teams);
+    i1 = (int)((long long)(team + 1) * n_bt / n_teams);
+  } else {
+    i0 = (int)((long long)blockIdx.x * a.units / gridDim.x);
+    i1 = (int)((long long)(blockIdx.x + 1) * a.units / gridDim.x);
+  }
+  if (i0 >= i1) return;
+  const int u0 = i0, u1 = i1;
   auto decode = [&](int u) {
     Unit r;
-    const int bt = u / n_groups;
-    r.ng = u - bt * n_groups;
+    const int bt = member >= 0 ? u : u / n_groups;
+    r.ng = member >= 0 ? member : u - bt * n_groups;
     r.bi = bt / n_tiles;
     const int tile = bt - r.bi * n_tiles;
     r.tile_y = (tile / a.tiles_x) * pT;
@@ -487,10 +507,13 @@ int m4d_wino6p_launch(const float* x, const void* wu6, const float* bias, int b,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return cus > 0 ? cus : 256;
   }();                                             // function-local static: initialised once, thread-safe (C++11)
-  // One workgroup per CU at most (154 KB of LDS each) -- and no more workgroups than the longest range needs: 960 units on 256
-  // CUs are 4 per workgroup whichever way, so 240 workgroups do it and 16 CUs stay free for the other frames' small kernels
+  // One workgroup per CU at most (154 KB of LDS each).  Large grids: team mode on every CU (see the kernel).  Smaller ones: no
+  // more workgroups than the longest range needs -- 960 units on 256 CUs are 4 per workgroup whichever way, so 240 workgroups
+  // do it and 16 CUs stay free for the other frames' small kernels.
+  const int n_groups = CoutPad / 64;
+  a.team = (n_cu % 8 == 0 && n_cu / 8 >= n_groups && units >= 4ll * n_cu) ? 1 : 0;
   const long long per_wg = (units + n_cu - 1) / n_cu;
-  const unsigned grid = (unsigned)((units + per_wg - 1) / per_wg);
+  const unsigned grid = a.team ? (unsigned)n_cu : (unsigned)((units + per_wg - 1) / per_wg);
   m4d_launch(conv3x3_wino6p_kernel, dim3(grid), dim3(512), (size_t)pLds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -457,6 +457,11 @@ def test_winograd_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
     (2, 70, 150, 240, 66, 0.1),       # 15 chunks, Cout % 4 != 0: scalar stores
     (1, 40, 40, 64, 64, 0.1),         # 9 units: fewer than CUs, one unit per workgroup
     (9, 33, 17, 80, 70, 0.1),         # many small images
+    # >= 1024 units: TEAM mode (the cout groups of a tile on n_groups workgroups of one XCD, XCD-banded tile runs)
+    (2, 192, 640, 64, 128, 0.1),      # 1920 units, teams of two
+    (9, 100, 130, 48, 120, 0.1),      # 1134 units, odd chunk count, ragged tiles, tile runs crossing images
+    (6, 100, 130, 32, 192, 1.0),      # teams of three: 10 teams per XCD, two workgroups per XCD idle
+    (3, 192, 640, 96, 64, 0.1),       # teams of one (a single cout group): XCD-banded contiguous runs
 ])
 def test_persistent_winograd_is_bitwise_the_one_tile_kernel(M, dev, b, h, w, cin, cout, slope):
     """m4d_wino6p.hip (persistent workgroups walking (tile, cout group) units, the K loop's DMA stream continuing across
