@@ -374,12 +374,19 @@ level_front_kernel(const FrontArgs a) {
   __syncthreads();
   if (st && t == 0) st[5] = __builtin_readcyclecounter();
   // ---- D: the tile's refiner-input rows, contiguous in HBM per tile row
+  // 16 bytes per lane (round 4): the stage's rows have an odd stride (conflict-free column writes above), so a lane gathers its
+  // four floats with four ds_read_b32 -- 64 lanes of one read still hit 64 distinct banks (bank = 4 quad + pixel + i) -- and
+  // stores them as ONE global_store_dwordx4: a quarter of the store instructions, and a CU issues 16-byte pieces of a
+  // 256-byte run several times faster than 4-byte pieces (tools/micro/store_issue_probe.hip; this phase was 12 % of the kernel)
   {
     float* fin = a.f_input + (long long)bi * hw * F_ST;
-    for (int e = t; e < P * F_ST; e += NT) {
-      const int pxl = e / F_ST, ch = e % F_ST;
+    constexpr int Q = F_ST / 4;                                // 16-byte quads per refiner-input row (F_ST is a multiple of 8)
+    for (int e = t; e < P * Q; e += NT) {
+      const int pxl = e / Q, q4 = e % Q;
       const int oy = tile_y + pxl / TW, ox = tile_x + pxl % TW;
-      if (oy < h && ox < w) fin[((long long)oy * w + ox) * F_ST + ch] = tile[pxl * F_LDS + ch];
+      const float* src = tile + pxl * F_LDS + 4 * q4;
+      const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+      if (oy < h && ox < w) m4d_store16(fin + ((long long)oy * w + ox) * F_ST + 4 * q4, v0, v1, v2, v3);
     }
   }
   if (st && t == 0) st[6] = __builtin_readcyclecounter();
