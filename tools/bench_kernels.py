@@ -110,7 +110,8 @@ def main():
                           f"{float(st[:, 4].mean()):.0f} max {float(st[:, 4].max()):.0f}, width mean {float(st[:, 5].mean()):.1f}; "
                           f"kernel span {(float(st[:, 3].max()) - float(st[:, 0].min())) / 1e3:.0f} kcycles over {len(st)} workgroups", flush=True)
         if name == "front":
-            tiles = 4096
+            tiles = max(4096, b * h * w // 32 + 64)       # 8 stamps per WORKGROUP: the smallest front tile is 8x4 pixels (a fixed 4096 rows
+                                                          # let batch-32 runs write past the buffer: a GPU memory fault under rocprofv3)
             stamps = torch.zeros((tiles, 8), dtype=torch.int64, device=dev)
             lib.m4d_front_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
             fn()
