@@ -48,6 +48,9 @@ inline void m4d_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t l
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
 }
 
+// a compile-time integer as a value: picks the instantiation of a generic lambda (`body(m4d_int<2>{})`)
+template <int N> struct m4d_int { static constexpr int value = N; };
+
 // ---- one 16-byte global store that stays ONE instruction ------------------------------------------------------------------
 // hipcc if-converts `if (vector_ok) *(float4*)p = v; else for (e) if (c + e < C) p[e] = v[e];` into guarded ELEMENT stores
 // for both arms (dword / dwordx2 / dwordx3 pieces): a CU issues 128-byte runs of 4-byte pieces at 16 B/clk against ~100 B/clk

@@ -200,8 +200,14 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   const unsigned bring = lds_base + (unsigned)(kBRingOff + pr * kBRingBytes);    // LDS byte address of this row's ring
   const unsigned char* bring_p = reinterpret_cast<const unsigned char*>(lds) + kBRingOff + pr * kBRingBytes;
   const unsigned bl = (unsigned)lane * 16u;
-  const unsigned bl_dma = bl + (unsigned)mt * 3072u;
-  // (the instruction offset of an LDS-DMA load moves BOTH the global address and the LDS address)
+  // HALF unit (uniform): only N-tile 0 of this cout group holds real output channels (Cout = 96: the second group) -- its K loop
+  // issues N-tile 0's MFMAs only and the epilogue handles N-tile 0 only.  The DMA protocol stays what it is (same pieces per
+  // wave and position, same vmcnt counts), but the waves that fetch N-tile 1's fragments (mt = 1) point all 64 lanes at one
+  // 16-byte word: one cache line per piece instead of sixteen, into ring bytes nobody reads.
+  const bool half = __builtin_amdgcn_readfirstlane(ng * 64 + 32 >= a.Cout ? 1 : 0) != 0;    // (scalar: the K loop branches on it)
+  const unsigned bl_dma = (half && mt == 1) ? 0u : bl + (unsigned)mt * 3072u;
+  // (the instruction offset of an LDS-DMA load moves BOTH the global address and the LDS address; the per-lane offset moves the
+  // global address only: lane l always lands at M0 + 16 l)
   auto b_dma = [&](const unsigned char* gsrc, int slot) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024\n\t"
@@ -216,13 +222,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   auto gen_l = [&](int c, int e, u32x4 (&A)[3]) { if (!(M4D_W6_ABL & 16)) gen_pair(c, e, A); };
 #define M4D_W6_WAIT(nn) asm volatile("s_waitcnt vmcnt(" #nn ") lgkmcnt(0)" ::: "memory")
 
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][nt][r] = 0.f;
+  f32x16 acc[4][2];                                // (zeroed by the K loop's instantiation: a half unit leaves N-tile 1 alone)
 
   // stamps (profiling build only): lane 0 of every wave of the first 64 workgroups; per workgroup 1280 words: per wave 32
   // positions x (after barrier, -, before wait, after wait), then at 1024 the header of wave 0 (start, end of K loop, end)
@@ -230,21 +230,13 @@ conv3x3_wino6_kernel(const Wino6Args a) {
                                ? a.stamps + (long long)blockIdx.x * 1280 + wv * 128 : nullptr;
   if (STAMPS && st && wv == 0) st[1024 + 0] = __builtin_readcyclecounter();
 
-  // ---- prologue: epilogue operands; raw(0), B(0), B(1) | B(2), raw(1), B(3) by DMA in the order the K loop's vmcnt counts
+  // ---- prologue: raw(0), B(0), B(1) | B(2), raw(1), B(3) by DMA in the order the K loop's vmcnt counts
   // assume: every end-of-position wait of the K loop is vmcnt(4 + 4) = "this position's and the previous position's DMAs may
   // still fly".  First chunk, DMAs in flight oldest first (kRawK = 4, pieces in brackets):
   //   after the prologue wait (10):  B(2)[3] raw(1)[4] B(3)[3]
   //   end of position 0 (+4, wait 8): retires B(2)[3] raw(1)[3]      -> position 1 reads slot 2: landed
   //   end of position 1 (+4, wait 8): retires raw(1)[1] B(3)[3]      -> position 2 reads slot 3 and raw(1): landed
   // then t(0), A(0, 0), B(0) in registers
-  float bs[2][4];                                  // this thread's output-channel quad of the bias, per N-tile (oldest loads)
-#pragma unroll
-  for (int ont = 0; ont < 2; ++ont)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int co = ng * 64 + ont * 32 + 4 * (t & 7) + e;
-      bs[ont][e] = a.bias[min(co, a.Cout - 1)];
-    }
 #pragma unroll
   for (int k = 0; k < kRawK; ++k) raw_dma(0, 0, k);
   b_dma(wc, 0);
@@ -261,13 +253,9 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   static_assert(kRawK == 4, "the vmcnt counts below assume 4 raw-halo pieces + 3 fragment pieces per position");
   M4D_W6_WAIT(10);                                 // raw(0), B(0), B(1) landed; B(2), raw(1), B(3) still in flight
   __builtin_amdgcn_s_barrier();
-  read_t(raw, 0);
-  read_t(raw, 1);
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) { B0[0][nt] = frag(0, nt, 0); B1[nt] = frag(0, nt, 1); B2[nt] = frag(0, nt, 2); }
   u32x4 A[2][3];                                   // [ring][part]: packed bf16 pairs
-#pragma unroll
-  for (int e = 0; e < 4; ++e) gen_pair(0, e, A[0]);
+  // (t(0), A(0, 0), B(0) into registers: first thing in the K loop's instantiation -- hipcc lays the two instantiations out one
+  // after the other behind scalar guards, and anything produced HERE for both would stay live across the first one's loop)
 
   // The compiler may sink pure arithmetic past a sched_barrier (only the machine scheduler honours it): an empty asm that
   // "modifies" the freshly produced operands pins their producers inside the region they are meant to overlap with.
@@ -281,14 +269,16 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(tv[c0 + 2 * cc][e]));
   };
+  // (NTL = the unit's N-tiles, a compile-time constant of the K loop's two instantiations below: 2, or 1 for a half unit)
 #define M4D_W6_MFMA(c, ap, bv)                                                                                         \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                     \
+  _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                                   \
     acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(c) & 1][ap]), bv[nt], acc[c][nt], 0, 0, 0);
-  // one MFMA, then `valu` vector instructions (8 + 4 n cycles of the VALU port for one MFMA and n others; the MFMA runs 32)
-#define M4D_W6_PIPE(n_mfma, valu)                                                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < n_mfma; ++i_) {                                                              \
+  // one MFMA, then `valu` vector instructions (8 + 4 n cycles of the VALU port for one MFMA and n others; the MFMA runs 32);
+  // a block has 2 NTL MFMAs and the same vector work either way
+#define M4D_W6_PIPE(valu)                                                                                              \
+  _Pragma("unroll") for (int i_ = 0; i_ < 2 * NTL; ++i_) {                                                             \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x002, (valu) * (2 / NTL), 0);                                                \
   }
   // One position = three blocks of 4 MFMAs (6 of the 9 term products, the small ones first), each followed by one DMA: the
   // texture path (16 cycles per 1-KB piece, 32 pieces per position and CU) then works beside the MFMAs instead of in a burst
@@ -296,25 +286,25 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // soon as the part's last MFMA is issued (lo after block 0, mid after block 1); the hi part, needed until the end, is
   // double buffered.
 #define M4D_W6_BLOCK0(c, cn, next_slot, valu)                                                                          \
-  frag_l(B0[((c) & 1) ^ 1][0], next_slot, 0, 0); frag_l(B0[((c) & 1) ^ 1][1], next_slot, 1, 0);                          \
+  frag_l(B0[((c) & 1) ^ 1][0], next_slot, 0, 0); if (NTL == 2) frag_l(B0[((c) & 1) ^ 1][1], next_slot, 1, 0);            \
   gen_l(cn, 0, A[((c) & 1) ^ 1]); gen_l(cn, 1, A[((c) & 1) ^ 1]);                                                \
   M4D_W6_MFMA(c, 0, B2) M4D_W6_MFMA(c, 2, B0[(c) & 1])                                                                 \
   asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][0]), "+v"(A[((c) & 1) ^ 1][0][1]));                                       \
-  M4D_W6_PIPE(4, valu)                                                                                                 \
+  M4D_W6_PIPE(valu)                                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
 #define M4D_W6_BLOCK1(c, cn, next_slot, valu)                                                                          \
-  frag_l(B2[0], next_slot, 0, 2); frag_l(B2[1], next_slot, 1, 2);                                                        \
+  frag_l(B2[0], next_slot, 0, 2); if (NTL == 2) frag_l(B2[1], next_slot, 1, 2);                                        \
   gen_l(cn, 2, A[((c) & 1) ^ 1]);                                                                                   \
   M4D_W6_MFMA(c, 1, B1) M4D_W6_MFMA(c, 0, B1)                                                                          \
   asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][2]));                                                                     \
-  M4D_W6_PIPE(4, valu)                                                                                                 \
+  M4D_W6_PIPE(valu)                                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
 #define M4D_W6_BLOCK2(c, cn, next_slot, valu)                                                                          \
-  frag_l(B1[0], next_slot, 0, 1); frag_l(B1[1], next_slot, 1, 1);                                                        \
+  frag_l(B1[0], next_slot, 0, 1); if (NTL == 2) frag_l(B1[1], next_slot, 1, 1);                                        \
   gen_l(cn, 3, A[((c) & 1) ^ 1]);                                                                                   \
   M4D_W6_MFMA(c, 1, B0[(c) & 1]) M4D_W6_MFMA(c, 0, B0[(c) & 1])                                                        \
   pin_a(A[((c) & 1) ^ 1]);                                                                                             \
-  M4D_W6_PIPE(4, valu)                                                                                                 \
+  M4D_W6_PIPE(valu)                                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
 
   // Uniform loop body (no branches: one scheduling region per position).  Work past the last chunk is harmless: the
@@ -323,15 +313,30 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // DMAs (one raw piece at columns 0-2, this wave's half of B four positions ahead); the MFMAs of this position interleaved
   // with the A operands of the next; then vmcnt(N) leaves exactly the DMAs of this and the previous position in flight
   // (N = 6 + their raw pieces), i.e. everything the barrier of the next position publishes has landed.
-  // every LDS read of the prologue (raw buffer 0, ring slot 0) has returned before this wave passes position 0's barrier,
-  // behind which the other waves' DMAs start refilling that buffer and that slot (the K loop's waits include lgkmcnt(0) too)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   int stq = 0;
 #define M4D_W6_STAMP(k) if (STAMPS && st && stq < 32) st[stq * 4 + (k)] = __builtin_readcyclecounter();
 #define W6L_BARRIER() do { if (!(M4D_W6_ABL & 1)) __builtin_amdgcn_s_barrier(); } while (0)
 #define W6L_RAW(...) do { if (!(M4D_W6_ABL & 4)) raw_dma(__VA_ARGS__); } while (0)
 #define W6L_BDMA(...) do { if (!(M4D_W6_ABL & 2)) b_dma(__VA_ARGS__); } while (0)
 #define W6L_WAIT(nn) do { if (!(M4D_W6_ABL & 32)) { M4D_W6_WAIT(nn); } } while (0)
+  auto k_loop = [&](auto ntl_tag) __attribute__((always_inline)) {
+  constexpr int NTL = decltype(ntl_tag)::value;
+  asm volatile("" ::: "memory");                   // (nothing below is hoisted above the branch that picks the instantiation)
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][nt][r] = 0.f;
+  read_t(raw, 0);
+  read_t(raw, 1);
+#pragma unroll
+  for (int nt = 0; nt < NTL; ++nt) { B0[0][nt] = frag(0, nt, 0); B1[nt] = frag(0, nt, 1); B2[nt] = frag(0, nt, 2); }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) gen_pair(0, e, A[0]);
+  // every LDS read above (raw buffer 0, ring slot 0) has returned before this wave passes position 0's barrier, behind which
+  // the other waves' DMAs start refilling that buffer and that slot (the K loop's waits include lgkmcnt(0) too)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int chunk = 0; chunk < n; ++chunk) {
     const unsigned char* wn = chunk < last ? wc + w_chunk : wc;                   // scalar select: B of the next chunk
     const int rnext_c = min(chunk + 2, last);
@@ -390,6 +395,8 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     if (STAMPS) ++stq;
     wc = wn;
   }
+  };
+  if (half) k_loop(m4d_int<1>{}); else k_loop(m4d_int<2>{});
 #undef M4D_W6_MFMA
 #undef M4D_W6_BLOCK0
 #undef M4D_W6_BLOCK1
@@ -402,11 +409,20 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   __syncthreads();                                 // every wave is done with raw / the rings: the epilogue buffer aliases them
 
   // ---- output transform: rows of A^T (M A) through LDS per (N-tile, M-tile), then one 2x2-output item x 4 couts per thread
+  float bs[2][4];                                  // this thread's output-channel quad of the bias, per N-tile: loaded here (not
+#pragma unroll                                     // held across the K loop), the latency hides behind the LDS pass below
+  for (int ont = 0; ont < 2; ++ont)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = ng * 64 + ont * 32 + 4 * (t & 7) + e;
+      bs[ont][e] = a.bias[min(co, a.Cout - 1)];
+    }
   constexpr int kMS = 36;                          // row stride (floats): 32 couts + 4 pad (16-byte aligned rows)
   constexpr int kRbMT = 4 * 2 * 32 * kMS;          // floats per (N-tile, M-tile): [4 rows i][2 k][32 tiles][kMS] = 36.9 KB
   float* Rb = lds;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
+    if (nt == 1 && half) break;                    // (a half unit never touched N-tile 1's accumulators)
     float* rbuf = Rb + (nt * 2 + mt) * kRbMT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -420,9 +436,10 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
   const bool vec_ok = (a.Cout & 3) == 0;
   const bool whole = tile_x + kT <= a.w && tile_y + kT <= a.h;      // uniform: no per-store bounds tests on interior tiles
-  const bool fast = whole && vec_ok && ng * 64 + 64 <= a.Cout;      // ... and every cout quad of the group is real
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
+    if (it == 1 && half) break;
+    const bool fast = whole && vec_ok && ng * 64 + 32 * it + 32 <= a.Cout;   // ... and every cout quad of the N-tile is real
     const int item = it * 512 + t;                 // (N-tile, M-tile, tile in M-tile, cout quad)
     const int cq = item & 7, tl = (item >> 3) & 31, omt = (item >> 8) & 1, ont = it;
     const float* rbuf = Rb + (ont * 2 + omt) * kRbMT;

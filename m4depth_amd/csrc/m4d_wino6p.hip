@@ -92,6 +92,13 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
   // ran a tile's groups back to back -- by then the 4-MB L2 had seen 7 MB of the other workgroups' halos: FETCH_SIZE 1.58x
   // the one-unit kernel's at batch 32.)  Otherwise: a contiguous range of the tile-major (tile, group) list.
   struct Unit { int bi, tile_y, tile_x, ng; };
+  // HALF unit: only N-tile 0 of its cout group holds real output channels (Cout = 96: the second group).  Its K loop issues N-tile
+  // 0's MFMAs only, its epilogue handles N-tile 0 only; the DMA protocol (pieces per wave and position, hence every vmcnt count)
+  // is the same, but the waves that fetch N-tile 1's fragments (mt = 1) point all 64 lanes at one 16-byte word: one cache line per
+  // piece instead of sixteen, into ring bytes a half unit never reads.
+  const int last_group_couts = a.Cout - (n_groups - 1) * 64;
+  auto is_half = [&](int ng) { return __builtin_amdgcn_readfirstlane((ng == n_groups - 1 && last_group_couts <= 32) ? 1 : 0) != 0; };
+  const bool alternate = last_group_couts <= 32 && n_groups > 1;
   int i0, i1, member = -1;                         // unit indices [i0, i1): tiles of the team (team mode) or (tile, group) units
   if (a.team) {
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
@@ -112,7 +119,9 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
   auto decode = [&](int u) {
     Unit r;
     const int bt = member >= 0 ? u : u / n_groups;
-    r.ng = member >= 0 ? member : u - bt * n_groups;
+    // (team mode with a half last group -- Cout = 96 --: the members swap groups tile by tile, or the member with the half
+    // units would run ahead of its team and finish a quarter earlier)
+    r.ng = member >= 0 ? (alternate ? (member + bt) % n_groups : member) : u - bt * n_groups;
     r.bi = bt / n_tiles;
     const int tile = bt - r.bi * n_tiles;
     r.tile_y = (tile / a.tiles_x) * pT;
@@ -198,12 +207,14 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
   const long long w_pos = 6 * 1024;
   const long long w_chunk = (long long)n_groups * 16 * w_pos;
   const unsigned bl = (unsigned)lane * 16u;
-  const unsigned bl_dma = bl + (unsigned)mt * 3072u;
-  auto b_dma = [&](const unsigned char* gsrc, int slot) {
+  // per-lane GLOBAL offset of a fragment DMA (the LDS side is M0 + 16 lane whatever this is): the lane's 16 bytes of the wave's
+  // three fragments -- or, for N-tile 1's fragments of a half unit, one word for everybody (see above)
+  auto b_lane_off = [&](bool half_unit) { return (half_unit && mt == 1) ? 0u : bl + (unsigned)mt * 3072u; };
+  auto b_dma = [&](const unsigned char* gsrc, int slot, unsigned voff) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %0, %2\n\tglobal_load_lds_dwordx4 %0, %2 offset:1024\n\t"
                  "global_load_lds_dwordx4 %0, %2 offset:2048"
-                 : : "v"(bl_dma), "s"(lds_base + (unsigned)(p_slot_off(slot) + pr * 6144) + (unsigned)mt * 3072u), "s"(gsrc) : "memory", "m0");
+                 : : "v"(voff), "s"(lds_base + (unsigned)(p_slot_off(slot) + pr * 6144) + (unsigned)mt * 3072u), "s"(gsrc) : "memory", "m0");
   };
   // The unit's 64 biases by LDS-DMA too (lane = output channel of the group, clamped to the last real one): a compiler-issued
   // global load in the unit loop would be waited for with a vmcnt the compiler counts WITHOUT the asm DMAs, i.e. a full drain
@@ -222,12 +233,6 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
 #define P6_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
   p6_f32x16 acc[4][2];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][nt][r] = 0.f;
 
   p6_u32x4 A[2][3];                                // [ring][part]: packed bf16 pairs
   auto pin_a = [&](p6_u32x4 (&X)[3]) {
@@ -240,31 +245,38 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(tv[c0 + 2 * cc][e]));
   };
+  // (NTL = the unit's N-tiles, a compile-time constant of the two instantiations of a unit's K loop: 2, or 1 for a half unit)
 #define P6_MFMA(c, ap, bv)                                                                                             \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                     \
+  _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                                   \
     acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(p6_bf16x8, A[(c) & 1][ap]), bv[nt], acc[c][nt], 0, 0, 0);
-#define P6_PIPE(n_mfma, valu)                                                                                          \
-  _Pragma("unroll") for (int i_ = 0; i_ < n_mfma; ++i_) {                                                              \
+  // the first product into an accumulator: in the unit's first chunk (FIRST) on top of the constant 0 instead of a zeroed register
+#define P6_MFMA0(c, ap, bv)                                                                                            \
+  _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                                   \
+    acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(p6_bf16x8, A[(c) & 1][ap]), bv[nt],         \
+                                                         FIRST ? p6_f32x16{} : acc[c][nt], 0, 0, 0);
+  // a block has 2 NTL MFMAs and the same vector work either way
+#define P6_PIPE(valu)                                                                                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < 2 * NTL; ++i_) {                                                             \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x002, valu, 0);                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x002, (valu) * (2 / NTL), 0);                                                \
   }
-  // One position = three blocks of 4 MFMAs (6 of the 9 term products, the small ones first); NEXT = prefetch the B registers
+  // One position = three blocks of 2 NTL MFMAs (6 of the 9 term products, the small ones first); NEXT = prefetch the B registers
   // (from ring slot next_slot) and generate the A operands (position cn) of the next position between the MFMAs
 #define P6_BLOCK0(c, cn, next_slot, valu, NEXT)                                                                        \
-  if (NEXT) { B0[((c) & 1) ^ 1][0] = frag(next_slot, 0, 0); B0[((c) & 1) ^ 1][1] = frag(next_slot, 1, 0);              \
+  if (NEXT) { B0[((c) & 1) ^ 1][0] = frag(next_slot, 0, 0); if (NTL == 2) B0[((c) & 1) ^ 1][1] = frag(next_slot, 1, 0); \
               gen_pair(cn, 0, A[((c) & 1) ^ 1]); gen_pair(cn, 1, A[((c) & 1) ^ 1]); }                                  \
-  P6_MFMA(c, 0, B2) P6_MFMA(c, 2, B0[(c) & 1])                                                                         \
-  if (NEXT) { asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][0]), "+v"(A[((c) & 1) ^ 1][0][1])); P6_PIPE(4, valu) }         \
+  P6_MFMA0(c, 0, B2) P6_MFMA(c, 2, B0[(c) & 1])                                                                        \
+  if (NEXT) { asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][0]), "+v"(A[((c) & 1) ^ 1][0][1])); P6_PIPE(valu) }            \
   __builtin_amdgcn_sched_barrier(0);
 #define P6_BLOCK1(c, cn, next_slot, valu, NEXT)                                                                        \
-  if (NEXT) { B2[0] = frag(next_slot, 0, 2); B2[1] = frag(next_slot, 1, 2); gen_pair(cn, 2, A[((c) & 1) ^ 1]); }       \
+  if (NEXT) { B2[0] = frag(next_slot, 0, 2); if (NTL == 2) B2[1] = frag(next_slot, 1, 2); gen_pair(cn, 2, A[((c) & 1) ^ 1]); } \
   P6_MFMA(c, 1, B1) P6_MFMA(c, 0, B1)                                                                                  \
-  if (NEXT) { asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][2])); P6_PIPE(4, valu) }                                      \
+  if (NEXT) { asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][2])); P6_PIPE(valu) }                                         \
   __builtin_amdgcn_sched_barrier(0);
 #define P6_BLOCK2(c, cn, next_slot, valu, NEXT)                                                                        \
-  if (NEXT) { B1[0] = frag(next_slot, 0, 1); B1[1] = frag(next_slot, 1, 1); gen_pair(cn, 3, A[((c) & 1) ^ 1]); }       \
+  if (NEXT) { B1[0] = frag(next_slot, 0, 1); if (NTL == 2) B1[1] = frag(next_slot, 1, 1); gen_pair(cn, 3, A[((c) & 1) ^ 1]); } \
   P6_MFMA(c, 1, B0[(c) & 1]) P6_MFMA(c, 0, B0[(c) & 1])                                                                \
-  if (NEXT) { pin_a(A[((c) & 1) ^ 1]); P6_PIPE(4, valu) }                                                              \
+  if (NEXT) { pin_a(A[((c) & 1) ^ 1]); P6_PIPE(valu) }                                                                 \
   __builtin_amdgcn_sched_barrier(0);
 
   if (M4D_W6P_ABL & 16) {                           // experiment: de-phase the CUs (their epilogue store bursts coincide otherwise)
@@ -277,12 +289,15 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
   int par = 0;                                     // raw buffer of the unit's chunk 0
 #pragma unroll
   for (int k = 0; k < pRawK; ++k) raw_dma(0, 0, k);
-  b_dma(wc, 0);
-  b_dma(wc + w_pos, 1);
+  {
+    const unsigned voff = b_lane_off(is_half(cur.ng));
+    b_dma(wc, 0, voff);
+    b_dma(wc + w_pos, 1, voff);
 #pragma unroll
-  for (int k = 0; k < pRawK; ++k) raw_dma(64, 1, k);                              // (n >= 2: the host checks)
-  b_dma(wc + 2 * w_pos, 2);
-  b_dma(wc + 3 * w_pos, 3);
+    for (int k = 0; k < pRawK; ++k) raw_dma(64, 1, k);                            // (n >= 2: the host checks)
+    b_dma(wc + 2 * w_pos, 2, voff);
+    b_dma(wc + 3 * w_pos, 3, voff);
+  }
   P6_WAIT(3);                                      // only B(3) still flies (see the wait table above)
   __builtin_amdgcn_s_barrier();
 
@@ -290,12 +305,24 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
     const bool has_next = u + 1 < u1;
     const Unit nxt = has_next ? decode(u + 1) : cur;                 // (the last unit's surplus DMAs re-fetch its own first chunks)
     const unsigned char* wnext = a.wu + ((long long)nxt.ng * 16 + 4 * pr) * w_pos;
+    const bool half = is_half(cur.ng);
+    const unsigned voff_cur = b_lane_off(half), voff_nxt = b_lane_off(is_half(nxt.ng));
 
+    // The unit's K loop and epilogue, two instantiations.  hipcc lays them out one after the other behind scalar guards: what
+    // one of them needs must not be produced before the branch, or it stays live across the other's loop (hence the empty asm),
+    // and N-tile 1's accumulators must not be mentioned in the half unit's epilogue under a run-time condition (they would stay
+    // live -- 64 registers -- through its K loop).
+    auto unit_body = [&](auto ntl_tag) __attribute__((always_inline)) {
+    constexpr int NTL = decltype(ntl_tag)::value;
+    asm volatile("" ::: "memory");
     // ---- t(0), A(0, 0), B(0) in registers: raw chunk 0 and ring slot 0 have landed and were published by a barrier
     read_t(raw_ptr(par), 0);
     read_t(raw_ptr(par), 1);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) { B0[0][nt] = frag(0, nt, 0); B1[nt] = frag(0, nt, 1); B2[nt] = frag(0, nt, 2); }
+    for (int nt = 0; nt < NTL; ++nt) { B0[0][nt] = frag(0, nt, 0); B1[nt] = frag(0, nt, 1); B2[nt] = frag(0, nt, 2); }
+    // (the accumulators are not zeroed: the unit's first chunk, peeled below, multiplies its first products onto the constant 0.
+    // Zeros carried over from the previous unit's epilogue -- round 4's first form -- are 128 registers live through BOTH
+    // instantiations as hipcc lays them out, one after the other behind scalar guards: spilled)
 #pragma unroll
     for (int e = 0; e < 4; ++e) gen_pair(0, e, A[0]);
     // every LDS read above has returned before this wave passes position 0's barrier, behind which the other waves' DMAs
@@ -304,7 +331,8 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
 
     // ---- K loop.  chunk < n - 1: the uniform body of m4d_wino6.hip; the raw DMA of chunk c fetches chunk c + 2 of the unified
     // stream (from chunk n - 2 on: the next unit's chunks 0, 1), the fragment DMA of (c, position p) chunk c + 1's position p
-    for (int chunk = 0; chunk < n - 1; ++chunk) {
+    auto chunk_body = [&](int chunk, auto first_tag) __attribute__((always_inline)) {
+      constexpr bool FIRST = decltype(first_tag)::value != 0;
       if (chunk == n - 2) set_raw_source(nxt);
       const unsigned char* wn = wc + w_chunk;
       const int roff = (chunk + 2 < n ? chunk + 2 : chunk + 2 - n) * 64;
@@ -315,7 +343,7 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
       P6_BLOCK0(0, 1, 1, 7, true)
       raw_dma(roff, rbuf_w, 0);
       P6_BLOCK1(0, 1, 1, 4, true)
-      b_dma(wn, 0);
+      b_dma(wn, 0, voff_cur);
       P6_BLOCK2(0, 1, 1, 4, true)
       if (!(M4D_W6P_ABL & 8) || chunk > 0) { P6_WAIT(7); }
       // position 1: A(2) from t2, t1
@@ -323,7 +351,7 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
       P6_BLOCK0(1, 2, 2, 7, true)
       raw_dma(roff, rbuf_w, 1);
       P6_BLOCK1(1, 2, 2, 4, true)
-      b_dma(wn + w_pos, 1);
+      b_dma(wn + w_pos, 1, voff_cur);
       P6_BLOCK2(1, 2, 2, 4, true)
       if (!(M4D_W6P_ABL & 8) || chunk > 0) { P6_WAIT(8); }
       // position 2: A(3) from t1, t3; columns 0, 2 of t(chunk + 1)
@@ -332,7 +360,7 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
       raw_dma(roff, rbuf_w, 2);
       read_t(rnext, 0);
       P6_BLOCK1(2, 3, 3, 6, true)
-      b_dma(wn + 2 * w_pos, 2);
+      b_dma(wn + 2 * w_pos, 2, voff_cur);
       pin_t(0);
       P6_BLOCK2(2, 3, 3, 6, true)
       P6_WAIT(8);
@@ -342,28 +370,31 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
       raw_dma(roff, rbuf_w, 3);
       read_t(rnext, 1);
       P6_BLOCK1(3, 0, 0, 6, true)
-      b_dma(wn + 3 * w_pos, 3);
+      b_dma(wn + 3 * w_pos, 3, voff_cur);
       pin_t(1);
       P6_BLOCK2(3, 0, 0, 6, true)
       P6_WAIT(8);
       wc = wn;
-    }
+    };
+    chunk_body(0, m4d_int<1>{});                   // (n >= 2: the host checks)
+    for (int chunk = 1; chunk < n - 1; ++chunk) chunk_body(chunk, m4d_int<0>{});
     // ---- last chunk: the next unit's raw chunk 1, its fragments of positions 0 and 1; ring slots 2 and 3 are left alone
     {
+      constexpr bool FIRST = false;
       const int rbuf_w = (par + n - 1) & 1;
       __builtin_amdgcn_s_barrier();
       bias_dma(cur.ng);                            // (+1 VM op in this position: the waits below only get stricter)
       P6_BLOCK0(0, 1, 1, 7, true)
       raw_dma(64, rbuf_w, 0);
       P6_BLOCK1(0, 1, 1, 4, true)
-      b_dma(wnext, 0);
+      b_dma(wnext, 0, voff_nxt);
       P6_BLOCK2(0, 1, 1, 4, true)
       P6_WAIT(7);
       __builtin_amdgcn_s_barrier();
       P6_BLOCK0(1, 2, 2, 7, true)
       raw_dma(64, rbuf_w, 1);
       P6_BLOCK1(1, 2, 2, 4, true)
-      b_dma(wnext + w_pos, 1);
+      b_dma(wnext + w_pos, 1, voff_nxt);
       P6_BLOCK2(1, 2, 2, 4, true)
       P6_WAIT(8);
       __builtin_amdgcn_s_barrier();
@@ -395,6 +426,8 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
       int te = t;
       asm volatile("" : "+v"(te));                                              // the epilogue's addressing is computed here, not kept live across the K loop
       const int cq = te & 15, tl = te >> 4;                                     // this thread's item: tile 0..31 of the pass's M-tile, cout quad 0..15
+      const int me = te & 31, khe = (te >> 5) & 1;                              // (= m, kh: from the opaque copy, or the row addresses below are
+                                                                                //  hoisted out of the unit loop, 30 registers that get spilled)
       const int co = cur.ng * 64 + 4 * cq;
       float4 rv[4];
       auto finish = [&](int pass) {                                            // bias, leaky_relu, stores of the item read in `pass`
@@ -443,20 +476,14 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
         const int kcol = pass >> 1, omt = pass & 1;
         if (mt == omt) {
 #pragma unroll
-          for (int ont = 0; ont < 2; ++ont)
+          for (int ont = 0; ont < 2; ++ont) {
+            if (ont >= NTL) break;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float m0 = acc[0][ont][r], m1 = acc[1][ont][r], m2 = acc[2][ont][r], m3 = acc[3][ont][r];
-              const int trow = (r & 3) + 8 * (r >> 2) + 4 * kh;
-              rbuf[(pr * 32 + trow) * pMS2 + ont * 32 + m] = kcol == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
+              const int trow = (r & 3) + 8 * (r >> 2) + 4 * khe;
+              rbuf[(pr * 32 + trow) * pMS2 + ont * 32 + me] = kcol == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3;
             }
-          if (kcol == 1) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-              for (int ont = 0; ont < 2; ++ont)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][ont][r] = 0.f;               // ready for the next unit
           }
         }
         if (pass > 0) finish(pass - 1);
@@ -467,11 +494,13 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
       }
       // ---- the next unit's fragments of positions 2 and 3 (slots 2, 3 are free again); everything else of it has landed
       if (has_next) {
-        b_dma(wnext + 2 * w_pos, 2);
-        b_dma(wnext + 3 * w_pos, 3);
+        b_dma(wnext + 2 * w_pos, 2, voff_nxt);
+        b_dma(wnext + 3 * w_pos, 3, voff_nxt);
       }
       if (!(M4D_W6P_ABL & 1)) finish(3);
     }
+    };
+    if (half) unit_body(m4d_int<1>{}); else unit_body(m4d_int<2>{});
     if (!has_next) break;
     cur = nxt;
     wc = wnext;

@@ -450,7 +450,7 @@ def test_winograd_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
 @pytest.mark.parametrize("b,h,w,cin,cout,slope", [
     (1, 192, 640, 128, 128, 0.1),     # the level-1 layer: 960 units on 256 workgroups (3-4 per workgroup, 8 K chunks)
     (1, 192, 640, 64, 128, 0.1),      # 4 chunks
-    (1, 192, 640, 128, 96, 0.1),      # a quarter-empty second cout group
+    (1, 192, 640, 128, 96, 0.1),      # a second cout group of 32 channels: half units (N-tile 0 only)
     (1, 192, 640, 96, 64, 0.1),       # one cout group per tile: 480 units, 6 chunks
     (4, 100, 130, 48, 120, 0.1),      # odd chunk count (the raw-buffer parity flips per unit), ragged tiles, unit ranges crossing images
     (3, 100, 130, 32, 192, 1.0),      # two chunks (the shortest unit: both raw prefetches are the next unit's), three cout groups
@@ -462,6 +462,10 @@ def test_winograd_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
     (9, 100, 130, 48, 120, 0.1),      # 1134 units, odd chunk count, ragged tiles, tile runs crossing images
     (6, 100, 130, 32, 192, 1.0),      # teams of three: 10 teams per XCD, two workgroups per XCD idle
     (3, 192, 640, 96, 64, 0.1),       # teams of one (a single cout group): XCD-banded contiguous runs
+    # HALF units (a last cout group of <= 32 channels runs N-tile 0 only) in team mode: the members swap groups tile by tile
+    (3, 192, 640, 128, 96, 0.1),      # the refiner's 128 -> 96 layer, 2880 units
+    (6, 100, 130, 32, 160, 1.0),      # teams of three, two full groups + a half one, two chunks, ragged tiles
+    (5, 100, 130, 48, 66, 0.1),       # the half group holds two channels: scalar stores
 ])
 def test_persistent_winograd_is_bitwise_the_one_tile_kernel(M, dev, b, h, w, cin, cout, slope):
     """m4d_wino6p.hip (persistent workgroups walking (tile, cout group) units, the K loop's DMA stream continuing across
