@@ -61,6 +61,11 @@ wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
 # from the grid (persistent workgroups, csrc/m4d_wino6p.hip, wherever a CU gets more than one (tile, 64-cout) unit), 1 = one
 # workgroup per unit always (csrc/m4d_wino6.hip), 2 = persistent always.  A/B timing only.
 wino6_kernel = int(_os.environ.get("M4D_WINO6_KERNEL", "0"))
+# Narrowest layer the bf16-split Winograd kernels serve: a cout group of <= 32 channels runs as a HALF unit (one N-tile), so the
+# refiner's 64 -> 32 layer is one half unit per tile: 35.7 -> 29.0 us on level 1, 20.8 -> 12.4 on level 2 against the fp32-MFMA
+# Winograd kernel that served it in rounds 2-4 (= 64 here), +0.9 % / +1.1 % frames/s at batch 1 / 32
+# (profiles/r04_wino6_half_units.txt)
+wino6_min_cout = int(_os.environ.get("M4D_WINO6_MIN_COUT", "32"))
 # (experiments build only, include/m4depth_hip_experiments.h) which kernel serves the bf16-split layers -- same bits either
 # way: 2 = the wide kernel m4d_wino6w.hip wherever it applies, 3 = the half-tile kernel m4d_wino6h.hip
 if _os.environ.get("M4D_WINO6_VARIANT") or _os.environ.get("M4D_WINO6_HALF_MAX_WG"):
@@ -113,8 +118,8 @@ def _use_winograd(b, h, w, cin, cout, stride):
         return 0
     n32 = -(-cout // 32)
     t16 = b * (-(-h // 16)) * (-(-w // 16))
-    if conv_arith == "bf16x3" and cin % 16 == 0 and cin >= 32 and cout >= 64 and t16 * (-(-cout // 64)) >= wino6_min_workgroups:
-        return 6                                                # 64-cout workgroups: 96 runs as 128 and is still ahead
+    if conv_arith == "bf16x3" and cin % 16 == 0 and cin >= 32 and cout >= wino6_min_cout and t16 * (-(-cout // 64)) >= wino6_min_workgroups:
+        return 6                                                # 64-cout units; a last group of <= 32 channels runs one N-tile
     if cin % 4 == 0 and t16 * n32 >= winograd2_min_workgroups:
         return 2
     t8 = b * (-(-h // 8)) * (-(-w // 16))
