@@ -407,7 +407,9 @@ def test_winograd_conv_kernel2(M, dev, b, h, w, cin, cout, slope):
 
 @pytest.mark.parametrize("b,h,w,cin,cout,slope", [
     (2, 32, 48, 64, 128, 0.1),
-    (1, 37, 53, 112, 96, 0.1),        # ragged tiles; 96 output channels run as two 64-wide workgroups
+    (1, 37, 53, 112, 96, 0.1),        # ragged tiles; 96 output channels: a full 64-cout unit and a HALF unit (N-tile 0 only) per tile
+    (2, 40, 56, 64, 32, 0.1),         # the refiner's 64 -> 32 layer: one half unit per tile
+    (1, 33, 47, 16, 24, 0.1),         # a half unit with a single K chunk and a partly filled N-tile (guarded stores)
     (1, 19, 21, 32, 40, 1.0),         # N padding (40 -> 64), no activation, a map smaller than two tiles
     (2, 16, 16, 16, 64, 0.1),         # a single 16-channel chunk
     (1, 50, 90, 96, 64, 0.1),
