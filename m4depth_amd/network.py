@@ -56,7 +56,10 @@ winograd2_min_workgroups = int(_os.environ.get("M4D_WINO2_MIN_WG", "60"))
 # products, float32 accumulation (csrc/m4d_wino6.hip: float32 accuracy -- error against float64 0.8x that of the fp32
 # MFMA kernels, tools/bench_wino6.py -- at 2.67x less matrix-core time); "f32" = the fp32-MFMA kernels everywhere.
 conv_arith = _os.environ.get("M4D_CONV_ARITH", "bf16x3")
-wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "40"))
+# Smallest grid ((tile, 64-cout) units) those kernels take: 30 = the narrow layers of level 3 (30 tiles: 96 -> 64, and 64 -> 32 as
+# half units) as well, +0.8 % frames/s at batch 1 against 40 (rounds 2-4: those two on the fp32-MFMA Winograd / direct kernels);
+# 20 (level 4's wide layers too) measured the same as 30
+wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "30"))
 # Which kernel serves those layers (an ARGUMENT of m4d_conv3x3_wino6_bias_act_k, same bits either way): 0 = the library chooses
 # from the grid (persistent workgroups, csrc/m4d_wino6p.hip, wherever a CU gets more than one (tile, 64-cout) unit), 1 = one
 # workgroup per unit always (csrc/m4d_wino6.hip), 2 = persistent always.  A/B timing only.

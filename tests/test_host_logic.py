@@ -249,9 +249,9 @@ def test_convolution_dispatch_at_the_bench_pyramid():
     for lvl in (1, 2):
         assert [kinds[(lvl, ci, co)] for ci, co in [(128, 128), (128, 96), (96, 64)]] == [6, 6, 6], lvl
     assert kinds[(1, 64, 32)] == 6 and kinds[(2, 64, 32)] == 6          # 32 output channels: one HALF unit (N-tile 0 only) per tile
-    # level 3 (30 tiles of 16x16): the 128-wide layers are 60 workgroups of the split kernel, 96->64 would be 30 (below its 40) and
-    # takes kernel 2 (60 32-wide workgroups), 64->32 the direct kernel
-    assert [kinds[(3, ci, co)] for ci, co in [(128, 128), (128, 96), (96, 64), (64, 32)]] == [6, 6, 2, 0]
+    # level 3 (30 tiles of 16x16): the 128-wide layers are 60 workgroups of the split kernel, 96->64 and 64->32 (half units) 30:
+    # the smallest grid it takes
+    assert [kinds[(3, ci, co)] for ci, co in [(128, 128), (128, 96), (96, 64), (64, 32)]] == [6, 6, 6, 6]
     assert all(kinds[(lvl, ci, co)] == 0 for lvl in (4, 5, 6) for ci, co in [(128, 128), (128, 96), (96, 64), (64, 32)])
     assert N._use_winograd(32, 24, 80, 128, 128, 1) == 6                 # batch 32: level 4 fills the chip
     assert N._use_winograd(1, 192, 640, 128, 128, 2) == 0                # stride 2 never
