@@ -222,7 +222,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   auto gen_l = [&](int c, int e, u32x4 (&A)[3]) { if (!(M4D_W6_ABL & 16)) gen_pair(c, e, A); };
 #define M4D_W6_WAIT(nn) asm volatile("s_waitcnt vmcnt(" #nn ") lgkmcnt(0)" ::: "memory")
 
-  f32x16 acc[4][2];                                // (zeroed by the K loop's instantiation: a half unit leaves N-tile 1 alone)
+  f32x16 acc[4][2];                                // (never zeroed: the first chunk multiplies onto the constant 0)
 
   // stamps (profiling build only): lane 0 of every wave of the first 64 workgroups; per workgroup 1280 words: per wave 32
   // positions x (after barrier, -, before wait, after wait), then at 1024 the header of wave 0 (start, end of K loop, end)
@@ -273,6 +273,12 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 #define M4D_W6_MFMA(c, ap, bv)                                                                                         \
   _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                                   \
     acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(c) & 1][ap]), bv[nt], acc[c][nt], 0, 0, 0);
+  // the first product into an accumulator: in the first chunk (FIRST, peeled below) on top of the constant 0 -- the 128
+  // accumulator registers are never zeroed (that was 128 v_mov per wave behind the prologue's DMA wait, on every unit's critical path)
+#define M4D_W6_MFMA0(c, ap, bv)                                                                                        \
+  _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                                   \
+    acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(c) & 1][ap]), bv[nt],            \
+                                                         FIRST ? f32x16{} : acc[c][nt], 0, 0, 0);
   // one MFMA, then `valu` vector instructions (8 + 4 n cycles of the VALU port for one MFMA and n others; the MFMA runs 32);
   // a block has 2 NTL MFMAs and the same vector work either way
 #define M4D_W6_PIPE(valu)                                                                                              \
@@ -288,7 +294,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
 #define M4D_W6_BLOCK0(c, cn, next_slot, valu)                                                                          \
   frag_l(B0[((c) & 1) ^ 1][0], next_slot, 0, 0); if (NTL == 2) frag_l(B0[((c) & 1) ^ 1][1], next_slot, 1, 0);            \
   gen_l(cn, 0, A[((c) & 1) ^ 1]); gen_l(cn, 1, A[((c) & 1) ^ 1]);                                                \
-  M4D_W6_MFMA(c, 0, B2) M4D_W6_MFMA(c, 2, B0[(c) & 1])                                                                 \
+  M4D_W6_MFMA0(c, 0, B2) M4D_W6_MFMA(c, 2, B0[(c) & 1])                                                                \
   asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][0]), "+v"(A[((c) & 1) ^ 1][0][1]));                                       \
   M4D_W6_PIPE(valu)                                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
@@ -322,12 +328,6 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   auto k_loop = [&](auto ntl_tag) __attribute__((always_inline)) {
   constexpr int NTL = decltype(ntl_tag)::value;
   asm volatile("" ::: "memory");                   // (nothing below is hoisted above the branch that picks the instantiation)
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][nt][r] = 0.f;
   read_t(raw, 0);
   read_t(raw, 1);
 #pragma unroll
@@ -337,7 +337,8 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // every LDS read above (raw buffer 0, ring slot 0) has returned before this wave passes position 0's barrier, behind which
   // the other waves' DMAs start refilling that buffer and that slot (the K loop's waits include lgkmcnt(0) too)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  for (int chunk = 0; chunk < n; ++chunk) {
+  auto chunk_body = [&](int chunk, auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value != 0;
     const unsigned char* wn = chunk < last ? wc + w_chunk : wc;                   // scalar select: B of the next chunk
     const int rnext_c = min(chunk + 2, last);
     const float4* rnext = raw + ((chunk + 1) & 1) * kRawSlots;
@@ -394,10 +395,13 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     wc = wn;
-  }
+  };
+  chunk_body(0, m4d_int<1>{});
+  for (int chunk = 1; chunk < n; ++chunk) chunk_body(chunk, m4d_int<0>{});
   };
   if (half) k_loop(m4d_int<1>{}); else k_loop(m4d_int<2>{});
 #undef M4D_W6_MFMA
+#undef M4D_W6_MFMA0
 #undef M4D_W6_BLOCK0
 #undef M4D_W6_BLOCK1
 #undef M4D_W6_BLOCK2
