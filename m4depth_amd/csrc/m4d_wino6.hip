@@ -291,30 +291,26 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // after the barrier that every wave would sit through.  The B registers of a part are refilled for the next position as
   // soon as the part's last MFMA is issued (lo after block 0, mid after block 1); the hi part, needed until the end, is
   // double buffered.
-#define M4D_W6_BLOCK0(c, cn, next_slot, valu)                                                                          \
-  frag_l(B0[((c) & 1) ^ 1][0], next_slot, 0, 0); if (NTL == 2) frag_l(B0[((c) & 1) ^ 1][1], next_slot, 1, 0);            \
-  gen_l(cn, 0, A[((c) & 1) ^ 1]); gen_l(cn, 1, A[((c) & 1) ^ 1]);                                                \
+#define M4D_W6_BLOCK0(c, cn, next_slot, valu, NEXT)                                                                    \
+  if (NEXT) { frag_l(B0[((c) & 1) ^ 1][0], next_slot, 0, 0); if (NTL == 2) frag_l(B0[((c) & 1) ^ 1][1], next_slot, 1, 0); \
+              gen_l(cn, 0, A[((c) & 1) ^ 1]); gen_l(cn, 1, A[((c) & 1) ^ 1]); }                                          \
   M4D_W6_MFMA0(c, 0, B2) M4D_W6_MFMA(c, 2, B0[(c) & 1])                                                                \
-  asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][0]), "+v"(A[((c) & 1) ^ 1][0][1]));                                       \
-  M4D_W6_PIPE(valu)                                                                                                    \
+  if (NEXT) { asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][0]), "+v"(A[((c) & 1) ^ 1][0][1])); M4D_W6_PIPE(valu) }         \
   __builtin_amdgcn_sched_barrier(0);
-#define M4D_W6_BLOCK1(c, cn, next_slot, valu)                                                                          \
-  frag_l(B2[0], next_slot, 0, 2); if (NTL == 2) frag_l(B2[1], next_slot, 1, 2);                                        \
-  gen_l(cn, 2, A[((c) & 1) ^ 1]);                                                                                   \
+#define M4D_W6_BLOCK1(c, cn, next_slot, valu, NEXT)                                                                    \
+  if (NEXT) { frag_l(B2[0], next_slot, 0, 2); if (NTL == 2) frag_l(B2[1], next_slot, 1, 2);                              \
+              gen_l(cn, 2, A[((c) & 1) ^ 1]); }                                                                          \
   M4D_W6_MFMA(c, 1, B1) M4D_W6_MFMA(c, 0, B1)                                                                          \
-  asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][2]));                                                                     \
-  M4D_W6_PIPE(valu)                                                                                                    \
+  if (NEXT) { asm volatile("" : "+v"(A[((c) & 1) ^ 1][0][2])); M4D_W6_PIPE(valu) }                                     \
   __builtin_amdgcn_sched_barrier(0);
-#define M4D_W6_BLOCK2(c, cn, next_slot, valu)                                                                          \
-  frag_l(B1[0], next_slot, 0, 1); if (NTL == 2) frag_l(B1[1], next_slot, 1, 1);                                        \
-  gen_l(cn, 3, A[((c) & 1) ^ 1]);                                                                                   \
+#define M4D_W6_BLOCK2(c, cn, next_slot, valu, NEXT)                                                                    \
+  if (NEXT) { frag_l(B1[0], next_slot, 0, 1); if (NTL == 2) frag_l(B1[1], next_slot, 1, 1);                              \
+              gen_l(cn, 3, A[((c) & 1) ^ 1]); }                                                                          \
   M4D_W6_MFMA(c, 1, B0[(c) & 1]) M4D_W6_MFMA(c, 0, B0[(c) & 1])                                                        \
-  pin_a(A[((c) & 1) ^ 1]);                                                                                             \
-  M4D_W6_PIPE(valu)                                                                                                    \
+  if (NEXT) { pin_a(A[((c) & 1) ^ 1]); M4D_W6_PIPE(valu) }                                                             \
   __builtin_amdgcn_sched_barrier(0);
 
-  // Uniform loop body (no branches: one scheduling region per position).  Work past the last chunk is harmless: the
-  // surplus DMAs re-fetch the last chunk / position into buffers nobody reads any more, the surplus t / A are never multiplied.
+  // Uniform loop body (no branches: one scheduling region per position); the first and the last chunk are peeled.
   // Per position: barrier (the fragments of the NEXT position, DMA'd by both waves of the row, are visible from here on);
   // DMAs (one raw piece at columns 0-2, this wave's half of B four positions ahead); the MFMAs of this position interleaved
   // with the A operands of the next; then vmcnt(N) leaves exactly the DMAs of this and the previous position in flight
@@ -337,67 +333,76 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // every LDS read above (raw buffer 0, ring slot 0) has returned before this wave passes position 0's barrier, behind which
   // the other waves' DMAs start refilling that buffer and that slot (the K loop's waits include lgkmcnt(0) too)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  auto chunk_body = [&](int chunk, auto first_tag) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value != 0;
+  // LAST chunk (peeled): no DMA -- there is nothing left to fetch, and the surplus fetches of rounds 2-4 (harmless re-fetches of
+  // the last chunk) were 8 pieces in flight at the end of the K loop that the epilogue had to drain before reusing the LDS.  Its
+  // waits, DMAs in flight at its entry oldest first:
+  //   after a full chunk:           (n-2, 2)[4] (n-2, 3)[4]  -> position 0 ends with vmcnt(4) (slot 2, read by position 1, landed),
+  //                                                             position 1 with vmcnt(0) (slot 3), positions 2 / 3 need none
+  // (never the first chunk as well: a single-chunk layer runs the first chunk's body, with the surplus fetches of old)
+  // Position 3 of it prepares nothing for a next chunk (NEXT = false), position 2 reads no t(chunk + 1).
+  auto chunk_body = [&](int chunk, auto first_tag, auto last_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value != 0, LAST = decltype(last_tag)::value != 0;
     const unsigned char* wn = chunk < last ? wc + w_chunk : wc;                   // scalar select: B of the next chunk
     const int rnext_c = min(chunk + 2, last);
     const float4* rnext = raw + ((chunk + 1) & 1) * kRawSlots;
     // position 0: A(1) from t1, t2
     W6L_BARRIER();
     M4D_W6_STAMP(0)
-    M4D_W6_BLOCK0(0, 1, 1, 7)
-    W6L_RAW(rnext_c, chunk & 1, 0);
-    M4D_W6_BLOCK1(0, 1, 1, 4)
-    W6L_BDMA(wn, 0);
-    M4D_W6_BLOCK2(0, 1, 1, 4)
+    M4D_W6_BLOCK0(0, 1, 1, 7, true)
+    if (!LAST) W6L_RAW(rnext_c, chunk & 1, 0);
+    M4D_W6_BLOCK1(0, 1, 1, 4, true)
+    if (!LAST) W6L_BDMA(wn, 0);
+    M4D_W6_BLOCK2(0, 1, 1, 4, true)
     M4D_W6_STAMP(2)
-    W6L_WAIT(8);                                                                  // this position's DMAs + the previous position's
+    if (!LAST) W6L_WAIT(8);                                                       // this position's DMAs + the previous position's
+    else W6L_WAIT(4);
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 1: A(2) from t2, t1
     W6L_BARRIER();
     M4D_W6_STAMP(0)
-    M4D_W6_BLOCK0(1, 2, 2, 7)
-    W6L_RAW(rnext_c, chunk & 1, 1);
-    M4D_W6_BLOCK1(1, 2, 2, 4)
-    W6L_BDMA(wn + w_pos, 1);
-    M4D_W6_BLOCK2(1, 2, 2, 4)
+    M4D_W6_BLOCK0(1, 2, 2, 7, true)
+    if (!LAST) W6L_RAW(rnext_c, chunk & 1, 1);
+    M4D_W6_BLOCK1(1, 2, 2, 4, true)
+    if (!LAST) W6L_BDMA(wn + w_pos, 1);
+    M4D_W6_BLOCK2(1, 2, 2, 4, true)
     M4D_W6_STAMP(2)
-    W6L_WAIT(8);
+    if (!LAST) W6L_WAIT(8);
+    else W6L_WAIT(0);
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 2: A(3) from t1, t3; columns 0, 2 of t(chunk + 1)
     W6L_BARRIER();
     M4D_W6_STAMP(0)
-    M4D_W6_BLOCK0(2, 3, 3, 7)
-    W6L_RAW(rnext_c, chunk & 1, 2);
-    read_t(rnext, 0);
-    M4D_W6_BLOCK1(2, 3, 3, 6)
-    W6L_BDMA(wn + 2 * w_pos, 2);
-    pin_t(0);
-    M4D_W6_BLOCK2(2, 3, 3, 6)
+    M4D_W6_BLOCK0(2, 3, 3, 7, true)
+    if (!LAST) { W6L_RAW(rnext_c, chunk & 1, 2); read_t(rnext, 0); }
+    M4D_W6_BLOCK1(2, 3, 3, 6, true)
+    if (!LAST) { W6L_BDMA(wn + 2 * w_pos, 2); pin_t(0); }
+    M4D_W6_BLOCK2(2, 3, 3, 6, true)
     M4D_W6_STAMP(2)
-    W6L_WAIT(8);
+    if (!LAST) W6L_WAIT(8);
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // (the fragment reads for position 3)
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
     // position 3: columns 1, 3 of t(chunk + 1) first (A(chunk + 1, 0) = t0 - t2 needs column ... 0 and 2 only)
     W6L_BARRIER();
     M4D_W6_STAMP(0)
-    M4D_W6_BLOCK0(3, 0, 0, 7)
-    W6L_RAW(rnext_c, chunk & 1, 3);
-    read_t(rnext, 1);
-    M4D_W6_BLOCK1(3, 0, 0, 6)
-    W6L_BDMA(wn + 3 * w_pos, 3);
-    pin_t(1);
-    M4D_W6_BLOCK2(3, 0, 0, 6)
+    M4D_W6_BLOCK0(3, 0, 0, 7, !LAST)
+    if (!LAST) { W6L_RAW(rnext_c, chunk & 1, 3); read_t(rnext, 1); }
+    M4D_W6_BLOCK1(3, 0, 0, 6, !LAST)
+    if (!LAST) { W6L_BDMA(wn + 3 * w_pos, 3); pin_t(1); }
+    M4D_W6_BLOCK2(3, 0, 0, 6, !LAST)
     M4D_W6_STAMP(2)
-    W6L_WAIT(8);
+    if (!LAST) W6L_WAIT(8);
     M4D_W6_STAMP(3)
     if (STAMPS) ++stq;
-    wc = wn;
+    if (!LAST) wc = wn;
   };
-  chunk_body(0, m4d_int<1>{});
-  for (int chunk = 1; chunk < n; ++chunk) chunk_body(chunk, m4d_int<0>{});
+  chunk_body(0, m4d_int<1>{}, m4d_int<0>{});     // (a single-chunk layer, Cin = 16, ends here: with its surplus fetches, as before)
+  if (n > 1) {
+    for (int chunk = 1; chunk < last; ++chunk) chunk_body(chunk, m4d_int<0>{}, m4d_int<0>{});
+    chunk_body(last, m4d_int<0>{}, m4d_int<1>{});
+  }
   };
   if (half) k_loop(m4d_int<1>{}); else k_loop(m4d_int<2>{});
 #undef M4D_W6_MFMA
