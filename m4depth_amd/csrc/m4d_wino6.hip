@@ -417,22 +417,25 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   if (STAMPS && st && wv == 0) st[1024 + 1] = __builtin_readcyclecounter();
   __syncthreads();                                 // every wave is done with raw / the rings: the epilogue buffer aliases them
 
-  // ---- output transform: rows of A^T (M A) through LDS per (N-tile, M-tile), then one 2x2-output item x 4 couts per thread
-  float bs[2][4];                                  // this thread's output-channel quad of the bias, per N-tile: loaded here (not
-#pragma unroll                                     // held across the K loop), the latency hides behind the LDS pass below
-  for (int ont = 0; ont < 2; ++ont)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int co = ng * 64 + ont * 32 + 4 * (t & 7) + e;
-      bs[ont][e] = a.bias[min(co, a.Cout - 1)];
-    }
+  // ---- output transform: rows of A^T (M A) through LDS per (N-tile, M-tile), then one 2x2-output item x 4 couts per thread.
+  // Items of a full unit: 16 consecutive lanes = the 16 cout quads of ONE pixel (both N-tiles: 256 contiguous bytes per store
+  // instruction and pixel, 4 pixels per instruction).  Rounds 2-4 walked the N-tiles one after the other: 8 lanes = 128 bytes
+  // per pixel, 8 pixels per instruction -- the pattern a CU issues at 16 B/clk instead of ~100 (tools/micro/
+  // store_issue_probe.hip: 4004 against 645 cycles for a unit's 64 KB).  N-tile 1's staging blocks are skewed by 32 floats:
+  // the two cout halves of a pixel then sit in different LDS banks (one 16-lane read group covers 64 distinct banks).
+  const int cq16 = half ? (t & 7) : (t & 15);      // this thread's cout quad of the unit (both of its items)
+  const int co = ng * 64 + 4 * cq16;
+  float bs[4];                                     // its bias quad: loaded here (not held across the K loop), the latency hides
+#pragma unroll                                     // behind the LDS pass below
+  for (int e = 0; e < 4; ++e) bs[e] = a.bias[min(co + e, a.Cout - 1)];
   constexpr int kMS = 36;                          // row stride (floats): 32 couts + 4 pad (16-byte aligned rows)
   constexpr int kRbMT = 4 * 2 * 32 * kMS;          // floats per (N-tile, M-tile): [4 rows i][2 k][32 tiles][kMS] = 36.9 KB
+  constexpr int kRbSkew = 32;                      // floats: N-tile 1's blocks start half a bank row later
   float* Rb = lds;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     if (nt == 1 && half) break;                    // (a half unit never touched N-tile 1's accumulators)
-    float* rbuf = Rb + (nt * 2 + mt) * kRbMT;
+    float* rbuf = Rb + (nt * 2 + mt) * kRbMT + nt * kRbSkew;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
@@ -445,16 +448,16 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   float* oimg = a.out + (long long)bi * a.h * a.w * a.Cout;
   const bool vec_ok = (a.Cout & 3) == 0;
   const bool whole = tile_x + kT <= a.w && tile_y + kT <= a.h;      // uniform: no per-store bounds tests on interior tiles
+  const bool fast = whole && vec_ok && ng * 64 + (half ? 32 : 64) <= a.Cout;   // ... and every cout quad of the unit is real
+  const int ont = cq16 >> 3, cq = cq16 & 7;        // N-tile and quad inside it
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     if (it == 1 && half) break;
-    const bool fast = whole && vec_ok && ng * 64 + 32 * it + 32 <= a.Cout;   // ... and every cout quad of the N-tile is real
-    const int item = it * 512 + t;                 // (N-tile, M-tile, tile in M-tile, cout quad)
-    const int cq = item & 7, tl = (item >> 3) & 31, omt = (item >> 8) & 1, ont = it;
-    const float* rbuf = Rb + (ont * 2 + omt) * kRbMT;
+    // full unit: item = (M-tile it, tile, cout quad of 16); half unit: (M-tile, tile, cout quad of 8), one item per thread
+    const int tl = half ? (t >> 3) & 31 : (t >> 4) & 31, omt = half ? (t >> 8) : it;
+    const float* rbuf = Rb + (ont * 2 + omt) * kRbMT + ont * kRbSkew;
     const int tg = omt * 32 + tl;                  // Winograd tile 0..63 of the workgroup (8 x 8)
     const int ty2 = tg >> 3, tx2 = tg & 7;
-    const int co = ng * 64 + ont * 32 + 4 * cq;
     float4 rv[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -467,8 +470,8 @@ conv3x3_wino6_kernel(const Wino6Args a) {
       const float* r2 = reinterpret_cast<const float*>(&rv[2][k]); const float* r3 = reinterpret_cast<const float*>(&rv[3][k]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v0 = ((r0[e] + r1[e]) + r2[e]) + bs[ont][e];
-        const float v1 = ((r1[e] - r2[e]) - r3[e]) + bs[ont][e];
+        const float v0 = ((r0[e] + r1[e]) + r2[e]) + bs[e];
+        const float v1 = ((r1[e] - r2[e]) - r3[e]) + bs[e];
         y[k][0][e] = v0 > 0.f ? v0 : v0 * a.slope;
         y[k][1][e] = v1 > 0.f ? v1 : v1 * a.slope;
       }
@@ -568,7 +571,7 @@ extern "C" int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, con
   a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.n_chunks = Cin / 16; a.slope = slope;
   a.tiles_x = (w + kT - 1) / kT; a.tiles_y = (h + kT - 1) / kT;
   a.stamps = g_wino6_stamps;
-  constexpr size_t lds_epi = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);             // epilogue staging 147 KB
+  constexpr size_t lds_epi = (size_t)(4 * 4 * 2 * 32 * 36 + 32) * sizeof(float);        // epilogue staging 147 KB (+ N-tile 1's skew)
   constexpr size_t lds_loop = (size_t)kBRingOff + 4 * kBRingBytes;                      // K loop: raw halo x 2 + fragment rings (154 KB)
   constexpr size_t lds = lds_epi > lds_loop ? lds_epi : lds_loop;
   static_assert(lds <= 160 * 1024, "LDS budget of one CU");
