@@ -418,15 +418,22 @@ conv3x3_small_kernel(const ConvArgs a) {
 
   // this wave's chunks: wave, wave + 4, ...  The next chunk's loads are in flight while the current one is multiplied;
   // the LDS region is private to the wave, whose DS operations execute in order: no workgroup barrier here.
+  // The last round is peeled: it loads nothing (rounds 1-4 kept the loop uniform with a surplus, never committed load -- which
+  // the __syncthreads() below then waited for: a memory round trip at the end of every launch of a latency-bound kernel).
   if (wave < a.n_chunks) {
     load_chunk(wave);
-    for (int c = wave; c < a.n_chunks; c += 4) {
+    int c = wave;
+    for (; c + 4 < a.n_chunks; c += 4) {
       commit_chunk();
       __builtin_amdgcn_wave_barrier();
-      load_chunk(min(c + 4, a.n_chunks - 1));          // unconditional (the surplus load of the last round is never committed)
+      load_chunk(c + 4);                               // unconditional inside the loop (a load under a branch is waited for at the merge)
       compute_chunk();
       __builtin_amdgcn_wave_barrier();
     }
+    commit_chunk();
+    __builtin_amdgcn_wave_barrier();
+    compute_chunk();
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();                                     // the reduction buffer aliases the staging regions
 
@@ -594,15 +601,21 @@ conv3x3_small6_kernel(const ConvArgs a) {
 
   // (Measured: a second chunk of operands in flight -- 2 x 108 staging registers -- is slower: 24.2 vs 22.5 us on the
   // 472-channel layer; the chunk time is set by how many bytes ONE CU keeps in flight, not by this wave's prefetch depth.)
+  // (last round peeled: no surplus load for the __syncthreads() below to wait for -- see conv3x3_small_kernel)
   if (wave < a.n_chunks) {
     load_chunk(wave, 0);
-    for (int c = wave; c < a.n_chunks; c += 4) {
+    int c = wave;
+    for (; c + 4 < a.n_chunks; c += 4) {
       commit_chunk(0);
       __builtin_amdgcn_wave_barrier();
-      load_chunk(min(c + 4, a.n_chunks - 1), 0);       // unconditional (the surplus load of the last round is never committed)
+      load_chunk(c + 4, 0);
       compute_chunk();
       __builtin_amdgcn_wave_barrier();
     }
+    commit_chunk(0);
+    __builtin_amdgcn_wave_barrier();
+    compute_chunk();
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();                                     // the reduction buffer aliases the staging regions
 
