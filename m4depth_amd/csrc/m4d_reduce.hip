@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int kDinlMaxBlocks = 256;
+constexpr int kDinlMaxBlocks = 512;
 
 // pass 0: sum x ; pass 1: sum (x - mean)^2, per (batch, channel); C % 4 == 0, C/4 divides 256
 __global__ void __launch_bounds__(256)
