@@ -1115,12 +1115,15 @@ class M4Depth(torch.nn.Module):
                 for i, m in enumerate(ms)))
             if not shared and all(m.total is None for m in ms):
                 acc = self._metric_acc = torch.zeros(7, dtype=torch.float32, device=gt_raw.device)
-                self._metric_mean = torch.zeros(7, dtype=torch.float32, device=gt_raw.device)
                 for i, m in enumerate(ms):
                     m.total = acc[i]
                     m.count = 0
                 shared = True
             if shared:
+                # a FRESH result tensor per step (the caching allocator makes that a host-side pointer bump): what test_step
+                # returns must not alias the next step's results, and a clone of one shared buffer was a 5-us copy kernel plus a
+                # launch gap at the end of every step
+                self._metric_mean = torch.empty(7, dtype=torch.float32, device=gt_raw.device)
                 nops.depth_metrics(gt_raw, est_raw, max_d, total=acc, count=ms[0].count + 1, mean=self._metric_mean)
                 for m in ms:
                     m.count += 1
@@ -1143,8 +1146,7 @@ class M4Depth(torch.nn.Module):
         if acc is not None and ms and all(m.total is not None and m.total.data_ptr() == acc[i].data_ptr()
                                           and m.count == ms[0].count for i, m in enumerate(ms)):
             if getattr(self, "_metric_mean_count", -1) == ms[0].count and ms[0].count > 0:
-                res = self._metric_mean.clone()              # written by the metric kernel itself; a copy: results a caller
-                                                             # keeps per step (a Keras-style history) must not alias the buffer
+                res = self._metric_mean                      # written by the metric kernel itself, into this step's own tensor
             else:
                 res = acc / float(max(ms[0].count, 1))
             return {m.name: res[i] for i, m in enumerate(ms)}
