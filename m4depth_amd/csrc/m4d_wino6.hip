@@ -26,7 +26,12 @@
 // and cost 10 % of the kernel; pixels outside the image come back as zeros from the buffer descriptor's range check).  The DMAs are inline asm with hand-counted s_waitcnt vmcnt(N) -- the compiler would drain every DMA in
 // flight (vmcnt(0)) before any LDS read it cannot prove independent; one raw s_barrier per position makes the partner's
 // fragments visible.  The B registers are refilled part by part as the MFMAs of the current position retire them.
-// Epilogue as in kernel 4 of m4d_wino.hip: rows of A^T (M A) through LDS, bias + leaky_relu, 16-byte stores.
+// Epilogue as in kernel 4 of m4d_wino.hip: rows of A^T (M A) through LDS, bias + leaky_relu, 16-byte stores (16 lanes = the 256
+// contiguous bytes of a pixel's 64 couts).
+// Round 4: a unit is prologue 2.6 + K loop 24 + epilogue 2.5 us on the level-1 128 -> 128 layer, and at batch 1 every layer is
+// 1-4 such units per CU, so the unit's BOUNDARY counts: the first chunk is peeled and multiplies onto the constant 0 (no
+// accumulator zeroing), the last chunk is peeled and issues no DMA (nothing for the epilogue to drain).  HALF units: a cout group
+// of <= 32 channels (Cout = 96's second group, Cout = 32) runs N-tile 0 only, a second instantiation of the K loop.
 // Deterministic: fixed summation order, no atomics.
 #include <cstdlib>
 #include "m4d_common.h"
