@@ -98,6 +98,9 @@ template <bool STAMPS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3x3_wino6_kernel(const Wino6Args a) {
   extern __shared__ __align__(16) float lds[];
+  // every kernel argument fetched by the FIRST scalar loads (hipcc issued the load of the pointers ~100 instructions later, behind
+  // the tile decode's divisions: a scalar-memory round trip right in front of the first DMA of every unit)
+  asm volatile("" : : "s"(a.x), "s"(a.wu), "s"(a.out), "s"(a.bias));
   float4* raw = reinterpret_cast<float4*>(lds);                      // [2][kRawSlots]
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address (for M0)
 
