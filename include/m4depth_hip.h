@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 4   /* 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -424,6 +424,12 @@ int m4d_conv3x3s2_dinl_bias_act(const float* x_raw, const float* mean, const flo
 long long m4d_metrics_workspace_bytes(void);
 int m4d_depth_metrics(const float* gt, const float* est, long long n, float max_d, void* workspace,
                       float* out7, float* total7, float count, float* mean7, void* stream);
+/* The same with the ground truth read in place out of a larger tensor: image j (per_image floats) starts at
+ * gt + j * gt_image_stride -- the last frame of a [b,T,H,W,1] sequence batch (test_step, m4depth_network.py:455-456) without
+ * the dense copy a framework slice costs at batch > 1.  Same per-thread element order as the dense form: the same bits. */
+int m4d_depth_metrics_strided(const float* gt, long long per_image, long long gt_image_stride, const float* est,
+                              long long n, float max_d, void* workspace, float* out7, float* total7, float count,
+                              float* mean7, void* stream);
 
 /* ---- training without MIOpen (train_step, m4depth_network.py:371-399: tf.GradientTape through every Conv2D) ---------- */
 

@@ -12,9 +12,12 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm4depth_hip.so")
+# M4D_LIB_FLAVOUR=experiments selects the `make EXPERIMENTS=1` library (libm4depth_hip_exp.so: the product kernels + the
+# measured-and-not-dispatched ones of tools/experiments/csrc with their process-global selectors); anything else = the product
+LIB_FLAVOUR = os.environ.get("M4D_LIB_FLAVOUR", "product")
+LIB_PATH = os.path.join(_HERE, "libm4depth_hip_exp.so" if LIB_FLAVOUR == "experiments" else "libm4depth_hip.so")
 
-ABI_VERSION = 4               # M4D_ABI_VERSION of include/m4depth_hip.h this binding was written for
+ABI_VERSION = 5               # M4D_ABI_VERSION of include/m4depth_hip.h this binding was written for
 
 _c_fp = ctypes.c_void_p       # device pointers travel as void*
 _c_int = ctypes.c_int
@@ -85,6 +88,8 @@ _SIGNATURES = {
     "m4d_refiner_tail6": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f,
                           _c_fp, _c_fp, _c_fp, _c_fp, _c_fp],
     "m4d_depth_metrics": [_c_fp, _c_fp, ctypes.c_longlong, _c_f, _c_fp, _c_fp, _c_fp, _c_f, _c_fp, _c_fp],
+    "m4d_depth_metrics_strided": [_c_fp, ctypes.c_longlong, ctypes.c_longlong, _c_fp, ctypes.c_longlong, _c_f, _c_fp, _c_fp, _c_fp,
+                                  _c_f, _c_fp, _c_fp],
     "m4d_level_pre": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int,
                       _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_level_pre_normalize": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int,
@@ -161,9 +166,9 @@ has_experiments = hasattr(lib, "m4d_tape_begin")      # a `make EXPERIMENTS=1` b
 
 def require_experiments(what):
     if not has_experiments:
-        raise RuntimeError(f"{what} needs the experiments build of the library: make -C m4depth_amd/csrc clean && "
-                           "make -C m4depth_amd/csrc EXPERIMENTS=1 (include/m4depth_hip_experiments.h); the product "
-                           "library exports only the kernels it dispatches")
+        raise RuntimeError(f"{what} needs the experiments build of the library: make -C m4depth_amd/csrc EXPERIMENTS=1 "
+                           "(-> libm4depth_hip_exp.so, sources in tools/experiments/csrc) and M4D_LIB_FLAVOUR=experiments in "
+                           "the environment; the product library exports only the kernels it dispatches")
 
 
 def build_info() -> str:
@@ -201,6 +206,14 @@ def as_f32(t, name):
     """Dense float32 device tensor (copies only when a conversion is needed)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor")
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        # a conversion here would put a framework copy kernel into the captured graph (round 4: ~43 per batch-32 step, the
+        # [:, t] slices of batch-major rot / trans): the capturing callers hand over dense frame-major tensors instead
+        raise RuntimeError(f"{name}: a non-contiguous / non-float32 tensor (shape {tuple(t.shape)}, strides {t.stride()}, "
+                           f"{t.dtype}) reached a kernel wrapper inside a hipGraph capture; it would be copied by a framework "
+                           "kernel inside the graph -- make it dense before capturing")
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()

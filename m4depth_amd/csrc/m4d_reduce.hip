@@ -175,12 +175,20 @@ constexpr int kMetricBlocks = 512;
 
 __global__ void __launch_bounds__(256)
 metrics_partial_kernel(const float* __restrict__ gt_raw, const float* __restrict__ est_raw, long long n, float max_d,
-                       double* __restrict__ partial) {
+                       double* __restrict__ partial, long long per_image, long long gt_image_stride) {
+  // gt image j starts at gt_raw + j * gt_image_stride (the last frame of a [b,T,H,W,1] sequence batch, read in place:
+  // m4depth_network.py:455); element i of the dense walk = (image i / per_image, offset i % per_image), kept incrementally --
+  // same elements per thread in the same order as the dense form, so the sums are the same bits
   float s[kMetricSums];
 #pragma unroll
   for (int k = 0; k < kMetricSums; ++k) s[k] = 0.f;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float gt = fminf(fmaxf(gt_raw[i], 0.0f), max_d);               // m4depth_network.py:465-467
+  const long long step = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long img = i / per_image, off = i - img * per_image;
+  for (; i < n; i += step) {
+    const float gt = fminf(fmaxf(gt_raw[img * gt_image_stride + off], 0.0f), max_d);               // m4depth_network.py:465-467
+    off += step;
+    while (off >= per_image) { off -= per_image; ++img; }
     const float est = fminf(fmaxf(est_raw[i], 0.001f), max_d);
     const bool m = gt > 1e-6f;                                            // metrics.py:3-5
     const float diff = gt - est;
@@ -620,14 +628,20 @@ extern "C" int m4d_enc_level0_fwd(const float* images, int bsz, long long stride
 
 extern "C" long long m4d_metrics_workspace_bytes(void) { return (long long)kMetricBlocks * kMetricSums * sizeof(double); }
 
-extern "C" int m4d_depth_metrics(const float* gt, const float* est, long long n, float max_d, void* workspace,
-                                 float* out7, float* total7, float count, float* mean7, void* stream) {
-  M4D_CHECK_ARG(gt && est && workspace && out7 && n > 0);
+extern "C" int m4d_depth_metrics_strided(const float* gt, long long per_image, long long gt_image_stride, const float* est,
+                                         long long n, float max_d, void* workspace, float* out7, float* total7, float count,
+                                         float* mean7, void* stream) {
+  M4D_CHECK_ARG(gt && est && workspace && out7 && n > 0 && per_image > 0 && gt_image_stride >= per_image && n % per_image == 0);
   M4D_CHECK_ARG(!mean7 || (total7 && count > 0.f));
   hipStream_t s = (hipStream_t)stream;
   long long g = (n + 255) / 256;
   const int nblk = (int)(g < kMetricBlocks ? g : kMetricBlocks);
-  m4d_launch(metrics_partial_kernel, dim3(nblk), dim3(256), 0, s, gt, est, n, max_d, (double*)workspace);
+  m4d_launch(metrics_partial_kernel, dim3(nblk), dim3(256), 0, s, gt, est, n, max_d, (double*)workspace, per_image, gt_image_stride);
   m4d_launch(metrics_finalize_kernel, dim3(1), dim3(kMetricSums * 32), 0, s, (const double*)workspace, nblk, out7, total7, count, mean7);
   return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_depth_metrics(const float* gt, const float* est, long long n, float max_d, void* workspace,
+                                 float* out7, float* total7, float count, float* mean7, void* stream) {
+  return m4d_depth_metrics_strided(gt, n, n, est, n, max_d, workspace, out7, total7, count, mean7, stream);
 }

@@ -16,7 +16,6 @@ from collections import namedtuple
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import network_ops as nops
 from ._lib import lib, dptr, stream_ptr, check, as_f32
@@ -440,22 +439,18 @@ class DomainNormalization(torch.nn.Module):
 
     def forward(self, f_map, slope=1.0):
         """``slope`` != 1 additionally applies the leaky_relu that follows the layer in the
-        encoder (fused into the same HIP pass on the GPU)."""
+        encoder (fused into the same HIP pass).  One hand-written kernel (m4d_dinl_fwd_padded); like the convolutions this
+        layer has no CPU / framework form in the product: a CPU tensor or a width the kernel has no instantiation for raises
+        (the host-logic tests patch a torch stand-in from tests/helpers.py; the TRAINING graph records the layer with torch
+        autograd ops, training.dinl_autograd)."""
         if self.scale is None:
             self._build(f_map.shape[-1], f_map.device)
-        if f_map.is_cuda and f_map.shape[-1] in (16, 32):
-            return nops.dinl_act(f_map, self.scale, self.bias, slope)
-        out = self._forward_torch(f_map)
-        return out if slope == 1.0 else F.leaky_relu(out, slope)
-
-    def _forward_torch(self, f_map):
-        mean = f_map.mean(dim=(1, 2), keepdim=True)
-        centred = f_map - mean
-        var = (centred * centred).mean(dim=(1, 2), keepdim=True)
-        n = centred / (var + 1e-12)
-        ss = (n * n).sum(dim=-1, keepdim=True)
-        n = n * torch.rsqrt(torch.clamp_min(ss, 1e-12))               # tf.math.l2_normalize
-        return self.scale * n + self.bias
+        if not f_map.is_cuda:
+            raise RuntimeError("m4depth_amd DomainNormalization runs on the GPU only (libm4depth_hip.so): got a CPU tensor; "
+                               "there is no CPU fallback")
+        if f_map.shape[-1] not in (16, 32):
+            raise ValueError(f"DomainNormalization: the HIP kernel is instantiated for 16 and 32 channels, not {f_map.shape[-1]}")
+        return nops.dinl_act(f_map, self.scale, self.bias, slope)
 
 
 class FeaturePyramid(torch.nn.Module):
@@ -970,8 +965,10 @@ class M4Depth(torch.nn.Module):
                     conv._packed_weights_winograd(16)
                     if cin % 4 == 0:
                         conv._packed_weights_winograd(8)
-                    if cin % 16 == 0 and cin >= 32 and conv.out_channels >= 64:
-                        conv._packed_weights_wino6()
+                    if cin % 16 == 0 and cin >= 32 and conv.out_channels >= min(wino6_min_cout, 32):
+                        conv._packed_weights_wino6()    # the dispatch's own condition (_use_winograd): a replayed hipGraph is
+                                                        # refreshed through prepack() alone, so every layout a layer CAN be
+                                                        # dispatched to must be (re)built here (round 4 left 64 -> 32 out)
         for lvl in self.d_estimator.levels:
             convs = list(lvl.disp_refiner.prep_conv_layers) + list(lvl.disp_refiner.est_d_conv_layers)
             c0 = convs[0] if convs else None
@@ -982,7 +979,7 @@ class M4Depth(torch.nn.Module):
                 c0._packed_weights_winograd(8, cin_pad)
                 if small_conv_split and cin_pad <= 256:
                     c0._packed_weights_small6(cin_pad)
-                if cin_pad % 16 == 0 and c0.out_channels >= 64:
+                if cin_pad % 16 == 0 and cin_pad >= 32 and c0.out_channels >= min(wino6_min_cout, 32):
                     c0._packed_weights_wino6(cin_pad)
             if len(convs) == 7 and convs[5].weight is not None and convs[5].weight.is_cuda \
                     and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16):
@@ -1050,6 +1047,11 @@ class M4Depth(torch.nn.Module):
     def _forward_inference(self, data, training=False):
         traj_samples, camera = data[0], data[1]
         self.step_counter += 1
+        # rot / trans dense float32 ONCE per frame (test_step's unstacking, m4depth_network.py:439-447, hands over [:, t] slices:
+        # non-contiguous from batch 2 on -- converted here they cost one tiny copy per frame instead of one per level)
+        traj_samples = [dict(s, rot=as_f32(s["rot"], "rot"), trans=as_f32(s["trans"], "trans"))
+                        if isinstance(s.get("rot"), torch.Tensor) and isinstance(s.get("trans"), torch.Tensor) else s
+                        for s in traj_samples]
         # The encoder is independent per frame (:358-360): run it ONCE on the frames stacked along
         # the batch axis (same per-sample arithmetic incl. the per-sample DINL statistics, a
         # quarter of the launches), then hand each frame its slice.
@@ -1215,12 +1217,20 @@ class GraphedSequence:
     copies), replays, and returns the static ``depth`` output tensor.  The batch must have the captured shapes and
     the captured ``new_traj`` pattern (it is control flow here); anything else raises."""
 
-    def __init__(self, model, example, warmup=2):
+    def __init__(self, model, example, warmup=2, debug_dot=None):
+        """``debug_dot``: a path -- the captured graph is dumped there in DOT form (hipGraphDebugDotPrint through
+        torch.cuda.CUDAGraph.debug_dump): one node per kernel with its mangled name, see ``kernel_nodes``."""
         self.model = model
         nt = example["new_traj"]
         self.new_traj = nt.clone() if isinstance(nt, torch.Tensor) else torch.as_tensor(np.asarray(nt))
-        self.static = {k: example[k].clone() for k in ("RGB_im", "rot", "trans")}
-        self.camera = {k: v.clone() for k, v in example["camera"].items()}
+        # rot / trans are kept FRAME-major ([T,b,k]) so that a frame's slice is dense at every batch size: a [:, t] slice of the
+        # batch-major tensor is non-contiguous from batch 2 on and every level wrapper would copy it with a framework kernel
+        # INSIDE the graph (round 4, batch 32: ~43 copy nodes per step on the latency chain).  The batch-major [b,T,k] views of
+        # the same memory are what input_buffers() hands out and what __call__ copies new batches into.
+        self._rot = as_f32(example["rot"], "rot").transpose(0, 1).contiguous()
+        self._trans = as_f32(example["trans"], "trans").transpose(0, 1).contiguous()
+        self.static = {"RGB_im": example["RGB_im"].clone(), "rot": self._rot.transpose(0, 1), "trans": self._trans.transpose(0, 1)}
+        self.camera = {k: as_f32(v, f"camera[{k}]").clone() for k, v in example["camera"].items()}
         self.seq_len = self.static["RGB_im"].shape[1]
         model.prepack()
         self.stream = torch.cuda.Stream()
@@ -1231,14 +1241,25 @@ class GraphedSequence:
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        if debug_dot is not None:
+            self.graph.enable_debug_mode()
         with torch.cuda.graph(self.graph, stream=self.stream):
             self.depth = self._run()
+        if debug_dot is not None:
+            self.graph.debug_dump(str(debug_dot))
         self.weights_stamp = model.weights_stamp()
+
+    @staticmethod
+    def kernel_nodes(dot_path):
+        """The kernel names (mangled) of a ``debug_dot`` dump, in node order."""
+        import re
+        text = open(dot_path).read()
+        return re.findall(r'label="\d+\n([^\n"]+)\n', text)
 
     def _samples(self):
         nt = torch.unbind(self.new_traj, dim=1)
-        return [{"RGB_im": self.static["RGB_im"][:, t], "rot": self.static["rot"][:, t],
-                 "trans": self.static["trans"][:, t], "new_traj": nt[t]} for t in range(self.seq_len)]
+        return [{"RGB_im": self.static["RGB_im"][:, t], "rot": self._rot[t], "trans": self._trans[t], "new_traj": nt[t]}
+                for t in range(self.seq_len)]
 
     def _run(self):
         return self.model([self._samples(), self.camera])["depth"]

@@ -174,12 +174,19 @@ def depth_metrics(gt, est, max_d=80.0, total=None, count=0, mean=None):
     """The 7 metrics of metrics.py for one batch, one pass: returns a [7] device tensor
     (AbsRel, SqRel, RMSE, RMSE_log, Delta1, Delta2, Delta3); clipping as in test_step.
     ``total`` [7] (Keras-Mean totals) is incremented and ``mean`` [7] = total / count written in the same launch."""
-    gt = as_f32(gt, "gt")
     est = as_f32(est, "est")
     if gt.numel() != est.numel():
         raise ValueError(f"gt {tuple(gt.shape)} and est {tuple(est.shape)} differ in size")
-    ws = _workspace("metrics", int(lib.m4d_metrics_workspace_bytes()), gt.device)
-    out = torch.empty(7, dtype=torch.float32, device=gt.device)
+    ws = _workspace("metrics", int(lib.m4d_metrics_workspace_bytes()), est.device)
+    out = torch.empty(7, dtype=torch.float32, device=est.device)
+    if (gt.is_cuda and gt.dtype == torch.float32 and gt.dim() >= 2 and not gt.is_contiguous() and gt[0].is_contiguous()
+            and gt.stride(0) >= gt[0].numel()):
+        # dense images at a batch stride: data["depth"][:, -1] of a [b,T,H,W,1] sequence batch, read in place
+        check(lib.m4d_depth_metrics_strided(ctypes.c_void_p(gt.data_ptr()), gt[0].numel(), gt.stride(0), dptr(est, "est"),
+                                            gt.numel(), float(max_d), dptr(ws), dptr(out), dptr(total, "total"), float(count),
+                                            dptr(mean, "mean"), stream_ptr()), "m4d_depth_metrics_strided")
+        return out
+    gt = as_f32(gt, "gt")
     check(lib.m4d_depth_metrics(dptr(gt, "gt"), dptr(est, "est"), gt.numel(), float(max_d), dptr(ws), dptr(out),
                                 dptr(total, "total"), float(count), dptr(mean, "mean"), stream_ptr()), "m4d_depth_metrics")
     return out

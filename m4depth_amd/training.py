@@ -253,6 +253,19 @@ def level_forward_train(level, curr_f_maps, prev_l_est, rot, trans, camera, prev
     return {"other": other, "depth": depth, "parallax": para_curr}
 
 
+def dinl_autograd(dn, f_map):
+    """DomainNormalization (m4depth_network.py:24-48) as the node the TRAINING graph records: (x - mean_hw) / (var_hw + 1e-12),
+    l2-normalised over the channels, scale and bias -- torch autograd ops standing where tf.GradientTape stands (the
+    inference forward runs the HIP kernel m4d_dinl_fwd_padded instead, network.DomainNormalization.forward)."""
+    mean = f_map.mean(dim=(1, 2), keepdim=True)
+    centred = f_map - mean
+    var = (centred * centred).mean(dim=(1, 2), keepdim=True)
+    n = centred / (var + 1e-12)
+    ss = (n * n).sum(dim=-1, keepdim=True)
+    n = n * torch.rsqrt(torch.clamp_min(ss, 1e-12))               # tf.math.l2_normalize
+    return dn.scale * n + dn.bias
+
+
 def encoder_forward_train(encoder, images, cache):
     """FeaturePyramid.call (m4depth_network.py:76-90), recorded by autograd."""
     fm = as_f32(images, "images")
@@ -262,7 +275,7 @@ def encoder_forward_train(encoder, images, cache):
             t = conv_bias_act(c1, fm, None, cache)
             if dn.scale is None:
                 dn._build(t.shape[-1], t.device)
-            t = F.leaky_relu(dn._forward_torch(t), 0.1)
+            t = F.leaky_relu(dinl_autograd(dn, t), 0.1)
         else:
             t = conv_bias_act(c1, fm, 0.1, cache)
         fm = conv_bias_act(c2, t, 0.1, cache)

@@ -401,6 +401,34 @@ def test_inference_follows_parameter_updates(dev):
     assert torch.equal(runner(d), after), "the captured graph replayed stale packed weights"
 
 
+def test_graph_replay_after_update_refreshes_every_dispatched_layout(dev, monkeypatch):
+    """a captured hipGraph is refreshed through ``prepack()`` ALONE, so prepack must rebuild every packed layout a
+    layer is dispatched to.  Round 4's prepack built the bf16-split Winograd copy only for Cout >= 64 while the dispatch sent
+    the refiner's 64 -> 32 layer there too: the replay kept the old weights.  Here every eligible layer is forced onto that
+    kernel (``wino6_min_workgroups`` = 1) and NO eager forward runs between the update and the replay."""
+    from m4depth_amd import network as net
+    monkeypatch.setattr(net, "wino6_min_workgroups", 1)
+    L, H, Wd, T, b = 3, 64, 96, 2, 1
+    W = S.init_weights(L, seed=8)
+    model = _model(dev, L, W)
+    assert net._use_winograd(b, H // 2, Wd // 2, 64, 32, 1) == 6, "the 64 -> 32 layer must be on the bf16-split Winograd kernel"
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=31)
+    d = {k: torch.stack([to_dev(s[k], dev) for s in samples], dim=1) for k in ("depth", "RGB_im", "rot", "trans")}
+    d["new_traj"] = torch.stack([torch.from_numpy(s["new_traj"]) for s in samples], dim=1)
+    d["camera"] = to_dev(cam, dev)
+    ds, dc = to_dev(samples, dev), to_dev(cam, dev)
+    runner = net.GraphedSequence(model, d)
+    before = runner(d).clone()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.0 + 0.05 * torch.randn(p.shape, generator=g).to(p.device))
+    replayed = runner(d).clone()                                        # straight to the replay: prepack() is all that runs
+    assert not torch.equal(replayed, before)
+    fresh = _model(dev, L, model.numpy_weights())
+    assert torch.equal(fresh([ds, dc])["depth"], replayed), "the captured graph replayed a stale packed layout"
+
+
 def test_weight_loads_after_capture_and_metric_result_copies(dev):
     """(1) ``load_numpy_weights`` / ``load_hwio`` on a built model overwrite the parameters in place, so a
     hipGraph captured BEFORE the load replays the new weights; a parameter that is REPLACED after the capture makes the

@@ -261,6 +261,59 @@ def test_graphed_sequence_matches_eager(dev):
         runner(bad)
 
 
+def test_graphed_batch2_has_only_library_kernels(dev, tmp_path):
+    """from batch 2 on the [:, t] slices of batch-major rot / trans are non-contiguous and every level
+    wrapper used to copy them with a framework kernel INSIDE the captured graph (batch 32: ~43 at::native copy nodes per step).
+    GraphedSequence keeps them frame-major now and ``as_f32`` refuses to copy under a capture; here a batch-2 sequence is
+    captured, the graph dumped (hipGraphDebugDotPrint) and every kernel node must be one of libm4depth_hip.so's; the strided
+    ground truth of the metric kernel (data["depth"][:, -1] read in place) gives the bits of the dense copy."""
+    import re
+    import m4depth_amd as M
+    from m4depth_amd import network as net, network_ops as nops
+    L, H, Wd, T, b = 3, 64, 96, 3, 2
+    W = S.init_weights(L, seed=8)
+    model = _build(dev, L, 4, 3, W)
+    model.compile(metrics=M.default_metrics())
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=33)
+    d = {k: torch.stack([to_dev(s[k], dev) for s in samples], dim=1) for k in ("depth", "RGB_im", "rot", "trans")}
+    d["new_traj"] = torch.stack([torch.from_numpy(s["new_traj"]) for s in samples], dim=1)
+    d["camera"] = to_dev(cam, dev)
+    assert not d["rot"][:, 1].is_contiguous()                       # the slices that used to be copied inside the graph
+    model.test_step(d)
+    eager = npy(model.last_estimates[-1][0]["parallax"])
+    dot = tmp_path / "graph.dot"
+    try:
+        runner = net.GraphedSequence(model, d, debug_dot=dot)
+        dumped = dot.exists()
+    except (RuntimeError, AttributeError) as e:                     # no debug dump in this torch / ROCm: the capture still must work
+        if "as_f32" in str(e) or "hipGraph capture" in str(e):
+            raise
+        runner, dumped = net.GraphedSequence(model, d), False
+    model.graphed_test_step(d, runner)
+    torch.cuda.synchronize()
+    assert_bits_equal(npy(model.last_estimates[-1][0]["parallax"]), eager, "batch-2 graph replay vs eager")
+    if dumped:
+        names = re.findall(r"_Z\w+", dot.read_text())
+        assert len(names) >= 40, f"no kernel nodes recognised in the graph dump ({len(names)})"
+        foreign = [n for n in names if "at6native" in n or "at4cuda" in n or "rocclr" in n]
+        assert not foreign, f"framework kernels inside the captured graph: {sorted(set(foreign))[:5]}"
+        assert all(n.startswith("_ZN12_GLOBAL__N_1") or "conv3x3_wino" in n for n in names), sorted(set(names))[:8]
+    # a non-contiguous input inside a capture is refused loudly instead of being copied by a framework kernel
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with pytest.raises(RuntimeError, match="hipGraph capture"):
+        with torch.cuda.graph(g, stream=st):
+            net.as_f32(d["rot"][:, 1], "rot")
+    # metric kernel: strided ground truth == dense copy, bit for bit
+    est = runner.depth
+    gt_view = d["depth"][:, -1]
+    assert not gt_view.is_contiguous()
+    a = nops.depth_metrics(gt_view, est, 80.0)
+    c = nops.depth_metrics(gt_view.contiguous(), est, 80.0)
+    assert torch.equal(a, c)
+
+
 def test_forward_is_deterministic_bitwise(dev):
     """No MIOpen / framework kernel is in the model and every hand-written kernel is deterministic: the same
     sequence twice, and frame-by-frame streaming vs one sequence call, are bit-identical."""

@@ -41,7 +41,10 @@ def test_domain_normalization_uses_variance_not_std():
     rng = np.random.default_rng(1)
     x = (rng.standard_normal([2, 8, 9, 6]) * 3 + 1).astype(F)
     dn = N.DomainNormalization()
-    got = dn(torch.from_numpy(x)).numpy()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):          # the product layer is GPU-only
+        dn(torch.from_numpy(x))
+    with torch_convolutions_on_cpu():
+        got = dn(torch.from_numpy(x)).numpy()
     ref = O.domain_normalization(x, np.ones(6, F), np.zeros(6, F))
     assert np.max(np.abs(got - ref)) < 1e-6
     assert np.allclose((got * got).sum(-1), 1.0, atol=1e-5)

@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(raw, s), f"{s} declared in include/m4depth_hip.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == syms, "ctypes binding and header disagree"
-    assert _lib.lib.m4d_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib.m4d_abi_version() == _lib.ABI_VERSION == 5
     assert "gfx950" in _lib.build_info()
     # the experiments header: its symbols are exported by an EXPERIMENTS=1 build and ONLY by it, and the binding knows them all
     exp = header_symbols("m4depth_hip_experiments.h")

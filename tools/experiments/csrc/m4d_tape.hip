@@ -14,8 +14,8 @@
 #include <mutex>
 #include <vector>
 #include "m4d_common.h"
-#include "../../include/m4depth_hip.h"
-#include "../../include/m4depth_hip_experiments.h"
+#include "../../../include/m4depth_hip.h"
+#include "../../../include/m4depth_hip_experiments.h"
 
 namespace {
 

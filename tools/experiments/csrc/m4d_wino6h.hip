@@ -16,8 +16,8 @@
 // Bit-identical to conv3x3_wino6_kernel: same products, same accumulation order, same association in the output transform.
 #include <type_traits>
 #include "m4d_common.h"
-#include "../../include/m4depth_hip.h"
-#include "../../include/m4depth_hip_experiments.h"
+#include "../../../include/m4depth_hip.h"
+#include "../../../include/m4depth_hip_experiments.h"
 
 namespace {
 

@@ -24,8 +24,8 @@
 // finishes ((s01 + R2) + bias, ((R1 - R2) - R3) + bias, leaky_relu).  tests/test_gpu_ops.py compares the two kernels bit for bit.
 #include <type_traits>
 #include "m4d_common.h"
-#include "../../include/m4depth_hip.h"
-#include "../../include/m4depth_hip_experiments.h"
+#include "../../../include/m4depth_hip.h"
+#include "../../../include/m4depth_hip_experiments.h"
 
 namespace {
 
