@@ -45,10 +45,13 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
+/* Kernel launches this library has issued since it was loaded (host-side counter): the difference across one step -- or across
+ * the hipGraph capture of one -- is the number of launches the step is made of (bench.py: roofline.launches_per_step). */
+long long m4d_launch_count(void);
 const char* m4d_build_info(void);
 
 /* ---- the reference's native op ------------------------------------------------ */

@@ -2,7 +2,13 @@
 #include <hip/hip_runtime.h>
 #include "../../include/m4depth_hip.h"
 
+#include <atomic>
+
 extern "C" int m4d_abi_version(void) { return M4D_ABI_VERSION; }
+
+static std::atomic<long long> g_launches{0};
+extern "C" __attribute__((visibility("hidden"))) void m4d_count_launch(void) { g_launches.fetch_add(1, std::memory_order_relaxed); }
+extern "C" long long m4d_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 
 #define M4D_STR2(x) #x
 #define M4D_STR(x) M4D_STR2(x)

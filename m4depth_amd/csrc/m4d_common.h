@@ -36,8 +36,13 @@ inline void m4d_tape_push_tuple(const void* fn, dim3 grid, dim3 block, unsigned 
 }
 #endif
 
+// kernel launches issued by this library since it was loaded (m4d_launch_count(): how many launches one step is made of --
+// the difference across a hipGraph capture of the step; a host-side counter, relaxed atomic, no effect on the launches)
+extern "C" void m4d_count_launch(void);
+
 template <class... KArgs, class... Args>
 inline void m4d_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args&&... args) {
+  m4d_count_launch();
 #if M4D_EXPERIMENTS
   if (m4d_tape_recording()) {
     std::tuple<std::remove_cv_t<std::remove_reference_t<KArgs>>...> vals(static_cast<KArgs>(args)...);

@@ -345,6 +345,39 @@ def test_error_against_float64_truth(dev, winograd):
                                     f"[{'winograd ' + winograd if winograd else 'direct'}] level {l}", factor=factor)
 
 
+def test_error_against_float64_truth_fullsize_configs1(dev):
+    """the full-size comparison that lived only in bench.py, as a test.  BASELINE configs[1] -- 384x1280,
+    6 levels, one 4-frame sequence (frame 0 = new_traj), batch 1 -- with BASELINE's own recipe (He-normal weights seed 42,
+    the seeded forward-motion sequence of bench.py's cpu_baseline / parity leg): the last frame's depth of the GPU and of
+    the float32 numpy oracle, both against the float64 evaluation of the oracle.  Asserted: the GPU is at least as close to
+    the truth as the float32 oracle is (median error, and the fraction of pixels within the north-star 1e-4), it is within
+    1e-4 of the float32 oracle on >= 99.9 % of the pixels, and AbsRel (metrics.py:32-40 on the clipped maps,
+    m4depth_network.py:462-470) agrees to 1e-6 relative.  ('fullsize': runs last, tests/conftest.py.)"""
+    L, H, Wd, T, b = 6, 384, 1280, 4, 1
+    W = S.init_weights(L, seed=42)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=1235)
+    model = _model(dev, L, W)
+    got = npy(model([to_dev(samples, dev), to_dev(cam, dev)])["depth"])
+    ref, _ = O.M4Depth(W, L)(samples, cam)
+    with O.float64_reference():
+        truth, _ = O.M4Depth(W, L)(samples, cam)
+    t = np.maximum(np.abs(truth["depth"]), 1e-9)
+    r_g64, r_o64 = np.abs(got - truth["depth"]) / t, np.abs(ref["depth"] - truth["depth"]) / t
+    r_go = np.abs(got - ref["depth"]) / np.maximum(np.abs(ref["depth"]), 1e-9)
+    a_gpu = float(O.metrics_batch(samples[-1]["depth"], got)[0])
+    a_ref = float(O.metrics_batch(samples[-1]["depth"], ref["depth"])[0])
+    print(f"configs[1] full size: depth within 1e-4 of float64: gpu {100 * np.mean(r_g64 < 1e-4):.4f} % oracle_f32 "
+          f"{100 * np.mean(r_o64 < 1e-4):.4f} %; median error gpu {np.median(r_g64):.2e} oracle_f32 {np.median(r_o64):.2e}; "
+          f"p99 gpu {np.percentile(r_g64, 99):.2e} oracle_f32 {np.percentile(r_o64, 99):.2e}; gpu within 1e-4 of oracle_f32 "
+          f"{100 * np.mean(r_go < 1e-4):.4f} %; AbsRel gpu {a_gpu:.8f} oracle {a_ref:.8f}")
+    assert np.isfinite(got).all()
+    assert np.median(r_g64) <= np.median(r_o64) + 1e-8, "GPU median error to float64 above the float32 oracle's"
+    assert np.percentile(r_g64, 99) <= np.percentile(r_o64, 99) * 1.25 + 1e-8
+    assert np.mean(r_g64 < 1e-4) >= np.mean(r_o64 < 1e-4), "fewer GPU pixels within 1e-4 of the truth than oracle pixels"
+    assert np.mean(r_go < 1e-4) >= 0.999
+    assert abs(a_gpu - a_ref) / a_ref < 1e-6
+
+
 # ------------------------------------------------------------------------------- helper ops (rows a3, a14)
 def test_helper_ops_vs_oracle(dev):
     """get_rot_mat, get_coords_2d and tile_in_batch as tensor functions (utils/depth_operations.py:18-68, 217-221)."""
