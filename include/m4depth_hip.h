@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_partial_finish; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -369,6 +369,24 @@ int m4d_conv3x3s_bias_act_ws(const float* x, const float* wp, const float* bias,
 int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const float* bias, int b, int h, int w,
                             int Cin, int Cout, int CoutPad, float slope, float* out, float* workspace,
                             long long workspace_floats, void* stream);
+/* Latency-first form of the same stride-1 layer for SMALL maps at batch 1 (round 5, csrc/m4d_convlat.hip; the DispRefiner
+ * convolutions of the coarse pyramid levels, m4depth_network.py:116-135): every wave requests everything it needs -- its weight
+ * fragments of at most two 16-channel chunks straight into MFMA operand registers, then the workgroup's halo -- in ONE memory
+ * round trip; K is split over the waves of a workgroup (kw sub-slices, added in wave order) and over s_out workgroups, whose
+ * raw partial tiles go to s_out slabs (out + z * out_slab_floats) that the CONSUMING call adds in slab order, + the producer's
+ * bias and leaky_relu, while it stages its input (s_in / x_slab_floats / x_bias / x_slope; x_bias NULL = x is a finished
+ * activation).  s_out == 1 writes the finished activation leaky_relu(sum + bias, slope).  float32 operands as exact 3 x bf16
+ * splits (arithmetic of m4d_conv3x3_small6_bias_act; another summation order over K).  wp = network_ops.pack_conv_weights_lat
+ * ([Cout/32][Cin/16][9 taps][3 parts][64 lanes][8] bf16: MFMA B-fragment order).  mt = 1 / 2 / 4 M-tiles (8x4 / 8x8 / 16x8
+ * pixels per workgroup), kw = 1 / 2 / 4, 1 <= s_in <= 4, Cin >= 16, Cin % 4 == 0.  Deterministic. */
+int m4d_conv3x3_lat(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
+                    const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, float slope,
+                    int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream);
+/* out = leaky_relu(bias + slab_0 + ... + slab_{s_in-1}, slope), slabs added in slab order: the finished form of a partial-sum
+ * activation, for consumers that do not add the slabs themselves and for inspection.  C % 4 == 0. */
+int m4d_partial_finish(const float* x, int s_in, long long x_slab_floats, const float* bias, float slope,
+                       long long pixels, int C, float* out, void* stream);
+
 /* The same stride-1 layer for SMALL maps (the DispRefiner convolutions of the coarsest pyramid levels, m4depth_network.py:
  * 116-135 at 6x20 ... 24x80 pixels): ONE launch -- a workgroup is an 8x4-pixel tile x 32 output channels whose four waves
  * walk interleaved 16-channel K chunks independently and add their partial tiles in wave order -- instead of the split-K

@@ -73,6 +73,9 @@ _SIGNATURES = {
     "m4d_conv3x3_small_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3s_small_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_small6_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
+    "m4d_conv3x3_lat": [_c_fp, _c_int, ctypes.c_longlong, _c_fp, _c_f, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f,
+                        _c_int, _c_int, _c_int, _c_fp, ctypes.c_longlong, _c_fp],
+    "m4d_partial_finish": [_c_fp, _c_int, ctypes.c_longlong, _c_fp, _c_f, ctypes.c_longlong, _c_int, _c_fp, _c_fp],
     "m4d_conv3x3_wino_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino2_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino6_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
@@ -202,13 +205,30 @@ def check(rc, what):
                            + (" (hipErrorInvalidValue: bad argument)" if rc == 1 else ""))
 
 
+# Framework copies inside a hipGraph capture: refused on the inference path (every node of its graph is a library kernel), allowed
+# inside ``framework_copies_in_capture()`` -- the TRAINING step's capture, whose autograd graph is made of framework nodes anyway
+# (slice copies, gradient accumulation) around the library's kernels.
+_capture_copies_ok = [False]
+
+
+class framework_copies_in_capture:
+    def __enter__(self):
+        self._old = _capture_copies_ok[0]
+        _capture_copies_ok[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _capture_copies_ok[0] = self._old
+        return False
+
+
 def as_f32(t, name):
     """Dense float32 device tensor (copies only when a conversion is needed)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor")
     if t.dtype == torch.float32 and t.is_contiguous():
         return t
-    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+    if t.is_cuda and not _capture_copies_ok[0] and torch.cuda.is_current_stream_capturing():
         # a conversion here would put a framework copy kernel into the captured graph (round 4: ~43 per batch-32 step, the
         # [:, t] slices of batch-major rot / trans): the capturing callers hand over dense frame-major tensors instead
         raise RuntimeError(f"{name}: a non-contiguous / non-float32 tensor (shape {tuple(t.shape)}, strides {t.stride()}, "

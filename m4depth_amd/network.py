@@ -144,6 +144,14 @@ pad_refiner_input = _os.environ.get("M4D_PAD_REFINER_INPUT", "1") == "1"
 small_map_conv_pixels = int(_os.environ.get("M4D_CONV_SMALL_PX", "2048"))
 small_map_stride2 = _os.environ.get("M4D_CONV_SMALL_S2", "1") == "1"     # the coarse stride-2 encoder layers on the one-launch kernel too
 
+# The latency-first small-map convolution (csrc/m4d_convlat.hip, round 5): every layer that may take the one-launch small-map
+# kernels (``small_maps_ok``, stride 1, Cin >= 16, Cin % 4 == 0) on maps of at most this many pixels (batch included) when
+# conv_arith is "bf16x3".  K is split over waves and workgroups until a wave owns one or two 16-channel chunks and requests
+# everything it needs in one memory round trip; the K slices of different workgroups reach the NEXT layer as partial-sum slabs
+# (network_ops.PartialAct) that it adds while staging.  Levels 4-6 at batch 1: 59 / 50 / 52 us of refiner convolutions per
+# level -> 38 / 37 / 48 (tools/bench_lat_convs.py).  0 = the round-2/3 small-map kernels.
+lat_conv_max_pixels = int(_os.environ.get("M4D_LAT_CONV_PX", "2048"))
+
 # DSCV and SNCV of a small level (<= 6000 pixels) in one launch (m4d_dscv_sncv_fwd).  0 = two launches.
 fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
 # level_pre and the per-cut normalisation of a level in one launch (m4d_level_pre_normalize).  0 = two launches.
@@ -356,6 +364,22 @@ class _Conv3x3SameTF(torch.nn.Module):
             return torch.from_numpy(wp.view("int16")).to(self.weight.device), cpad
         return self._cache.get(("small6", cin_pad), _stamp(self.weight), build)
 
+    def _packed_weights_lat(self, cin_pad=None):
+        """wp (int16 bits) for m4d_conv3x3_lat: the TF kernel split into three bf16 terms, MFMA B-fragment order."""
+        if cin_pad is not None and cin_pad == self.weight.shape[1]:
+            cin_pad = None
+
+        def build():
+            wp = nops.pack_conv_weights_lat(self._hwio_numpy(cin_pad))
+            return torch.from_numpy(wp.view("int16")).to(self.weight.device)
+        return self._cache.get(("lat", cin_pad), _stamp(self.weight), build)
+
+    def lat_eligible(self, b, h, w, cin):
+        """Would ``forward`` run this layer on the latency-first small-map kernel for an input of this shape?"""
+        eff_b = self.dispatch_batch if self.per_image_dispatch else b
+        return (self.small_maps_ok and self.stride == 1 and conv_arith == "bf16x3" and lat_conv_max_pixels > 0
+                and eff_b * h * w <= lat_conv_max_pixels and cin >= 16 and cin % 4 == 0)
+
     def _packed_weights_wino6(self, cin_pad=None):
         """(wu6 int16 bits, CoutPad) for m4d_conv3x3_wino6_bias_act: U = G g G^T split into three bf16 terms on the host."""
         if cin_pad is not None and cin_pad == self.weight.shape[1]:
@@ -377,10 +401,15 @@ class _Conv3x3SameTF(torch.nn.Module):
         pw = max((-(-w // s) - 1) * s + 3 - w, 0)
         return (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)
 
-    def forward(self, x_nhwc, slope=None):
+    def forward(self, x_nhwc, slope=None, final=True):
         """Convolution + bias (+ leaky_relu(slope) when ``slope`` is given): ONE hand-written HIP kernel.  There is no CPU /
         framework form of this layer in the product: a CPU tensor raises (the host-logic tests patch a torch stand-in over
-        this method from tests/helpers.py to check the layer wiring and the ``same_pads`` rule without a GPU)."""
+        this method from tests/helpers.py to check the layer wiring and the ``same_pads`` rule without a GPU).
+        ``final`` = False: the caller hands the result to another layer of this class, so on the latency-first small-map
+        kernel it may come back as K-slice partial sums (``network_ops.PartialAct``) that layer finishes while staging; a
+        ``PartialAct`` input is finished here first (one launch) if this layer runs on any other kernel."""
+        if isinstance(x_nhwc, nops.PartialAct) and not self.lat_eligible(*x_nhwc.shape):
+            x_nhwc = x_nhwc.dense()
         if not x_nhwc.is_cuda:
             raise RuntimeError("m4depth_amd convolutions run on the GPU only (libm4depth_hip.so): got a CPU tensor; "
                                "there is no CPU fallback")
@@ -396,6 +425,11 @@ class _Conv3x3SameTF(torch.nn.Module):
         # (``dispatch_batch``, set by the model from its input: the same in every launch mode), so that a batch-32 evaluation
         # does not run its coarse encoder levels on the latency kernels of a single small map.
         eff_b = self.dispatch_batch if self.per_image_dispatch else b_
+        if self.lat_eligible(b_, h_, w_, cin_):
+            wl = self._packed_weights_lat(cin_)
+            # (configuration from the per-image grid x the dispatch batch, like the kernel choice: the same in every launch mode)
+            cfg = nops.lat_config(eff_b, h_, w_, cin_, self.out_channels, final)
+            return _timed("conv", self.tag, lambda: nops.conv3x3_lat(x_nhwc, wl, self.bias, self.out_channels, act, config=cfg))
         wino = _use_winograd(eff_b, h_, w_, cin_, self.out_channels, self.stride)
         if wino == 6:
             wu, cpad = self._packed_weights_wino6(cin_)
@@ -529,11 +563,11 @@ class DispRefiner(torch.nn.Module):
     def forward(self, feature_map):
         prev_out = feature_map
         for conv in self.prep_conv_layers:
-            prev_out = conv(prev_out, slope=0.1)
+            prev_out = conv(prev_out, slope=0.1)                          # (finished tensors: ``prep`` is returned)
         prep = prev_out
         n = len(self.est_d_conv_layers)
         for i, conv in enumerate(self.est_d_conv_layers):
-            prev_out = conv(prev_out, slope=0.1 if i < n - 1 else None)   # last convolution: no activation
+            prev_out = conv(prev_out, slope=0.1 if i < n - 1 else None, final=(i == n - 1))   # last convolution: no activation
         return [prev_out, prep]
 
 
@@ -726,9 +760,9 @@ class DepthEstimatorLevel(torch.nn.Module):
                 and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16)):
             x = f_input
             for ci, conv in enumerate(convs[:5]):
-                x = conv(x, slope=0.1)
+                x = conv(x, slope=0.1, final=(ci == 4))                   # the fused tail reads a finished tensor
                 if debug_tap is not None:
-                    debug_tap(f"refiner_conv{ci + 1}", self.lvl_depth, x)
+                    debug_tap(f"refiner_conv{ci + 1}", self.lvl_depth, x.dense() if isinstance(x, nops.PartialAct) else x)
             split = tail_split and conv_arith == "bf16x3"
             w6p, w7p = self._tail_weights(convs, split)
             tail_fn = nops.refiner_tail6 if split else nops.refiner_tail
@@ -959,6 +993,9 @@ class M4Depth(torch.nn.Module):
                 conv._packed_weights()
                 if small_conv_split and conv.small_maps_ok and conv.stride == 1 and 16 <= cin <= 256 and cin % 4 == 0:
                     conv._packed_weights_small6()
+                if conv.small_maps_ok and conv.stride == 1 and conv_arith == "bf16x3" and lat_conv_max_pixels > 0 \
+                        and cin >= 16 and cin % 4 == 0:
+                    conv._packed_weights_lat()
                 if cin == 3 or (conv.stride == 2 and cin == 16 and conv.out_channels == 16):
                     conv._hwio_device()                # the encoder's level-0 kernels read the TF layout directly
                 if conv.stride == 1 and cin >= 16 and cin % 2 == 0:
@@ -979,6 +1016,8 @@ class M4Depth(torch.nn.Module):
                 c0._packed_weights_winograd(8, cin_pad)
                 if small_conv_split and cin_pad <= 256:
                     c0._packed_weights_small6(cin_pad)
+                if conv_arith == "bf16x3" and lat_conv_max_pixels > 0:
+                    c0._packed_weights_lat(cin_pad)
                 if cin_pad % 16 == 0 and cin_pad >= 32 and c0.out_channels >= min(wino6_min_cout, 32):
                     c0._packed_weights_wino6(cin_pad)
             if len(convs) == 7 and convs[5].weight is not None and convs[5].weight.is_cuda \

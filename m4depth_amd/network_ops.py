@@ -352,6 +352,96 @@ def pack_conv_weights_small6(kernel_hwio):
     return np.ascontiguousarray(parts.transpose(2, 1, 4, 0, 3)), cpad   # chunk, tap, n, part, channel
 
 
+def pack_conv_weights_lat(kernel_hwio):
+    """A TF HWIO [3,3,Cin,Cout] kernel split exactly into three bf16 terms per weight, in the MFMA B-fragment order
+    m4d_conv3x3_lat loads straight into operand registers: [ceil(Cout/32)][ceil(Cin/16)][9 taps][3 parts][64 lanes][8] bf16
+    (uint16 bits); lane = k_half * 32 + cout % 32, element e = channel 8 k_half + e of the chunk.  Zero padded.
+    numpy in, numpy uint16 out."""
+    import numpy as np
+    k = np.asarray(kernel_hwio, dtype=np.float32)
+    assert k.shape[:2] == (3, 3)
+    cin, cout = k.shape[2], k.shape[3]
+    nch, ng = -(-cin // 16), -(-cout // 32)
+    full = np.zeros((9, nch * 16, ng * 32), np.float32)
+    full[:, :cin, :cout] = k.reshape(9, cin, cout)
+    parts = split_bf16x3(full).reshape(3, 9, nch, 2, 8, ng, 32)   # part, tap, chunk, k_half, e, group, n
+    return np.ascontiguousarray(parts.transpose(5, 2, 1, 0, 3, 6, 4)).reshape(ng, nch, 9, 3, 64, 8)
+
+
+class PartialAct:
+    """An activation that exists as K-slice partial sums: ``slabs`` [S,b,h,w,C] raw sums of m4d_conv3x3_lat's K slices, to be
+    added in slab order, + ``bias``, leaky_relu(``slope``) -- which the consuming m4d_conv3x3_lat does while it stages its
+    input.  ``dense()`` = the finished [b,h,w,C] tensor (one HIP launch, m4d_partial_finish: same order, same bits)."""
+
+    def __init__(self, slabs, bias, slope):
+        self.slabs, self.bias, self.slope = slabs, bias, 1.0 if slope is None else float(slope)
+
+    @property
+    def shape(self):
+        return self.slabs.shape[1:]
+
+    @property
+    def is_cuda(self):
+        return self.slabs.is_cuda
+
+    @property
+    def device(self):
+        return self.slabs.device
+
+    def dense(self):
+        S, b, h, w, C = self.slabs.shape
+        out = torch.empty((b, h, w, C), dtype=torch.float32, device=self.slabs.device)
+        check(lib.m4d_partial_finish(dptr(self.slabs, "slabs"), S, b * h * w * C, dptr(self.bias, "bias"), self.slope,
+                                     b * h * w, C, dptr(out), stream_ptr()), "m4d_partial_finish")
+        return out
+
+
+def lat_config(b, h, w, cin, cout, final=False):
+    """(mt, kw, s_out) of m4d_conv3x3_lat for a layer -- the rule the sweep of tools/bench_lat_convs.py reads out
+    (profiles/r05_lat_conv_sweep.txt): as many K slices over workgroups as there can be (s_out <= 4 partial slabs, no empty
+    slice; ``final`` forces 1: the consumer cannot add slabs), one chunk per wave where the slice allows it (kw = 1 / 2 / 4 K
+    sub-slices over the waves of a workgroup), and a grid of at most one workgroup per CU: on larger maps first the waves
+    stop splitting K (kw -> 1: four cout groups share one staged halo), then a wave takes 2 / 4 M-tiles."""
+    n_chunks, n_groups = -(-cin // 16), -(-cout // 32)
+    s_out = 1 if final else min(4, n_chunks)
+    while s_out > 1 and (s_out - 1) * (-(-n_chunks // s_out)) >= n_chunks:
+        s_out -= 1                                      # no empty K slice
+    cps = -(-n_chunks // s_out)
+    kw = 1 if cps <= 1 else (2 if cps <= 2 else 4)
+
+    def wgs(mt, kw):
+        mtx, mty = (2 if mt == 4 else 1), (2 if mt >= 2 else 1)
+        tiles = b * (-(-h // (4 * mty))) * (-(-w // (8 * mtx)))
+        return tiles * (-(-n_groups // (4 // kw))) * s_out
+    mt = 1
+    while wgs(mt, kw) > 256 and kw > 1:
+        kw //= 2
+    while wgs(mt, kw) > 256 and mt < 4:
+        mt *= 2
+    return mt, kw, s_out
+
+
+def conv3x3_lat(x, wp, bias, cout, slope=0.1, final=False, config=None):
+    """m4d_conv3x3_lat: ``x`` a finished [b,h,w,Cin] tensor or a ``PartialAct``; returns a finished tensor (s_out == 1) or a
+    ``PartialAct`` the next m4d_conv3x3_lat call finishes while staging.  ``config`` = (mt, kw, s_out) overrides lat_config."""
+    if isinstance(x, PartialAct):
+        xs, s_in, x_bias, x_slope = x.slabs, x.slabs.shape[0], x.bias, x.slope
+        b, h, w, cin = x.shape
+        slab = b * h * w * cin
+    else:
+        xs = as_f32(x, "x")
+        s_in, x_bias, x_slope = 1, None, 1.0
+        b, h, w, cin = xs.shape
+        slab = 0
+    mt, kw, s_out = config if config is not None else lat_config(b, h, w, cin, cout, final)
+    act = 1.0 if slope is None else float(slope)
+    out = torch.empty((s_out, b, h, w, cout), dtype=torch.float32, device=xs.device)
+    check(lib.m4d_conv3x3_lat(dptr(xs, "x"), s_in, slab, dptr(x_bias, "x_bias"), float(x_slope), dptr(wp, "wp", torch.int16),
+                              dptr(bias, "bias"), b, h, w, cin, int(cout), act, mt, kw, s_out, dptr(out), b * h * w * int(cout),
+                              stream_ptr()), "m4d_conv3x3_lat")
+    return out[0] if s_out == 1 else PartialAct(out, bias, act)
+
+
 def conv3x3_small6_bias_act(x, wp6, bias, cout, cout_pad, slope=0.1):
     """The one-launch small-map convolution with float32 operands split into three bf16 terms (csrc/m4d_conv.hip,
     conv3x3_small6_kernel): float32 accuracy at 2.7x less matrix-core time per wave."""

@@ -403,7 +403,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        from ._lib import framework_copies_in_capture
+        with framework_copies_in_capture(), torch.cuda.graph(self.graph):      # the autograd graph's own nodes are framework kernels
             self.loss, self.est = self._step()
 
     def _data(self):

@@ -30,7 +30,7 @@ class torch_convolutions_on_cpu:
         from m4depth_amd import network as N
         self._cls, self._old = N._Conv3x3SameTF, N._Conv3x3SameTF.forward
 
-        def forward(conv, x_nhwc, slope=None):
+        def forward(conv, x_nhwc, slope=None, final=True):
             assert not x_nhwc.is_cuda
             x = x_nhwc.permute(0, 3, 1, 2)
             (pt, pb), (pl, pr) = conv.same_pads(*x.shape[2:])

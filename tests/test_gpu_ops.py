@@ -554,6 +554,99 @@ def test_small_map_conv_bf16_split(M, dev, b, h, w, cin, cout, slope):
     assert torch.equal(got, nops.conv3x3_small6_bias_act(xd, wd, bd, cout, cpad, slope))
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,slope", [(1, 6, 20, 472, 128, 0.1), (1, 12, 40, 240, 128, 0.1), (1, 24, 80, 128, 96, 0.1),
+                                                  (1, 48, 160, 96, 64, 0.1), (2, 7, 9, 100, 40, 1.0), (3, 5, 33, 16, 32, 0.1),
+                                                  (1, 13, 17, 64, 32, 0.1), (1, 9, 11, 32, 5, 1.0)])
+def test_latency_conv_vs_oracle(M, dev, b, h, w, cin, cout, slope):
+    """m4d_conv3x3_lat (round 5: the latency-first small-map convolution, csrc/m4d_convlat.hip) vs the oracle, every variant:
+    1 / 2 / 4 M-tiles per wave x 1 / 2 / 4 K sub-slices per workgroup x 1-4 K slices over workgroups (partial slabs finished by
+    m4d_partial_finish).  Tolerance of the other float32 convolution kernels; error to float64 no larger than the bf16-split
+    small-map kernel's; variants with the same (kw, s_out) are bitwise equal whatever the M-tile count; the chosen default
+    configuration is among them; ragged tiles, a partial last chunk (Cin = 100), Cout not a multiple of 32, batch."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(cin * 5 + cout)
+    x = rng.standard_normal([b, h, w, cin]).astype(F)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = (0.1 * rng.standard_normal([cout])).astype(F)
+    xd, bd = to_dev(x, dev), to_dev(bias, dev)
+    wd = torch.from_numpy(nops.pack_conv_weights_lat(k).view(np.int16)).to(dev)
+    act = lambda r: np.where(r > 0, r, r * r.dtype.type(slope))
+    ref32 = act(O.conv2d_same(x, k, bias, 1)).astype(F)
+    with O.float64_reference():
+        ref64 = act(O.conv2d_same(x.astype(np.float64), k.astype(np.float64), bias.astype(np.float64), 1))
+    wp6, cpad = nops.pack_conv_weights_small6(k)
+    small6 = nops.conv3x3_small6_bias_act(xd, torch.from_numpy(wp6.view(np.int16)).to(dev), bd, cout, cpad, slope)
+    e_small6 = np.abs(npy(small6).astype(np.float64) - ref64).mean()
+    n_chunks = -(-cin // 16)
+    same_order = {}
+    tried = 0
+    for kw in (1, 2, 4):
+        for s_out in (1, 2, 3, 4):
+            if s_out > n_chunks or (s_out - 1) * (-(-n_chunks // s_out)) >= n_chunks:
+                continue
+            for mt in (1, 2, 4):
+                if 2 * kw * {1: 60, 2: 100, 4: 180}[mt] * 96 > 160 * 1024:
+                    continue
+                out = nops.conv3x3_lat(xd, wd, bd, cout, slope, config=(mt, kw, s_out))
+                if s_out > 1:
+                    assert isinstance(out, nops.PartialAct) and out.slabs.shape == (s_out, b, h, w, cout)
+                    if cout % 4 != 0:
+                        continue                                   # m4d_partial_finish wants whole channel quads
+                    out = out.dense()
+                got = npy(out)
+                tried += 1
+                assert np.max(np.abs(got - ref32)) < 1e-5 * max(1.0, np.abs(ref32).max()), (mt, kw, s_out)
+                e = np.abs(got.astype(np.float64) - ref64).mean()
+                # (one wave adding all of a long K in one accumulator -- kw = s_out = 1 on 472 channels -- rounds more often
+                # than the four interleaved chains of the small-map kernel: within 2x; the dispatched configurations split K
+                # at least as finely as that kernel and are held to its error below)
+                assert e <= 2.0 * e_small6 + 1e-12, (mt, kw, s_out, e, e_small6)
+                key = (kw, s_out)
+                if key in same_order:
+                    assert torch.equal(out, same_order[key]), f"mt {mt} differs bitwise from another M-tile count at {key}"
+                else:
+                    same_order[key] = out
+    assert tried >= 6
+    default = nops.conv3x3_lat(xd, wd, bd, cout, slope, final=True)
+    cfg = nops.lat_config(b, h, w, cin, cout, final=True)
+    assert cfg[2] == 1 and torch.equal(default, same_order[(cfg[1], 1)])
+    assert torch.equal(default, nops.conv3x3_lat(xd, wd, bd, cout, slope, final=True))     # deterministic
+
+
+def test_latency_conv_chain_finishes_partial_sums_while_staging(M, dev):
+    """A chain of m4d_conv3x3_lat calls hands K-slice partial sums from layer to layer (``PartialAct``): the consumer adds the
+    slabs in slab order, the producer's bias and leaky_relu while it stages its halo -- bit for bit what it computes from the
+    finished tensor of m4d_partial_finish -- for 2, 3 and 4 slabs; the whole refiner prefix of a coarse level (472 -> 128 ->
+    128 -> 96 -> 64 -> 32 at 6x20) against the oracle."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(77)
+    b, h, w = 1, 6, 20
+    chans = [472, 128, 128, 96, 64, 32]
+    x = rng.standard_normal([b, h, w, chans[0]]).astype(F)
+    ks = [(rng.standard_normal([3, 3, ci, co]) * np.sqrt(2.0 / (9 * ci))).astype(F) for ci, co in zip(chans[:-1], chans[1:])]
+    bs = [(0.1 * rng.standard_normal([co])).astype(F) for co in chans[1:]]
+    wds = [torch.from_numpy(nops.pack_conv_weights_lat(k).view(np.int16)).to(dev) for k in ks]
+    bds = [to_dev(bb, dev) for bb in bs]
+    xd = to_dev(x, dev)
+    for s_out in (2, 3, 4):
+        p = nops.conv3x3_lat(xd, wds[0], bds[0], chans[1], 0.1, config=(1, 4, s_out))
+        assert isinstance(p, nops.PartialAct)
+        for cfg in ((1, 1, 1), (1, 4, 1), (2, 2, 2)):
+            a = nops.conv3x3_lat(p, wds[1], bds[1], chans[2], 0.1, config=cfg)
+            c = nops.conv3x3_lat(p.dense(), wds[1], bds[1], chans[2], 0.1, config=cfg)
+            if cfg[2] > 1:
+                a, c = a.dense(), c.dense()
+            assert torch.equal(a, c), (s_out, cfg)
+    # default configurations, layer after layer
+    cur, ref = xd, x
+    for i in range(5):
+        cur = nops.conv3x3_lat(cur, wds[i], bds[i], chans[i + 1], 0.1, final=(i == 4))
+        r = O.conv2d_same(ref, ks[i], bs[i], 1)
+        ref = np.where(r > 0, r, r * F(0.1)).astype(F)
+    assert isinstance(cur, torch.Tensor)
+    assert np.max(np.abs(npy(cur) - ref)) < 2e-5 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("kernel", ["f32", "bf16x3"])
 @pytest.mark.parametrize("b,h,w,quat", [(2, 24, 40, True), (1, 37, 53, False), (1, 6, 20, True), (3, 96, 320, True), (1, 10, 14, True),
                                         (1, 11, 15, False), (1, 3, 5, True)])
