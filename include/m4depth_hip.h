@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_partial_finish; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -382,6 +382,11 @@ int m4d_conv3x3_bias_act_ws(const float* x, const float* wp, const float* bias, 
 int m4d_conv3x3_lat(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
                     const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, float slope,
                     int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream);
+/* ... with stride 1 or 2 (TF 'SAME'; the coarse stride-2 layers of the encoder, m4depth_network.py:66-72): out / every slab
+ * [b, ceil(h/stride), ceil(w/stride), Cout]. */
+int m4d_conv3x3s_lat(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
+                     const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, int stride, float slope,
+                     int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream);
 /* out = leaky_relu(bias + slab_0 + ... + slab_{s_in-1}, slope), slabs added in slab order: the finished form of a partial-sum
  * activation, for consumers that do not add the slabs themselves and for inspection.  C % 4 == 0. */
 int m4d_partial_finish(const float* x, int s_in, long long x_slab_floats, const float* bias, float slope,

@@ -75,6 +75,8 @@ _SIGNATURES = {
     "m4d_conv3x3_small6_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_lat": [_c_fp, _c_int, ctypes.c_longlong, _c_fp, _c_f, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f,
                         _c_int, _c_int, _c_int, _c_fp, ctypes.c_longlong, _c_fp],
+    "m4d_conv3x3s_lat": [_c_fp, _c_int, ctypes.c_longlong, _c_fp, _c_f, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                         _c_f, _c_int, _c_int, _c_int, _c_fp, ctypes.c_longlong, _c_fp],
     "m4d_partial_finish": [_c_fp, _c_int, ctypes.c_longlong, _c_fp, _c_f, ctypes.c_longlong, _c_int, _c_fp, _c_fp],
     "m4d_conv3x3_wino_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino2_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],

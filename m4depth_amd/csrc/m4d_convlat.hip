@@ -36,6 +36,7 @@ struct LatArgs {
   float* out; long long out_slab; int s_out;        // s_out K slices = gridDim.z; slice z -> out + z * out_slab (raw partial sums)
   int b, h, w, Cin, Cout, n_chunks, n_groups, tiles_x, tiles_y;
   int cgw_log2, chunks_per_slice;                   // waves = (1 << cgw_log2) cout groups x (4 >> cgw_log2) K sub-slices
+  int oh, ow, pad_y, pad_x;                         // output size; TF 'SAME' pad before (1 at stride 1; 0 or 1 at stride 2)
 };
 
 constexpr int kLatRow = 24;                         // floats per staged halo pixel and chunk: 3 parts x 16 bf16 = 96 bytes
@@ -43,7 +44,7 @@ constexpr int kLatRow = 24;                         // floats per staged halo pi
 // Stage `n_st` chunks (first chunk c0) of the halo: add the SIN partial slabs in slab order, the producer's bias + leaky_relu,
 // zero outside the map, exact 3-way bf16 split, [chunk][pixel][part][16 channels] in LDS.
 template <int SIN, int HW, int HP>
-__device__ __forceinline__ void lat_stage(const LatArgs& a, float* lds_a, int t, int bi, int ty0, int tx0, int c0, int n_st) {
+__device__ __forceinline__ void lat_stage(const LatArgs& a, float* lds_a, int t, int bi, int gy0, int gx0, int c0, int n_st) {
   constexpr int IB = SIN >= 3 ? 2 : 4;              // items per thread in flight: IB * SIN 16-byte loads
   const int n_items = n_st * HP * 4;
   for (int base = 0; base < n_items; base += 256 * IB) {
@@ -56,7 +57,7 @@ __device__ __forceinline__ void lat_stage(const LatArgs& a, float* lds_a, int t,
       const int idc = min(idx, n_items - 1);
       const int j = idc / (HP * 4), rem = idc - j * (HP * 4);
       const int hp = rem >> 2, q = rem & 3;
-      const int gy = ty0 - 1 + hp / HW, gx = tx0 - 1 + hp % HW;
+      const int gy = gy0 + hp / HW, gx = gx0 + hp % HW;             // (gy0, gx0) = the halo's first input pixel
       ch[i] = (c0 + j) * 16 + 4 * q;
       ok[i] = idx < n_items && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && ch[i] < a.Cin;
       dst[i] = idx < n_items ? (j * HP + hp) * kLatRow + 2 * q : -1;
@@ -90,11 +91,11 @@ __device__ __forceinline__ void lat_stage(const LatArgs& a, float* lds_a, int t,
   }
 }
 
-template <int MTX, int MTY>
+template <int MTX, int MTY, int STRIDE>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_lat_kernel(const LatArgs a) {
   constexpr int MT = MTX * MTY;
-  constexpr int TW = 8 * MTX, TH = 4 * MTY, HW = TW + 2, HP = HW * (TH + 2);
+  constexpr int TW = 8 * MTX, TH = 4 * MTY, HW = (TW - 1) * STRIDE + 3, HP = HW * ((TH - 1) * STRIDE + 3);   // output tile, input halo
   constexpr int kChunkF = HP * kLatRow;               // floats of one staged chunk
   extern __shared__ __align__(16) float lds_dyn[];
   const int t = threadIdx.x, lane = t & 63;
@@ -143,10 +144,10 @@ conv3x3_lat_kernel(const LatArgs a) {
     const int c0 = c_begin + r0 * kw;
     const int n_st = min(2 * kw, c_end - c0);
     switch (a.s_in) {
-      case 1: lat_stage<1, HW, HP>(a, lds_dyn, t, bi, ty0, tx0, c0, n_st); break;
-      case 2: lat_stage<2, HW, HP>(a, lds_dyn, t, bi, ty0, tx0, c0, n_st); break;
-      case 3: lat_stage<3, HW, HP>(a, lds_dyn, t, bi, ty0, tx0, c0, n_st); break;
-      default: lat_stage<4, HW, HP>(a, lds_dyn, t, bi, ty0, tx0, c0, n_st); break;
+      case 1: lat_stage<1, HW, HP>(a, lds_dyn, t, bi, ty0 * STRIDE - a.pad_y, tx0 * STRIDE - a.pad_x, c0, n_st); break;
+      case 2: lat_stage<2, HW, HP>(a, lds_dyn, t, bi, ty0 * STRIDE - a.pad_y, tx0 * STRIDE - a.pad_x, c0, n_st); break;
+      case 3: lat_stage<3, HW, HP>(a, lds_dyn, t, bi, ty0 * STRIDE - a.pad_y, tx0 * STRIDE - a.pad_x, c0, n_st); break;
+      default: lat_stage<4, HW, HP>(a, lds_dyn, t, bi, ty0 * STRIDE - a.pad_y, tx0 * STRIDE - a.pad_x, c0, n_st); break;
     }
     __syncthreads();
 #pragma unroll
@@ -161,7 +162,7 @@ conv3x3_lat_kernel(const LatArgs a) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             const int my = m / MTX, mx = m % MTX;
-            const float* ap = ac + ((my * 4 + (n >> 3) + tp / 3) * HW + mx * 8 + (n & 7) + tp % 3) * kLatRow;
+            const float* ap = ac + (((my * 4 + (n >> 3)) * STRIDE + tp / 3) * HW + (mx * 8 + (n & 7)) * STRIDE + tp % 3) * kLatRow;
             const lat_bf16x8 a0 = *reinterpret_cast<const lat_bf16x8*>(ap);
             const lat_bf16x8 a1 = *reinterpret_cast<const lat_bf16x8*>(ap + 8);
             const lat_bf16x8 a2 = *reinterpret_cast<const lat_bf16x8*>(ap + 16);
@@ -198,7 +199,7 @@ conv3x3_lat_kernel(const LatArgs a) {
     }
   }
   if (ks != 0 || !active || co >= a.Cout) return;
-  float* op = a.out + blockIdx.z * a.out_slab + (long long)bi * a.h * a.w * a.Cout + co;
+  float* op = a.out + blockIdx.z * a.out_slab + (long long)bi * a.oh * a.ow * a.Cout + co;
   const bool final_out = a.s_out == 1;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -207,10 +208,10 @@ conv3x3_lat_kernel(const LatArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;  // C/D map of the 32x32 MFMA: col = lane & 31, row = mr
       const int oy = ty0 + my * 4 + (mr >> 3), ox = tx0 + mx * 8 + (mr & 7);
-      if (oy < a.h && ox < a.w) {
+      if (oy < a.oh && ox < a.ow) {
         float v = acc[m][r];
         if (final_out) { v += my_bias; v = v > 0.f ? v : v * a.slope; }
-        op[((long long)oy * a.w + ox) * a.Cout] = v;
+        op[((long long)oy * a.ow + ox) * a.Cout] = v;
       }
     }
   }
@@ -235,53 +236,77 @@ partial_finish_kernel(const float* __restrict__ x, long long slab, int s_in, con
   }
 }
 
-template <int MTX, int MTY>
+template <int MTX, int MTY, int STRIDE>
 void lat_launch(const LatArgs& a, int kw, hipStream_t s) {
-  constexpr int HP = (8 * MTX + 2) * (4 * MTY + 2), MT = MTX * MTY;
+  constexpr int HP = ((8 * MTX - 1) * STRIDE + 3) * ((4 * MTY - 1) * STRIDE + 3), MT = MTX * MTY;
   const int cgw = 4 / kw;
   const size_t lds_a = (size_t)2 * kw * HP * kLatRow * 4;
   const size_t lds_r = (size_t)(kw - 1) * cgw * MT * 16 * 64 * 4;
   const size_t lds = lds_a > lds_r ? lds_a : lds_r;
   static bool attr_done = false;                      // per instantiation; the attribute is per function, set once per process
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lat_kernel<MTX, MTY>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lat_kernel<MTX, MTY, STRIDE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const dim3 grid((unsigned)(a.b * a.tiles_x * a.tiles_y), (unsigned)((a.n_groups + cgw - 1) / cgw), (unsigned)a.s_out);
-  m4d_launch(conv3x3_lat_kernel<MTX, MTY>, grid, dim3(256), lds, s, a);
+  m4d_launch(conv3x3_lat_kernel<MTX, MTY, STRIDE>, grid, dim3(256), lds, s, a);
 }
 
 }  // namespace
 
-extern "C" int m4d_conv3x3_lat(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
-                               const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, float slope,
-                               int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream) {
-  M4D_CHECK_ARG(x && wp && bias && out && b > 0 && h > 0 && w > 0);
+static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
+                          const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, int stride, float slope,
+                          int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream) {
+  M4D_CHECK_ARG(x && wp && bias && out && b > 0 && h > 0 && w > 0 && (stride == 1 || stride == 2));
   M4D_CHECK_ARG(Cin >= 16 && Cin % 4 == 0 && Cout >= 1);
+  const int oh = (h + stride - 1) / stride, ow = (w + stride - 1) / stride;
   M4D_CHECK_ARG(s_in >= 1 && s_in <= 4 && (s_in == 1 || x_slab_floats >= (long long)b * h * w * Cin));
-  M4D_CHECK_ARG(s_out >= 1 && (s_out == 1 || out_slab_floats >= (long long)b * h * w * Cout));
+  M4D_CHECK_ARG(s_out >= 1 && (s_out == 1 || out_slab_floats >= (long long)b * oh * ow * Cout));
   M4D_CHECK_ARG((mt == 1 || mt == 2 || mt == 4) && (kw == 1 || kw == 2 || kw == 4));
   LatArgs a;
   a.x = x; a.x_slab = x_slab_floats; a.s_in = s_in; a.x_bias = x_bias; a.x_slope = x_slope;
   a.wp = reinterpret_cast<const unsigned char*>(wp); a.bias = bias; a.slope = slope;
   a.out = out; a.out_slab = out_slab_floats; a.s_out = s_out;
-  a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
+  a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.oh = oh; a.ow = ow;
+  // TF 'SAME': total pad = max((out - 1) * stride + 3 - in, 0), before = total / 2
+  a.pad_y = ((oh - 1) * stride + 3 - h > 0 ? (oh - 1) * stride + 3 - h : 0) / 2;
+  a.pad_x = ((ow - 1) * stride + 3 - w > 0 ? (ow - 1) * stride + 3 - w : 0) / 2;
   a.n_chunks = (Cin + 15) / 16; a.n_groups = (Cout + 31) / 32;
   M4D_CHECK_ARG(s_out <= a.n_chunks);
   a.cgw_log2 = kw == 1 ? 2 : (kw == 2 ? 1 : 0);
   a.chunks_per_slice = (a.n_chunks + s_out - 1) / s_out;
   M4D_CHECK_ARG((long long)(s_out - 1) * a.chunks_per_slice < a.n_chunks);     // no empty K slice
   const int mtx = mt == 4 ? 2 : 1, mty = mt >= 2 ? 2 : 1;
-  a.tiles_x = (w + 8 * mtx - 1) / (8 * mtx); a.tiles_y = (h + 4 * mty - 1) / (4 * mty);
+  a.tiles_x = (ow + 8 * mtx - 1) / (8 * mtx); a.tiles_y = (oh + 4 * mty - 1) / (4 * mty);
   // LDS: two staged rounds of kw chunks each
-  const size_t lds_a = (size_t)2 * kw * (8 * mtx + 2) * (4 * mty + 2) * kLatRow * 4;
+  const size_t lds_a = (size_t)2 * kw * ((8 * mtx - 1) * stride + 3) * ((4 * mty - 1) * stride + 3) * kLatRow * 4;
   M4D_CHECK_ARG(lds_a <= 160 * 1024);
   hipStream_t s = (hipStream_t)stream;
-  if (mt == 1) lat_launch<1, 1>(a, kw, s);
-  else if (mt == 2) lat_launch<1, 2>(a, kw, s);
-  else lat_launch<2, 2>(a, kw, s);
+  if (stride == 1) {
+    if (mt == 1) lat_launch<1, 1, 1>(a, kw, s);
+    else if (mt == 2) lat_launch<1, 2, 1>(a, kw, s);
+    else lat_launch<2, 2, 1>(a, kw, s);
+  } else {
+    if (mt == 1) lat_launch<1, 1, 2>(a, kw, s);
+    else if (mt == 2) lat_launch<1, 2, 2>(a, kw, s);
+    else lat_launch<2, 2, 2>(a, kw, s);
+  }
   return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_conv3x3_lat(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
+                               const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, float slope,
+                               int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream) {
+  return lat_launch_any(x, s_in, x_slab_floats, x_bias, x_slope, wp, bias, b, h, w, Cin, Cout, 1, slope, mt, kw, s_out, out,
+                        out_slab_floats, stream);
+}
+
+extern "C" int m4d_conv3x3s_lat(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
+                                const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, int stride, float slope,
+                                int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream) {
+  return lat_launch_any(x, s_in, x_slab_floats, x_bias, x_slope, wp, bias, b, h, w, Cin, Cout, stride, slope, mt, kw, s_out, out,
+                        out_slab_floats, stream);
 }
 
 extern "C" int m4d_partial_finish(const float* x, int s_in, long long x_slab_floats, const float* bias, float slope,

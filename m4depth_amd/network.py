@@ -151,6 +151,11 @@ small_map_stride2 = _os.environ.get("M4D_CONV_SMALL_S2", "1") == "1"     # the c
 # (network_ops.PartialAct) that it adds while staging.  Levels 4-6 at batch 1: 59 / 50 / 52 us of refiner convolutions per
 # level -> 38 / 37 / 48 (tools/bench_lat_convs.py).  0 = the round-2/3 small-map kernels.
 lat_conv_max_pixels = int(_os.environ.get("M4D_LAT_CONV_PX", "2048"))
+# ... and the narrow layers (Cout <= 32: one cout group, the Winograd kernels run them as half units on 30-120 workgroups) up to
+# this many pixels: level 3's 64 -> 32 layer at batch 1 (48x160)
+lat_conv_narrow_max_pixels = int(_os.environ.get("M4D_LAT_CONV_NARROW_PX", "0"))
+# ... and the stride-2 encoder layers whose OUTPUT has at most this many pixels (sequence batch included)
+lat_conv_s2_max_pixels = int(_os.environ.get("M4D_LAT_CONV_S2_PX", "2048"))
 
 # DSCV and SNCV of a small level (<= 6000 pixels) in one launch (m4d_dscv_sncv_fwd).  0 = two launches.
 fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
@@ -376,9 +381,13 @@ class _Conv3x3SameTF(torch.nn.Module):
 
     def lat_eligible(self, b, h, w, cin):
         """Would ``forward`` run this layer on the latency-first small-map kernel for an input of this shape?"""
+        if not (self.small_maps_ok and conv_arith == "bf16x3" and cin >= 16 and cin % 4 == 0 and self.stride in (1, 2)):
+            return False
         eff_b = self.dispatch_batch if self.per_image_dispatch else b
-        return (self.small_maps_ok and self.stride == 1 and conv_arith == "bf16x3" and lat_conv_max_pixels > 0
-                and eff_b * h * w <= lat_conv_max_pixels and cin >= 16 and cin % 4 == 0)
+        if self.stride == 2:                              # the coarse stride-2 encoder layers: by OUTPUT pixels
+            return small_map_stride2 and eff_b * (-(-h // 2)) * (-(-w // 2)) <= lat_conv_s2_max_pixels
+        limit = max(lat_conv_max_pixels, lat_conv_narrow_max_pixels) if self.out_channels <= 32 else lat_conv_max_pixels
+        return eff_b * h * w <= limit
 
     def _packed_weights_wino6(self, cin_pad=None):
         """(wu6 int16 bits, CoutPad) for m4d_conv3x3_wino6_bias_act: U = G g G^T split into three bf16 terms on the host."""
@@ -428,8 +437,9 @@ class _Conv3x3SameTF(torch.nn.Module):
         if self.lat_eligible(b_, h_, w_, cin_):
             wl = self._packed_weights_lat(cin_)
             # (configuration from the per-image grid x the dispatch batch, like the kernel choice: the same in every launch mode)
-            cfg = nops.lat_config(eff_b, h_, w_, cin_, self.out_channels, final)
-            return _timed("conv", self.tag, lambda: nops.conv3x3_lat(x_nhwc, wl, self.bias, self.out_channels, act, config=cfg))
+            cfg = nops.lat_config(eff_b, h_, w_, cin_, self.out_channels, final, self.stride)
+            return _timed("conv", self.tag, lambda: nops.conv3x3_lat(x_nhwc, wl, self.bias, self.out_channels, act, config=cfg,
+                                                                     stride=self.stride))
         wino = _use_winograd(eff_b, h_, w_, cin_, self.out_channels, self.stride)
         if wino == 6:
             wu, cpad = self._packed_weights_wino6(cin_)
@@ -540,7 +550,8 @@ class FeaturePyramid(torch.nn.Module):
             if self.use_dinl and i == 0:
                 tmp = dn_layer(conv_s1(feature_maps), slope=0.1)
             else:
-                tmp = conv_s1(feature_maps, slope=0.1)
+                # (consumed by conv_s2 alone: on the latency-first small-map kernels it may stay K-slice partial sums)
+                tmp = conv_s1(feature_maps, slope=0.1, final=False)
             feature_maps = conv_s2(tmp, slope=0.1)
             outputs.append(feature_maps)
         return outputs
@@ -993,8 +1004,9 @@ class M4Depth(torch.nn.Module):
                 conv._packed_weights()
                 if small_conv_split and conv.small_maps_ok and conv.stride == 1 and 16 <= cin <= 256 and cin % 4 == 0:
                     conv._packed_weights_small6()
-                if conv.small_maps_ok and conv.stride == 1 and conv_arith == "bf16x3" and lat_conv_max_pixels > 0 \
-                        and cin >= 16 and cin % 4 == 0:
+                if conv.small_maps_ok and conv_arith == "bf16x3" and cin >= 16 and cin % 4 == 0 and (
+                        (conv.stride == 1 and max(lat_conv_max_pixels, lat_conv_narrow_max_pixels) > 0)
+                        or (conv.stride == 2 and lat_conv_s2_max_pixels > 0)):
                     conv._packed_weights_lat()
                 if cin == 3 or (conv.stride == 2 and cin == 16 and conv.out_channels == 16):
                     conv._hwio_device()                # the encoder's level-0 kernels read the TF layout directly

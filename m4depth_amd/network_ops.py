@@ -396,13 +396,20 @@ class PartialAct:
         return out
 
 
-def lat_config(b, h, w, cin, cout, final=False):
-    """(mt, kw, s_out) of m4d_conv3x3_lat for a layer -- the rule the sweep of tools/bench_lat_convs.py reads out
-    (profiles/r05_lat_conv_sweep.txt): as many K slices over workgroups as there can be (s_out <= 4 partial slabs, no empty
-    slice; ``final`` forces 1: the consumer cannot add slabs), one chunk per wave where the slice allows it (kw = 1 / 2 / 4 K
-    sub-slices over the waves of a workgroup), and a grid of at most one workgroup per CU: on larger maps first the waves
-    stop splitting K (kw -> 1: four cout groups share one staged halo), then a wave takes 2 / 4 M-tiles."""
+def _lat_halo_pixels(mt, stride):
+    mtx, mty = (2 if mt == 4 else 1), (2 if mt >= 2 else 1)
+    return ((8 * mtx - 1) * stride + 3) * ((4 * mty - 1) * stride + 3)
+
+
+def lat_config(b, h, w, cin, cout, final=False, stride=1):
+    """(mt, kw, s_out) of m4d_conv3x3_lat / m4d_conv3x3s_lat for a layer -- the rule the sweep of tools/bench_lat_convs.py
+    reads out (profiles/r05_lat_conv_sweep.txt): as many K slices over workgroups as there can be (s_out <= 4 partial slabs, no
+    empty slice; ``final`` forces 1: the consumer cannot add slabs), one chunk per wave where the slice allows it (kw = 1 / 2 /
+    4 K sub-slices over the waves of a workgroup), and a grid of at most one workgroup per CU: on larger maps first the waves
+    stop splitting K (kw -> 1: four cout groups share one staged halo), then a wave takes 2 / 4 M-tiles.  (h, w) = the INPUT
+    size; two staged rounds of kw chunks must fit the 160 KB of LDS."""
     n_chunks, n_groups = -(-cin // 16), -(-cout // 32)
+    oh, ow = -(-h // stride), -(-w // stride)
     s_out = 1 if final else min(4, n_chunks)
     while s_out > 1 and (s_out - 1) * (-(-n_chunks // s_out)) >= n_chunks:
         s_out -= 1                                      # no empty K slice
@@ -411,19 +418,23 @@ def lat_config(b, h, w, cin, cout, final=False):
 
     def wgs(mt, kw):
         mtx, mty = (2 if mt == 4 else 1), (2 if mt >= 2 else 1)
-        tiles = b * (-(-h // (4 * mty))) * (-(-w // (8 * mtx)))
+        tiles = b * (-(-oh // (4 * mty))) * (-(-ow // (8 * mtx)))
         return tiles * (-(-n_groups // (4 // kw))) * s_out
+
+    def fits(mt, kw):
+        return 2 * kw * _lat_halo_pixels(mt, stride) * 96 <= 160 * 1024
     mt = 1
-    while wgs(mt, kw) > 256 and kw > 1:
+    while (wgs(mt, kw) > 256 or not fits(mt, kw)) and kw > 1:
         kw //= 2
-    while wgs(mt, kw) > 256 and mt < 4:
+    while wgs(mt, kw) > 256 and mt < 4 and fits(mt * 2, kw):
         mt *= 2
     return mt, kw, s_out
 
 
-def conv3x3_lat(x, wp, bias, cout, slope=0.1, final=False, config=None):
-    """m4d_conv3x3_lat: ``x`` a finished [b,h,w,Cin] tensor or a ``PartialAct``; returns a finished tensor (s_out == 1) or a
-    ``PartialAct`` the next m4d_conv3x3_lat call finishes while staging.  ``config`` = (mt, kw, s_out) overrides lat_config."""
+def conv3x3_lat(x, wp, bias, cout, slope=0.1, final=False, config=None, stride=1):
+    """m4d_conv3x3_lat / m4d_conv3x3s_lat: ``x`` a finished [b,h,w,Cin] tensor or a ``PartialAct``; returns a finished tensor
+    (s_out == 1) or a ``PartialAct`` the next call finishes while staging.  ``config`` = (mt, kw, s_out) overrides lat_config;
+    ``stride`` 1 or 2 (TF 'SAME')."""
     if isinstance(x, PartialAct):
         xs, s_in, x_bias, x_slope = x.slabs, x.slabs.shape[0], x.bias, x.slope
         b, h, w, cin = x.shape
@@ -433,12 +444,13 @@ def conv3x3_lat(x, wp, bias, cout, slope=0.1, final=False, config=None):
         s_in, x_bias, x_slope = 1, None, 1.0
         b, h, w, cin = xs.shape
         slab = 0
-    mt, kw, s_out = config if config is not None else lat_config(b, h, w, cin, cout, final)
+    mt, kw, s_out = config if config is not None else lat_config(b, h, w, cin, cout, final, stride)
     act = 1.0 if slope is None else float(slope)
-    out = torch.empty((s_out, b, h, w, cout), dtype=torch.float32, device=xs.device)
-    check(lib.m4d_conv3x3_lat(dptr(xs, "x"), s_in, slab, dptr(x_bias, "x_bias"), float(x_slope), dptr(wp, "wp", torch.int16),
-                              dptr(bias, "bias"), b, h, w, cin, int(cout), act, mt, kw, s_out, dptr(out), b * h * w * int(cout),
-                              stream_ptr()), "m4d_conv3x3_lat")
+    oh, ow = -(-h // stride), -(-w // stride)
+    out = torch.empty((s_out, b, oh, ow, cout), dtype=torch.float32, device=xs.device)
+    check(lib.m4d_conv3x3s_lat(dptr(xs, "x"), s_in, slab, dptr(x_bias, "x_bias"), float(x_slope), dptr(wp, "wp", torch.int16),
+                               dptr(bias, "bias"), b, h, w, cin, int(cout), int(stride), act, mt, kw, s_out, dptr(out),
+                               b * oh * ow * int(cout), stream_ptr()), "m4d_conv3x3s_lat")
     return out[0] if s_out == 1 else PartialAct(out, bias, act)
 
 

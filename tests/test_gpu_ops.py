@@ -613,6 +613,57 @@ def test_latency_conv_vs_oracle(M, dev, b, h, w, cin, cout, slope):
     assert torch.equal(default, nops.conv3x3_lat(xd, wd, bd, cout, slope, final=True))     # deterministic
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 48, 160, 96, 96), (2, 24, 80, 128, 128), (1, 12, 40, 192, 192), (1, 96, 320, 64, 64),
+                                            (1, 13, 17, 32, 40), (3, 7, 10, 100, 20), (1, 8, 9, 16, 32)])
+def test_latency_conv_stride2_vs_oracle(M, dev, b, h, w, cin, cout):
+    """m4d_conv3x3s_lat at stride 2 (the coarse stride-2 encoder layers, m4depth_network.py:66-72): TF 'SAME' padding on even
+    and odd sizes (pad before 0 / 1), every (mt, kw, s_out) that fits the LDS, against the oracle and the fp32-MFMA one-launch
+    kernel it replaces; partial slabs consumed by a following stride-1 call bit for bit as the finished tensor."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.standard_normal([b, h, w, cin]).astype(F)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = (0.1 * rng.standard_normal([cout])).astype(F)
+    xd, bd = to_dev(x, dev), to_dev(bias, dev)
+    wd = torch.from_numpy(nops.pack_conv_weights_lat(k).view(np.int16)).to(dev)
+    r = O.conv2d_same(x, k, bias, 2)
+    ref32 = np.where(r > 0, r, r * F(0.1)).astype(F)
+    oh, ow = -(-h // 2), -(-w // 2)
+    assert ref32.shape == (b, oh, ow, cout)
+    n_chunks = -(-cin // 16)
+    tried = 0
+    same_order = {}
+    for kw in (1, 2, 4):
+        for s_out in (1, 2, 4):
+            if s_out > n_chunks or (s_out - 1) * (-(-n_chunks // s_out)) >= n_chunks:
+                continue
+            for mt in (1, 2, 4):
+                if 2 * kw * nops._lat_halo_pixels(mt, 2) * 96 > 160 * 1024:
+                    continue
+                out = nops.conv3x3_lat(xd, wd, bd, cout, 0.1, config=(mt, kw, s_out), stride=2)
+                if s_out > 1:
+                    out = out.dense()
+                tried += 1
+                assert np.max(np.abs(npy(out) - ref32)) < 1e-5 * max(1.0, np.abs(ref32).max()), (mt, kw, s_out)
+                key = (kw, s_out)
+                if key in same_order:
+                    assert torch.equal(out, same_order[key]), (mt, kw, s_out)
+                else:
+                    same_order[key] = out
+    assert tried >= 4
+    default = nops.conv3x3_lat(xd, wd, bd, cout, 0.1, final=True, stride=2)
+    cfg = nops.lat_config(b, h, w, cin, cout, True, 2)
+    assert torch.equal(default, same_order[(cfg[1], 1)])
+    if n_chunks >= 2 and cout % 4 == 0 and cout >= 16:
+        # stride-2 partial slabs -> a stride-1 consumer
+        k2 = (rng.standard_normal([3, 3, cout, 32]) * np.sqrt(2.0 / (9 * cout))).astype(F)
+        w2 = torch.from_numpy(nops.pack_conv_weights_lat(k2).view(np.int16)).to(dev)
+        b2 = to_dev(np.zeros(32, F), dev)
+        p = nops.conv3x3_lat(xd, wd, bd, cout, 0.1, config=(1, 1, 2), stride=2)
+        assert isinstance(p, nops.PartialAct)
+        assert torch.equal(nops.conv3x3_lat(p, w2, b2, 32, 0.1, final=True), nops.conv3x3_lat(p.dense(), w2, b2, 32, 0.1, final=True))
+
+
 def test_latency_conv_chain_finishes_partial_sums_while_staging(M, dev):
     """A chain of m4d_conv3x3_lat calls hands K-slice partial sums from layer to layer (``PartialAct``): the consumer adds the
     slabs in slab order, the producer's bias and leaky_relu while it stages its halo -- bit for bit what it computes from the
