@@ -197,6 +197,10 @@ level_pipeline_streams = int(_os.environ.get("M4D_LEVEL_PIPELINE", "8"))
 _pf = _os.environ.get("M4D_PIPE_FORK_FRAMES", "1,2")
 pipeline_fork_frames = None if _pf == "all" else {int(v) for v in _pf.split(",") if v.strip() != ""}
 pipeline_skip_implied_encoder_wait = _os.environ.get("M4D_PIPE_SKIP_ENC_WAIT", "1") == "1"
+# A reset frame (new_traj: six state-seeding launches of a few microseconds) shares the stream of the frame that follows it: the
+# first full frame's coarse-to-fine chain then has no cross-stream wait in front of every level (round 5: each such wait is a
+# ~4.7 us gap in the executor's queue, profiles/r05_queue_trace_b1_graph.txt, on a chain that runs with the chip otherwise idle).
+pipeline_merge_reset_frame = _os.environ.get("M4D_PIPE_MERGE_RESET", "1") == "1"
 # Encoding every frame on its own stream too (instead of one encoder pass batched over the frames, before the
 # decoder) was measured slightly slower (633 vs 643 frames/s at batch 1): the batched pass has 4x fewer launches.
 # Encoder level 0 (conv 3->16, DINL, conv 16->16 stride 2) as m4d_enc_level0_fwd: three passes that recompute the first
@@ -896,11 +900,25 @@ class DepthEstimatorPyramid(torch.nn.Module):
         # or level-major order turn the lists level-major and cost 16 %: profiles/r04_graph_executor.txt.)
         order = [(seq_i, diag - seq_i) for diag in range(n_fr + n_lvls - 1)
                  for seq_i in range(max(0, diag - n_lvls + 1), min(n_fr, diag + 1))]
+
+        def is_reset(f):
+            nt = traj_samples[f]["new_traj"]
+            return bool(nt.reshape(-1)[0].item()) if isinstance(nt, torch.Tensor) else bool(np.asarray(nt).reshape(-1)[0])
+        # frame -> stream: one per frame; with pipeline_merge_reset_frame a reset frame rides on the next frame's stream
+        stream_of = list(range(n_fr))
+        if pipeline_merge_reset_frame:
+            for f in range(n_fr - 1):
+                if is_reset(f) and not is_reset(f + 1):
+                    stream_of[f] = f + 1
+            # a merged reset frame must be ISSUED before the frame it shares the stream with reaches the same level: issue the
+            # whole reset frame first (it is six tiny launches)
+            merged = [f for f in range(n_fr) if stream_of[f] != f]
+            order = [(f, l) for f in merged for l in range(n_lvls)] + [(f, l) for (f, l) in order if f not in merged]
         for seq_i, l in order:
             if True:
                 lvl = n_lvls - 1 - l
                 sample = traj_samples[seq_i]
-                st = streams[seq_i % n_streams]
+                st = streams[stream_of[seq_i] % n_streams]
                 with torch.cuda.stream(st):
                     if l == 0:
                         if f_maps_pyrs is None:          # per-frame encoder on the frame's own stream
@@ -921,8 +939,8 @@ class DepthEstimatorPyramid(torch.nn.Module):
                             # a later frame of that batch: its features come from another stream (implied by the wait on the
                             # previous frame's level below when that frame is of the same encoder batch)
                             st.wait_event(late_encoder[1])
-                    if seq_i > 0:
-                        st.wait_event(done[(seq_i - 1, lvl)])
+                    if seq_i > 0 and stream_of[seq_i - 1] != stream_of[seq_i]:
+                        st.wait_event(done[(seq_i - 1, lvl)])           # (same stream: ordered by the stream itself)
                     prev = None if d_est[seq_i] is None else dict(d_est[seq_i][-1])
                     est = self.levels[lvl](f_pyrs[seq_i][lvl], prev, sample['rot'], sample['trans'], local_cameras[lvl],
                                            sample["new_traj"])
