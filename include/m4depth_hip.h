@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -320,6 +320,15 @@ int m4d_level_front(const float* raw_f, float* norm_out, const float* prev_f, co
                     const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
                     int b, int h, int w, int C, int nbre_cuts, int cv_accum,
                     float* f_input, int f_stride, float log_scale, void* stream);
+/* ... with the search ranges as arguments: (dscv_range, sncv_range) = (4, 3), the reference's hard-coded windows
+ * (m4depth_network.py:221,232), or (6, 6), BASELINE configs[4] (13 hypotheses, 13x13 window: levels 1-5 of the 6-level pyramid;
+ * f_stride = (2 dscv_range + 1 + (2 sncv_range + 1)^2) * cuts + 6 rounded up to a multiple of 8).  Bit-identical to the three
+ * separate entry points with the same ranges. */
+int m4d_level_front_r(const float* raw_f, float* norm_out, const float* prev_f, const float* depth_prev_t,
+                      const float* prev_l_parallax, const float* prev_l_other, int ph, int pw,
+                      const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
+                      int b, int h, int w, int C, int nbre_cuts, int dscv_range, int sncv_range, int cv_accum,
+                      float* f_input, int f_stride, float log_scale, void* stream);
 
 /* Level-local intrinsics of DepthEstimatorPyramid.call (m4depth_network.py:300-302) for all levels in one launch:
  * f_out / c_out [levels,b,2], level l (0 = finest) = cam / 2^(l+1). */

@@ -103,6 +103,8 @@ _SIGNATURES = {
     "m4d_level_front_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "m4d_level_front": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
                         _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_f, _c_fp],
+    "m4d_level_front_r": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
+                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_f, _c_fp],
     "m4d_conv3x3_wgrad": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, ctypes.c_longlong, _c_fp, _c_fp],
     "m4d_dilate2": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_camera_pyramid": [_c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_fp, _c_fp],

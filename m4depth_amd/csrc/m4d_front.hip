@@ -53,9 +53,12 @@ struct FrontArgs {
   unsigned long long* stamps;  // profiling only (m4d_front_set_stamps): 7 cycle-counter stamps per workgroup
 };
 
-template <int NC, int K, int TW, int TH, int YS>
+// RD / RS = the DSCV / SNCV search ranges: 4 / 3 are the reference's (m4depth_network.py:221,232); 6 / 6 is BASELINE configs[4]
+// ("large-window LDS tiling stress": 13 hypotheses, a 13x13 window -- the halo is 6 pixels wide and a refiner-input row 188 ...
+// 734 floats, so the tiles are 16x8 ... 4x4 pixels)
+template <int NC, int K, int TW, int TH, int YS, int RD = 4, int RS = 3>
 struct FrontGeom {
-  static constexpr int R = 3, MO = 7, NCP = 9;
+  static constexpr int R = RS, MO = 2 * RS + 1, NCP = 2 * RD + 1;
   static constexpr int C = NC * K, CP = C + 4, C4 = C / 4;
   static constexpr int HWT = TW + 2 * R, HHT = TH + 2 * R;
   static constexpr int P = TW * TH;
@@ -77,10 +80,10 @@ struct FrontGeom {
   static_assert(LP >= 4 && LP <= 64, "the centre hypothesis spreads its 4 corners over 4 lanes of the pixel");
 };
 
-template <int NC, int K, int TW, int TH, int YS, bool SEQ16>
+template <int NC, int K, int TW, int TH, int YS, bool SEQ16, int RD = 4, int RS = 3>
 __global__ void __launch_bounds__(TW * TH * K * YS)
 level_front_kernel(const FrontArgs a) {
-  using Gm = FrontGeom<NC, K, TW, TH, YS>;
+  using Gm = FrontGeom<NC, K, TW, TH, YS, RD, RS>;
   constexpr int R = Gm::R, MO = Gm::MO, NCP = Gm::NCP, C = Gm::C, CP = Gm::CP, C4 = Gm::C4, HWT = Gm::HWT, HHT = Gm::HHT;
   constexpr int P = Gm::P, NT = Gm::NT, NW = Gm::NW, LP = Gm::LP, G = Gm::G, PPW = Gm::PPW;
   constexpr int F_IN = Gm::F_IN, F_ST = Gm::F_ST, F_LDS = Gm::F_LDS, U = Gm::U, RPL = Gm::RPL, NPASS = Gm::NPASS;
@@ -392,9 +395,9 @@ level_front_kernel(const FrontArgs a) {
   if (st && t == 0) st[6] = __builtin_readcyclecounter();
 }
 
-template <int NC, int K, int TW, int TH, int YS, bool SEQ16>
+template <int NC, int K, int TW, int TH, int YS, bool SEQ16, int RD = 4, int RS = 3>
 int launch_front_acc(const FrontArgs& a0, hipStream_t s) {
-  using Gm = FrontGeom<NC, K, TW, TH, YS>;
+  using Gm = FrontGeom<NC, K, TW, TH, YS, RD, RS>;
   constexpr size_t lds = (size_t)Gm::LDS_FLOATS * sizeof(float);
   static_assert(lds <= 160 * 1024, "tile does not fit LDS");
   FrontArgs a = a0;
@@ -404,17 +407,17 @@ int launch_front_acc(const FrontArgs& a0, hipStream_t s) {
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&level_front_kernel<NC, K, TW, TH, YS, SEQ16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&level_front_kernel<NC, K, TW, TH, YS, SEQ16, RD, RS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  m4d_launch((level_front_kernel<NC, K, TW, TH, YS, SEQ16>), dim3((unsigned)total), dim3(Gm::NT), lds, s, a);
+  m4d_launch((level_front_kernel<NC, K, TW, TH, YS, SEQ16, RD, RS>), dim3((unsigned)total), dim3(Gm::NT), lds, s, a);
   return M4D_LAUNCH_RESULT();
 }
 
-template <int NC, int K, int TW, int TH, int YS>
+template <int NC, int K, int TW, int TH, int YS, int RD = 4, int RS = 3>
 int launch_front(const FrontArgs& a, hipStream_t s) {
-  return a.cv_accum ? launch_front_acc<NC, K, TW, TH, YS, true>(a, s) : launch_front_acc<NC, K, TW, TH, YS, false>(a, s);
+  return a.cv_accum ? launch_front_acc<NC, K, TW, TH, YS, true, RD, RS>(a, s) : launch_front_acc<NC, K, TW, TH, YS, false, RD, RS>(a, s);
 }
 
 unsigned long long* g_front_stamps = nullptr;        // debug hook (m4d_front_set_stamps)
@@ -424,24 +427,30 @@ unsigned long long* g_front_stamps = nullptr;        // debug hook (m4d_front_se
 extern "C" void m4d_front_set_stamps(unsigned long long* device_buffer) { g_front_stamps = device_buffer; }
 
 extern "C" int m4d_level_front_supported(int C, int nbre_cuts, int dscv_range, int sncv_range, int f_stride) {
-  if (dscv_range != 4 || sncv_range != 3 || nbre_cuts <= 0 || C % nbre_cuts != 0) return 0;
+  if (nbre_cuts <= 0 || C % nbre_cuts != 0) return 0;
   const int nc = C / nbre_cuts;
-  const int f_in = 58 * nbre_cuts + 6;
+  const int ncp = 2 * dscv_range + 1, mo = 2 * sncv_range + 1;
+  const int f_in = (ncp + mo * mo) * nbre_cuts + 6;
   if (f_stride != (f_in + 7) / 8 * 8) return 0;
-  return (nc == 16 && nbre_cuts == 1) || (nc == 16 && nbre_cuts == 2) || (nc == 32 && nbre_cuts == 2) ||
-         (nc == 24 && nbre_cuts == 4) || (nc == 32 && nbre_cuts == 4) || (nc == 24 && nbre_cuts == 8);       // levels 4, 5, 6
+  if (dscv_range == 4 && sncv_range == 3)
+    return (nc == 16 && nbre_cuts == 1) || (nc == 16 && nbre_cuts == 2) || (nc == 32 && nbre_cuts == 2) ||
+           (nc == 24 && nbre_cuts == 4) || (nc == 32 && nbre_cuts == 4) || (nc == 24 && nbre_cuts == 8);     // levels 4, 5, 6
+  if (dscv_range == 6 && sncv_range == 6)          // BASELINE configs[4]: levels 1-5 (level 6's 13x13 halo of 192 channels is 200 KB)
+    return (nc == 16 && nbre_cuts == 1) || (nc == 16 && nbre_cuts == 2) || (nc == 32 && nbre_cuts == 2) ||
+           (nc == 24 && nbre_cuts == 4) || (nc == 32 && nbre_cuts == 4);
+  return 0;
 }
 
-extern "C" int m4d_level_front(const float* raw_f, float* norm_out, const float* prev_f, const float* depth_prev_t,
-                               const float* prev_l_parallax, const float* prev_l_other, int ph, int pw,
-                               const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
-                               int b, int h, int w, int C, int nbre_cuts, int cv_accum,
-                               float* f_input, int f_stride, float log_scale, void* stream) {
+extern "C" int m4d_level_front_r(const float* raw_f, float* norm_out, const float* prev_f, const float* depth_prev_t,
+                                 const float* prev_l_parallax, const float* prev_l_other, int ph, int pw,
+                                 const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
+                                 int b, int h, int w, int C, int nbre_cuts, int dscv_range, int sncv_range, int cv_accum,
+                                 float* f_input, int f_stride, float log_scale, void* stream) {
   M4D_CHECK_ARG(raw_f && norm_out && prev_f && depth_prev_t && rot && trans && cam_f && cam_c && f_input);
   M4D_CHECK_ARG(b > 0 && h >= 2 && w >= 2 && (rot_c == 3 || rot_c == 4) && (cv_accum == 0 || cv_accum == 1));
   M4D_CHECK_ARG((prev_l_parallax == nullptr) == (prev_l_other == nullptr));
   if (prev_l_parallax) M4D_CHECK_ARG(ph > 0 && pw > 0);
-  M4D_CHECK_ARG(m4d_level_front_supported(C, nbre_cuts, 4, 3, f_stride));
+  M4D_CHECK_ARG(m4d_level_front_supported(C, nbre_cuts, dscv_range, sncv_range, f_stride));
   M4D_CHECK_ARG(((((uintptr_t)raw_f | (uintptr_t)norm_out | (uintptr_t)prev_f | (uintptr_t)f_input)) & 15u) == 0);
   M4D_CHECK_ARG(raw_f != norm_out && prev_f != norm_out);
   FrontArgs a;
@@ -453,6 +462,15 @@ extern "C" int m4d_level_front(const float* raw_f, float* norm_out, const float*
   a.stamps = g_front_stamps;
   hipStream_t s = (hipStream_t)stream;
   const int nc = C / nbre_cuts;
+  if (dscv_range == 6) {
+    // 13 hypotheses, 13x13 window (round 5): the tile is what the refiner-input stage (188 / 370 / 734 floats per pixel) and the
+    // 6-pixel halo leave of the LDS; the window rows are split four ways (13 = 4 + 4 + 4 + 1)
+    if (nc == 16 && nbre_cuts == 1) return launch_front<16, 1, 16, 8, 4, 6, 6>(a, s);      // stage 99 KB, halo 45 KB
+    if (nc == 16 && nbre_cuts == 2) return launch_front<16, 2, 8, 8, 4, 6, 6>(a, s);       // stage 97 KB, halo 58 KB
+    if (nc == 32 && nbre_cuts == 2) return launch_front<32, 2, 8, 8, 4, 6, 6>(a, s);       // halo 109 KB
+    if (nc == 24 && nbre_cuts == 4) return launch_front<24, 4, 8, 4, 4, 6, 6>(a, s);       // halo 128 KB
+    return launch_front<32, 4, 4, 4, 4, 6, 6>(a, s);                                       // halo 135 KB
+  }
   // Tile / workgroup shape by geometry and size (profiles/r02_front_tile_sweep.txt): one workgroup's pipeline is a serial
   // chain (stage -> normalise -> SNCV -> DSCV -> store), so a launch needs several workgroups per CU in flight; small maps
   // (levels 2-3 at batch 1: 30720 / 7680 pixels) take half-height tiles with the SNCV window rows split four ways.
@@ -495,4 +513,13 @@ extern "C" int m4d_level_front(const float* raw_f, float* norm_out, const float*
     case 5: return launch_front<32, 2, 16, 4, 4>(a, s);
     default: return launch_front<32, 2, 16, 8, 2>(a, s);
   }
+}
+
+extern "C" int m4d_level_front(const float* raw_f, float* norm_out, const float* prev_f, const float* depth_prev_t,
+                               const float* prev_l_parallax, const float* prev_l_other, int ph, int pw,
+                               const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
+                               int b, int h, int w, int C, int nbre_cuts, int cv_accum,
+                               float* f_input, int f_stride, float log_scale, void* stream) {
+  return m4d_level_front_r(raw_f, norm_out, prev_f, depth_prev_t, prev_l_parallax, prev_l_other, ph, pw, rot, rot_c, trans, cam_f,
+                           cam_c, b, h, w, C, nbre_cuts, 4, 3, cv_accum, f_input, f_stride, log_scale, stream);
 }

@@ -678,8 +678,7 @@ class DepthEstimatorLevel(torch.nn.Module):
         use_front = (fused_front and use_state and not nt and dev.type == "cuda" and self._spare_f is not None
                      and ab.SNCV and ab.time_recurr and ab.normalize_features and ab.level_memory
                      and b * h * w > (fused_front_min_pixels if k <= 2 else max(fused_front_min_pixels, fused_front_coarse_min_pixels))
-                     and self.dscv_range == 4 and self.sncv_range == 3
-                     and bool(lib.m4d_level_front_supported(c, k, 4, 3, F_st)))
+                     and bool(lib.m4d_level_front_supported(c, k, self.dscv_range, self.sncv_range, F_st)))
         # normalised current features land in the spare state buffer: after the level
         # ran they ARE the new prev_f_maps (:211, :259) -- a pointer swap, not a copy.
         # (inference, state mode) the normalisation shares a launch with level_pre below: both open the level, neither
@@ -742,10 +741,11 @@ class DepthEstimatorLevel(torch.nn.Module):
                 pp = as_f32(prev_l_est["parallax"], "prev_l_est['parallax']")
                 po = as_f32(prev_l_est["other"], "prev_l_est['other']")
                 ph, pw = pp.shape[1:3]
-            check(_timed("front", self.lvl_depth, lambda: lib.m4d_level_front(
+            check(_timed("front", self.lvl_depth, lambda: lib.m4d_level_front_r(
                 dptr(curr_f_maps, "curr_f_maps"), dptr(curr_f), dptr(prev_f), dptr(as_f32(prev_t_depth, "prev_t_depth")),
                 dptr(pp), dptr(po), ph, pw, dptr(rot_t), rot_t.shape[1], dptr(tr), dptr(cf), dptr(cc),
-                b, h, w, c, k, _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr), F_st, scale, stream_ptr())), "m4d_level_front")
+                b, h, w, c, k, self.dscv_range, self.sncv_range, _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr), F_st, scale,
+                stream_ptr())), "m4d_level_front_r")
             para_prev_t = para_prev_l = None
         elif fused_cost_volumes and self.ablation.SNCV and dev.type == "cuda" and not kt_on and b * h * w <= 6000:
             # small maps: both (independent) cost volumes in one launch

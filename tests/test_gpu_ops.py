@@ -986,12 +986,36 @@ def test_fused_level_front_is_bitwise_the_separate_kernels(M, dev, depth, b, h, 
     """m4d_level_front (normalise + level_pre + DSCV + SNCV in one launch, whole refiner-input rows) against the three
     separate launches it replaces: refiner input (incl. the zero padding channels), feature state and outputs bit for bit,
     over three consecutive frames (the second and third see a depth memory and a coarser estimate that vary per pixel)."""
+    _fused_front_vs_separate(M, dev, depth, b, h, w, quat, cv_accum, 4, 3)
+
+
+@pytest.mark.parametrize("depth,b,h,w,quat,cv_accum", [
+    (1, 1, 21, 37, True, "fp32_round"),      # 16x8 tiles, ragged both ways; 13 hypotheses over 4 lanes per pixel
+    (1, 2, 8, 16, False, "fp16_seq"),        # exactly one tile
+    (2, 1, 19, 20, True, "fp32_round"),      # C = 32, 2 cuts: 8x8 tiles, refiner-input rows of 370 (stride 376)
+    (3, 2, 16, 17, True, "fp32_round"),      # C = 64: the 109-KB halo
+    (3, 1, 9, 11, False, "fp16_seq"),
+    (4, 1, 13, 18, True, "fp32_round"),      # C = 96, 4 cuts of 24: 8x4 tiles, rows of 734
+    (5, 2, 7, 10, True, "fp32_round"),       # C = 128: 4x4 tiles
+    (5, 1, 8, 8, False, "fp16_seq"),
+])
+def test_fused_level_front_large_windows_is_bitwise_the_separate_kernels(M, dev, depth, b, h, w, quat, cv_accum):
+    """BASELINE configs[4] (search ranges 6 / 6: 13 DSCV hypotheses, a 13x13 SNCV window -- "large-window LDS tiling stress"):
+    m4d_level_front_r's (6, 6) instantiations (levels 1-5, round 5) against m4d_level_pre_normalize + m4d_dscv_fwd +
+    m4d_sncv_fwd with the same ranges, bit for bit; level 6 (192 channels: a 200-KB halo) has no fused form and says so."""
+    from m4depth_amd import network as net
+    assert not net.lib.m4d_level_front_supported(192, 8, 6, 6, (182 * 8 + 6 + 7) // 8 * 8)
+    _fused_front_vs_separate(M, dev, depth, b, h, w, quat, cv_accum, 6, 6)
+
+
+def _fused_front_vs_separate(M, dev, depth, b, h, w, quat, cv_accum, rd, rs):
     from m4depth_amd import network as net
     rng = np.random.default_rng(500 + depth * 10 + h)
     C = S_ENC[depth - 1]
     from m4depth_amd import synthetic as S
-    W = S.init_weights(6, seed=4)
-    settings = {"nbre_lvls": 6, "is_training": False, "ablation": M.M4depthAblationParameters(), "cv_accum": cv_accum}
+    W = S.init_weights(6, seed=4, dscv_range=rd, sncv_range=rs)
+    settings = {"nbre_lvls": 6, "is_training": False, "ablation": M.M4depthAblationParameters(), "cv_accum": cv_accum,
+                "dscv_range": rd, "sncv_range": rs}
     levels = []
     for _ in range(2):
         gl = M.DepthEstimatorLevel(settings, depth)
@@ -1002,7 +1026,8 @@ def test_fused_level_front_is_bitwise_the_separate_kernels(M, dev, depth, b, h, 
     cam = to_dev(camera_np(b, h, w), dev)
     old = (net.fused_front, net.fused_front_min_pixels, net.fused_front_coarse_min_pixels)
     net.fused_front_coarse_min_pixels = 0            # levels 4-6: take the fused front on these small maps too
-    assert bool(net.lib.m4d_level_front_supported(C, 2 ** (depth // 2), 4, 3, (58 * 2 ** (depth // 2) + 6 + 7) // 8 * 8))
+    f_row = (2 * rd + 1 + (2 * rs + 1) ** 2) * 2 ** (depth // 2) + 6
+    assert bool(net.lib.m4d_level_front_supported(C, 2 ** (depth // 2), rd, rs, (f_row + 7) // 8 * 8))
     try:
         for step in range(4):
             rot, trans = motion_np(rng, b, quat=quat, t_scale=(3.0, 3.0, 1.0))
