@@ -265,7 +265,8 @@ def kernel_rooflines(args, batch, timer, net, eager_steps):
         if wino == 6:           # float32 operands as 3 bf16 terms each: 6 bf16 MFMA products per float32 multiply
             flops_exec, peak, key = 6.0 * flops_wino, BF16_MFMA_PEAK_TFLOPS, "wino6_l1_128_128"
             units = batch * ((h1 + 15) // 16) * ((w1 + 15) // 16) * 2
-            persistent = net.wino6_kernel == 2 or (net.wino6_kernel == 0 and units >= 2048)      # csrc/m4d_wino6.hip kPersistentMinUnits
+            from m4depth_amd._lib import lib as _mlib
+            persistent = net.wino6_kernel == 2 or (net.wino6_kernel == 0 and units >= int(_mlib.m4d_wino6_persistent_min_units()))
             kname = (("conv3x3_wino6p_kernel (persistent workgroups, csrc/m4d_wino6p.hip; " if persistent else
                       "conv3x3_wino6_kernel (one workgroup per (tile, 64 couts), csrc/m4d_wino6.hip; ") +
                      "level-1 refiner 128->128, Winograd F(2x2,3x3), float32 operands split into 3 bf16 "

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -184,6 +184,9 @@ int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bia
  * Cin >= 32).  Bit-identical results; an argument, not process state: tests and A/B timing use it. */
 int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                  int Cin, int Cout, int CoutPad, float slope, float* out, int kernel, void* stream);
+/* Grids of at least this many (16x16-pixel tile, 64-cout) units run on the persistent-workgroup form of the kernel above when
+ * `kernel` is 0 (what bench.py needs to name the kernel its roofline layer ran on). */
+long long m4d_wino6_persistent_min_units(void);
 /* Profiling only (tools/wino6_phases.py): per-position cycle stamps of the first 64 workgroups; NULL switches it off. */
 void m4d_wino6_set_stamps(unsigned long long* device_buffer);
 

@@ -119,7 +119,7 @@ _EXPERIMENT_SIGNATURES = {"m4d_tape_begin": [], "m4d_tape_end": [], "m4d_tape_le
 _EXPERIMENT_VOID_SIGNATURES = {"m4d_wino6_set_variant": [_c_int], "m4d_wino6_set_half_tile_max_workgroups": [_c_int]}
 EXPERIMENT_SYMBOLS = list(_EXPERIMENT_SIGNATURES) + list(_EXPERIMENT_VOID_SIGNATURES)
 
-_LL_SIGNATURES = {"m4d_launch_count": [], "m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
+_LL_SIGNATURES = {"m4d_launch_count": [], "m4d_wino6_persistent_min_units": [], "m4d_conv3x3_workspace_floats": [_c_int, _c_int, _c_int, _c_int],
                   "m4d_dinl_workspace_floats": [_c_int, _c_int], "m4d_metrics_workspace_bytes": [],
                   "m4d_bias_act_bwd_workspace_floats": [ctypes.c_longlong, _c_int], "m4d_loss_workspace_floats": [],
                   "m4d_conv3x3_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]}

@@ -542,6 +542,12 @@ extern "C" void m4d_wino6_set_half_tile_max_workgroups(int max_wg) { g_wino6_hal
 int m4d_wino6p_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
                       float slope, float* out, void* stream);
 
+extern "C" long long m4d_wino6_persistent_min_units(void) {
+  static const long long v = [] { const char* e = getenv("M4D_WINO6P_MIN_UNITS"); const long long u = e ? atoll(e) : 0;
+                                  return u > 0 ? u : kPersistentMinUnits; }();             // (env: measurement knob)
+  return v;
+}
+
 extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                           int Cin, int Cout, int CoutPad, float slope, float* out, void* stream) {
   return m4d_conv3x3_wino6_bias_act_k(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, 0, stream);
@@ -559,7 +565,7 @@ extern "C" int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, con
     // per-unit prologue, fetches a tile's halo once for its cout groups and stores 256-byte runs; smaller grids keep this
     // file's kernel (a cheaper epilogue, and the dispatcher places its workgroups dynamically beside other frames' kernels)
     const long long units = (long long)b * ((w + kT - 1) / kT) * ((h + kT - 1) / kT) * (CoutPad / 64);
-    const bool persistent = kernel == 2 || (kernel == 0 && Cin >= 32 && units >= kPersistentMinUnits);
+    const bool persistent = kernel == 2 || (kernel == 0 && Cin >= 32 && units >= m4d_wino6_persistent_min_units());
     if (persistent && g_wino6_stamps == nullptr)
       return m4d_wino6p_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
   }

@@ -529,19 +529,28 @@ int m4d_wino6p_launch(const float* x, const void* wu6, const float* bias, int b,
   const long long units = (long long)b * a.tiles_x * a.tiles_y * (CoutPad / 64);
   M4D_CHECK_ARG(units < (1ll << 31));
   a.units = (int)units;
-  static const int n_cu = [] {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
+  // CU count and the > 64 KB dynamic-LDS opt-in per DEVICE (a process may drive several GPUs)
+  static int cu_of_device[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cu_of_device[dev] == 0) {
+    int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return cus > 0 ? cus : 256;
-  }();                                             // function-local static: initialised once, thread-safe (C++11)
+    cu_of_device[dev] = cus > 0 ? cus : 256;
+  }
+  const int n_cu = cu_of_device[dev];
   // One workgroup per CU at most (154 KB of LDS each).  Large grids: team mode on every CU (see the kernel).  Smaller ones: no
   // more workgroups than the longest range needs -- 960 units on 256 CUs are 4 per workgroup whichever way, so 240 workgroups
   // do it and 16 CUs stay free for the other frames' small kernels.
   const int n_groups = CoutPad / 64;
   a.team = (n_cu % 8 == 0 && n_cu / 8 >= n_groups && units >= 4ll * n_cu) ? 1 : 0;
-  const long long per_wg = (units + n_cu - 1) / n_cu;
+  // M4D_WINO6P_MAX_WG (measurement knob): at most this many persistent workgroups -- the other CUs stay free for the kernels of
+  // the other frames' coarse levels, whose workgroups otherwise each wait for one of this kernel's ~27-us units to end
+  static const int max_wg = [] { const char* e = getenv("M4D_WINO6P_MAX_WG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 30; }();
+  const int cu_used = n_cu < max_wg ? n_cu : max_wg;
+  const long long per_wg = (units + cu_used - 1) / cu_used;
   const unsigned grid = a.team ? (unsigned)n_cu : (unsigned)((units + per_wg - 1) / per_wg);
   m4d_launch(conv3x3_wino6p_kernel, dim3(grid), dim3(512), (size_t)pLds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();

@@ -915,39 +915,38 @@ class DepthEstimatorPyramid(torch.nn.Module):
             merged = [f for f in range(n_fr) if stream_of[f] != f]
             order = [(f, l) for f in merged for l in range(n_lvls)] + [(f, l) for (f, l) in order if f not in merged]
         for seq_i, l in order:
-            if True:
-                lvl = n_lvls - 1 - l
-                sample = traj_samples[seq_i]
-                st = streams[stream_of[seq_i] % n_streams]
-                with torch.cuda.stream(st):
-                    if l == 0:
-                        if f_maps_pyrs is None:          # per-frame encoder on the frame's own stream
-                            f_pyrs[seq_i] = encoder(sample['RGB_im'])
-                        elif f_maps_pyrs[seq_i] is not None:
-                            f_pyrs[seq_i] = f_maps_pyrs[seq_i]
-                        elif f_pyrs[seq_i] is None:      # first frame of the late encoder batch: encode all remaining frames here
-                            rest = [i for i in range(seq_i, n_fr) if f_maps_pyrs[i] is None]
-                            bsz = sample['RGB_im'].shape[0]
-                            tail = encoder(_stack_frames([traj_samples[i] for i in rest]))
-                            for j, i in enumerate(rest):
-                                f_pyrs[i] = [lvl[j * bsz:(j + 1) * bsz] for lvl in tail]
-                            enc_done = torch.cuda.Event()
-                            enc_done.record(st)
-                            keep.append(enc_done)
-                            late_encoder = (seq_i, enc_done)
-                        elif not (pipeline_skip_implied_encoder_wait and seq_i - 1 >= late_encoder[0]):
-                            # a later frame of that batch: its features come from another stream (implied by the wait on the
-                            # previous frame's level below when that frame is of the same encoder batch)
-                            st.wait_event(late_encoder[1])
-                    if seq_i > 0 and stream_of[seq_i - 1] != stream_of[seq_i]:
-                        st.wait_event(done[(seq_i - 1, lvl)])           # (same stream: ordered by the stream itself)
-                    prev = None if d_est[seq_i] is None else dict(d_est[seq_i][-1])
-                    est = self.levels[lvl](f_pyrs[seq_i][lvl], prev, sample['rot'], sample['trans'], local_cameras[lvl],
-                                           sample["new_traj"])
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                    done[(seq_i, lvl)] = ev
-                    d_est[seq_i] = [est] if d_est[seq_i] is None else d_est[seq_i] + [est]
+            lvl = n_lvls - 1 - l
+            sample = traj_samples[seq_i]
+            st = streams[stream_of[seq_i] % n_streams]
+            with torch.cuda.stream(st):
+                if l == 0:
+                    if f_maps_pyrs is None:          # per-frame encoder on the frame's own stream
+                        f_pyrs[seq_i] = encoder(sample['RGB_im'])
+                    elif f_maps_pyrs[seq_i] is not None:
+                        f_pyrs[seq_i] = f_maps_pyrs[seq_i]
+                    elif f_pyrs[seq_i] is None:      # first frame of the late encoder batch: encode all remaining frames here
+                        rest = [i for i in range(seq_i, n_fr) if f_maps_pyrs[i] is None]
+                        bsz = sample['RGB_im'].shape[0]
+                        tail = encoder(_stack_frames([traj_samples[i] for i in rest]))
+                        for j, i in enumerate(rest):
+                            f_pyrs[i] = [lvl[j * bsz:(j + 1) * bsz] for lvl in tail]
+                        enc_done = torch.cuda.Event()
+                        enc_done.record(st)
+                        keep.append(enc_done)
+                        late_encoder = (seq_i, enc_done)
+                    elif not (pipeline_skip_implied_encoder_wait and seq_i - 1 >= late_encoder[0]):
+                        # a later frame of that batch: its features come from another stream (implied by the wait on the
+                        # previous frame's level below when that frame is of the same encoder batch)
+                        st.wait_event(late_encoder[1])
+                if seq_i > 0 and stream_of[seq_i - 1] != stream_of[seq_i]:
+                    st.wait_event(done[(seq_i - 1, lvl)])           # (same stream: ordered by the stream itself)
+                prev = None if d_est[seq_i] is None else dict(d_est[seq_i][-1])
+                est = self.levels[lvl](f_pyrs[seq_i][lvl], prev, sample['rot'], sample['trans'], local_cameras[lvl],
+                                       sample["new_traj"])
+                ev = torch.cuda.Event()
+                ev.record(st)
+                done[(seq_i, lvl)] = ev
+                d_est[seq_i] = [est] if d_est[seq_i] is None else d_est[seq_i] + [est]
         d_est_seq = [ests[::-1] for ests in d_est]
         for st in streams:                            # join
             ev = torch.cuda.Event()
