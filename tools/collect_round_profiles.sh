@@ -7,7 +7,7 @@
 #   of the roofline kernel.
 # usage (GPU box, repo root): bash tools/collect_round_profiles.sh r04   -> gpurun_out/<tag>/ ; copy what is cited into profiles/
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -65,6 +65,16 @@ timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${TAG}_q -
 TRACE=$(find /tmp/prof_${TAG}_q -name "*kernel_trace.csv" | head -1)
 [ -n "$TRACE" ] && python tools/queue_trace.py "$TRACE" > $OUT/queue_trace_b1_graph.txt 2> /dev/null
 need $OUT/queue_trace_b1_graph.txt
+
+# the captured graph's kernel nodes at batch 1 and 32 (every node one of libm4depth_hip.so's: the tool exits non-zero otherwise)
+for B in 1 32; do
+  timeout 600 python tools/dump_graph_nodes.py --batch $B --out $OUT/hipgraph_nodes_b$B.dot > $OUT/hipgraph_nodes_b$B.txt 2>&1 || FAILED="$FAILED graph_nodes_b$B"
+  need $OUT/hipgraph_nodes_b$B.dot $OUT/hipgraph_nodes_b$B.txt
+done
+# the latency-first small-map convolution: every configuration per coarse-level layer, beside conv3x3_small6 (network_ops.lat_config's table)
+timeout 900 python tools/bench_lat_convs.py sweep > $OUT/lat_conv_sweep.txt 2>&1; need $OUT/lat_conv_sweep.txt
+# BASELINE configs[4] (768x2560, search ranges 6 / 6): fused fronts of levels 1-4 (m4d_level_front_r)
+timeout 600 python bench.py --height 768 --width 2560 --dscv-range 6 --sncv-range 6 --steps 10 --no-cpu-baseline > $OUT/bench_config4.json 2> $OUT/bench_config4.err; need $OUT/bench_config4.json
 
 timeout 600 python tools/bench_train.py > $OUT/bench_train.json 2>/dev/null; need $OUT/bench_train.json
 head -c 400 $OUT/bench_b1.json; echo
