@@ -247,7 +247,10 @@ def kernel_rooflines(args, batch, timer, net, eager_steps):
     hot path of a full frame against the HBM peak."""
     rep = {}
     summ = timer.summary()
-    traffic, traffic_note = load_traffic(batch)
+    if (args.height, args.width, args.levels, args.dscv_range, args.sncv_range) == (384, 1280, 6, 4, 3):
+        traffic, traffic_note = load_traffic(batch)
+    else:                                   # the PMC passes are collected at the level-1 geometry of the 384x1280 pyramid only
+        traffic, traffic_note = {}, "no PMC traffic for this geometry (tools/pmc_traffic.py measures the 384x1280 / ranges 4,3 pyramid)"
     rep["traffic_note"] = traffic_note
 
     def tr(name):

@@ -155,7 +155,7 @@ lat_conv_max_pixels = int(_os.environ.get("M4D_LAT_CONV_PX", "2048"))
 # this many pixels: level 3's 64 -> 32 layer at batch 1 (48x160)
 lat_conv_narrow_max_pixels = int(_os.environ.get("M4D_LAT_CONV_NARROW_PX", "0"))
 # ... and the stride-2 encoder layers whose OUTPUT has at most this many pixels (sequence batch included)
-lat_conv_s2_max_pixels = int(_os.environ.get("M4D_LAT_CONV_S2_PX", "2048"))
+lat_conv_s2_max_pixels = int(_os.environ.get("M4D_LAT_CONV_S2_PX", "0"))
 
 # DSCV and SNCV of a small level (<= 6000 pixels) in one launch (m4d_dscv_sncv_fwd).  0 = two launches.
 fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
@@ -1285,9 +1285,7 @@ class GraphedSequence:
     copies), replays, and returns the static ``depth`` output tensor.  The batch must have the captured shapes and
     the captured ``new_traj`` pattern (it is control flow here); anything else raises."""
 
-    def __init__(self, model, example, warmup=2, debug_dot=None):
-        """``debug_dot``: a path -- the captured graph is dumped there in DOT form (hipGraphDebugDotPrint through
-        torch.cuda.CUDAGraph.debug_dump): one node per kernel with its mangled name, see ``kernel_nodes``."""
+    def __init__(self, model, example, warmup=2):
         self.model = model
         nt = example["new_traj"]
         self.new_traj = nt.clone() if isinstance(nt, torch.Tensor) else torch.as_tensor(np.asarray(nt))
@@ -1309,20 +1307,9 @@ class GraphedSequence:
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        if debug_dot is not None:
-            self.graph.enable_debug_mode()
         with torch.cuda.graph(self.graph, stream=self.stream):
             self.depth = self._run()
-        if debug_dot is not None:
-            self.graph.debug_dump(str(debug_dot))
         self.weights_stamp = model.weights_stamp()
-
-    @staticmethod
-    def kernel_nodes(dot_path):
-        """The kernel names (mangled) of a ``debug_dot`` dump, in node order."""
-        import re
-        text = open(dot_path).read()
-        return re.findall(r'label="\d+\n([^\n"]+)\n', text)
 
     def _samples(self):
         nt = torch.unbind(self.new_traj, dim=1)

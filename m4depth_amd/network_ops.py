@@ -401,6 +401,11 @@ def _lat_halo_pixels(mt, stride):
     return ((8 * mtx - 1) * stride + 3) * ((4 * mty - 1) * stride + 3)
 
 
+import os as _os
+# grid cap of the latency-first small-map convolution (workgroups): 256 = one per CU
+lat_max_workgroups = int(_os.environ.get("M4D_LAT_MAX_WG", "256"))
+
+
 def lat_config(b, h, w, cin, cout, final=False, stride=1):
     """(mt, kw, s_out) of m4d_conv3x3_lat / m4d_conv3x3s_lat for a layer -- the rule the sweep of tools/bench_lat_convs.py
     reads out (profiles/r05_lat_conv_sweep.txt): as many K slices over workgroups as there can be (s_out <= 4 partial slabs, no
@@ -424,9 +429,9 @@ def lat_config(b, h, w, cin, cout, final=False, stride=1):
     def fits(mt, kw):
         return 2 * kw * _lat_halo_pixels(mt, stride) * 96 <= 160 * 1024
     mt = 1
-    while (wgs(mt, kw) > 256 or not fits(mt, kw)) and kw > 1:
+    while (wgs(mt, kw) > lat_max_workgroups or not fits(mt, kw)) and kw > 1:
         kw //= 2
-    while wgs(mt, kw) > 256 and mt < 4 and fits(mt * 2, kw):
+    while wgs(mt, kw) > lat_max_workgroups and mt < 4 and fits(mt * 2, kw):
         mt *= 2
     return mt, kw, s_out
 
