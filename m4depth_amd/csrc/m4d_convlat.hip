@@ -91,17 +91,21 @@ __device__ __forceinline__ void lat_stage(const LatArgs& a, float* lds_a, int t,
   }
 }
 
-template <int MTX, int MTY, int STRIDE>
+// MW ("M over waves", MTX * MTY = 4): the four waves of a workgroup are the four M-tiles of its 16x8-pixel tile, every wave all of
+// the K slice for the workgroup's ONE cout group (kw = cgw = 1) -- for narrow short-K layers on LARGER maps (the encoder's
+// 32 -> 32 and 64 -> 64 stride-2 layers: one or two cout groups, 2-4 chunks), where the other split leaves waves idle.
+template <int MTX, int MTY, int STRIDE, bool MW = false>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_lat_kernel(const LatArgs a) {
-  constexpr int MT = MTX * MTY;
+  constexpr int MT = MTX * MTY, MA = MW ? 1 : MT;     // M-tiles of the workgroup's tile / accumulators per wave
+  static_assert(!MW || MT == 4, "one M-tile per wave");
   constexpr int TW = 8 * MTX, TH = 4 * MTY, HW = (TW - 1) * STRIDE + 3, HP = HW * ((TH - 1) * STRIDE + 3);   // output tile, input halo
   constexpr int kChunkF = HP * kLatRow;               // floats of one staged chunk
   extern __shared__ __align__(16) float lds_dyn[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int cgw = 1 << a.cgw_log2, kw = 4 >> a.cgw_log2;
-  const int cg = wave & (cgw - 1), ks = wave >> a.cgw_log2;
+  const int cgw = MW ? 1 : 1 << a.cgw_log2, kw = MW ? 1 : 4 >> a.cgw_log2;
+  const int cg = MW ? 0 : wave & (cgw - 1), ks = MW ? 0 : wave >> a.cgw_log2;
   const int tiles = a.tiles_x * a.tiles_y;
   const int bi = blockIdx.x / tiles, tile = blockIdx.x - bi * tiles;
   const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * TW;
@@ -116,9 +120,9 @@ conv3x3_lat_kernel(const LatArgs a) {
   // epilogue operand first: nothing at the end of the launch waits for memory
   const float my_bias = (a.s_out == 1 && active && co < a.Cout) ? a.bias[co] : 0.f;
 
-  lat_f32x16 acc[MT];
+  lat_f32x16 acc[MA];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MA; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
@@ -160,8 +164,8 @@ conv3x3_lat_kernel(const LatArgs a) {
           const lat_bf16x8 b1 = __builtin_bit_cast(lat_bf16x8, bq[q][1][tp]);
           const lat_bf16x8 b2 = __builtin_bit_cast(lat_bf16x8, bq[q][2][tp]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const int my = m / MTX, mx = m % MTX;
+          for (int m = 0; m < MA; ++m) {
+            const int mi = MW ? wave : m, my = mi / MTX, mx = mi % MTX;
             const float* ap = ac + (((my * 4 + (n >> 3)) * STRIDE + tp / 3) * HW + (mx * 8 + (n & 7)) * STRIDE + tp % 3) * kLatRow;
             const lat_bf16x8 a0 = *reinterpret_cast<const lat_bf16x8*>(ap);
             const lat_bf16x8 a1 = *reinterpret_cast<const lat_bf16x8*>(ap + 8);
@@ -185,7 +189,7 @@ conv3x3_lat_kernel(const LatArgs a) {
     float* red = lds_dyn;                             // [kw - 1][cgw][MT][16][64]
     if (ks > 0) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MA; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[((((ks - 1) * cgw + cg) * MT + m) * 16 + r) * 64 + lane] = acc[m][r];
     }
@@ -193,7 +197,7 @@ conv3x3_lat_kernel(const LatArgs a) {
     if (ks == 0) {
       for (int k = 1; k < kw; ++k)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MA; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][r] += red[((((k - 1) * cgw + cg) * MT + m) * 16 + r) * 64 + lane];
     }
@@ -202,8 +206,8 @@ conv3x3_lat_kernel(const LatArgs a) {
   float* op = a.out + blockIdx.z * a.out_slab + (long long)bi * a.oh * a.ow * a.Cout + co;
   const bool final_out = a.s_out == 1;
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int my = m / MTX, mx = m % MTX;
+  for (int m = 0; m < MA; ++m) {
+    const int mi = MW ? wave : m, my = mi / MTX, mx = mi % MTX;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;  // C/D map of the 32x32 MFMA: col = lane & 31, row = mr
@@ -236,21 +240,22 @@ partial_finish_kernel(const float* __restrict__ x, long long slab, int s_in, con
   }
 }
 
-template <int MTX, int MTY, int STRIDE>
-void lat_launch(const LatArgs& a, int kw, hipStream_t s) {
+template <int MTX, int MTY, int STRIDE, bool MW = false>
+void lat_launch(const LatArgs& a, int kw_in, hipStream_t s) {
   constexpr int HP = ((8 * MTX - 1) * STRIDE + 3) * ((4 * MTY - 1) * STRIDE + 3), MT = MTX * MTY;
-  const int cgw = 4 / kw;
+  const int kw = MW ? 1 : kw_in;
+  const int cgw = MW ? 1 : 4 / kw;
   const size_t lds_a = (size_t)2 * kw * HP * kLatRow * 4;
   const size_t lds_r = (size_t)(kw - 1) * cgw * MT * 16 * 64 * 4;
   const size_t lds = lds_a > lds_r ? lds_a : lds_r;
   static bool attr_done = false;                      // per instantiation; the attribute is per function, set once per process
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lat_kernel<MTX, MTY, STRIDE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lat_kernel<MTX, MTY, STRIDE, MW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const dim3 grid((unsigned)(a.b * a.tiles_x * a.tiles_y), (unsigned)((a.n_groups + cgw - 1) / cgw), (unsigned)a.s_out);
-  m4d_launch(conv3x3_lat_kernel<MTX, MTY, STRIDE>, grid, dim3(256), lds, s, a);
+  m4d_launch(conv3x3_lat_kernel<MTX, MTY, STRIDE, MW>, grid, dim3(256), lds, s, a);
 }
 
 }  // namespace
@@ -263,7 +268,8 @@ static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, con
   const int oh = (h + stride - 1) / stride, ow = (w + stride - 1) / stride;
   M4D_CHECK_ARG(s_in >= 1 && s_in <= 4 && (s_in == 1 || x_slab_floats >= (long long)b * h * w * Cin));
   M4D_CHECK_ARG(s_out >= 1 && (s_out == 1 || out_slab_floats >= (long long)b * oh * ow * Cout));
-  M4D_CHECK_ARG((mt == 1 || mt == 2 || mt == 4) && (kw == 1 || kw == 2 || kw == 4));
+  M4D_CHECK_ARG((mt == 1 || mt == 2 || mt == 4 || mt == 8) && (kw == 1 || kw == 2 || kw == 4));   // mt 8 = "M over waves" (kw unused)
+  if (mt == 8) kw = 1;
   LatArgs a;
   a.x = x; a.x_slab = x_slab_floats; a.s_in = s_in; a.x_bias = x_bias; a.x_slope = x_slope;
   a.wp = reinterpret_cast<const unsigned char*>(wp); a.bias = bias; a.slope = slope;
@@ -277,7 +283,7 @@ static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, con
   a.cgw_log2 = kw == 1 ? 2 : (kw == 2 ? 1 : 0);
   a.chunks_per_slice = (a.n_chunks + s_out - 1) / s_out;
   M4D_CHECK_ARG((long long)(s_out - 1) * a.chunks_per_slice < a.n_chunks);     // no empty K slice
-  const int mtx = mt == 4 ? 2 : 1, mty = mt >= 2 ? 2 : 1;
+  const int mtx = mt >= 4 ? 2 : 1, mty = mt >= 2 ? 2 : 1;
   a.tiles_x = (ow + 8 * mtx - 1) / (8 * mtx); a.tiles_y = (oh + 4 * mty - 1) / (4 * mty);
   // LDS: two staged rounds of kw chunks each
   const size_t lds_a = (size_t)2 * kw * ((8 * mtx - 1) * stride + 3) * ((4 * mty - 1) * stride + 3) * kLatRow * 4;
@@ -286,11 +292,13 @@ static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, con
   if (stride == 1) {
     if (mt == 1) lat_launch<1, 1, 1>(a, kw, s);
     else if (mt == 2) lat_launch<1, 2, 1>(a, kw, s);
-    else lat_launch<2, 2, 1>(a, kw, s);
+    else if (mt == 4) lat_launch<2, 2, 1>(a, kw, s);
+    else lat_launch<2, 2, 1, true>(a, kw, s);
   } else {
     if (mt == 1) lat_launch<1, 1, 2>(a, kw, s);
     else if (mt == 2) lat_launch<1, 2, 2>(a, kw, s);
-    else lat_launch<2, 2, 2>(a, kw, s);
+    else if (mt == 4) lat_launch<2, 2, 2>(a, kw, s);
+    else lat_launch<2, 2, 2, true>(a, kw, s);
   }
   return M4D_LAUNCH_RESULT();
 }

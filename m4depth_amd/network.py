@@ -156,6 +156,9 @@ lat_conv_max_pixels = int(_os.environ.get("M4D_LAT_CONV_PX", "2048"))
 lat_conv_narrow_max_pixels = int(_os.environ.get("M4D_LAT_CONV_NARROW_PX", "0"))
 # ... and the stride-2 encoder layers whose OUTPUT has at most this many pixels (sequence batch included)
 lat_conv_s2_max_pixels = int(_os.environ.get("M4D_LAT_CONV_S2_PX", "0"))
+# ... and the narrow short-K stride-2 encoder layers (Cin, Cout <= 64: 32 -> 32 at 192x640 and 64 -> 64 at 96x320 of the 384x1280
+# pyramid, fp32-MFMA direct kernels of ~25 us each at batch 1) in the kernel's M-over-waves form, up to this many OUTPUT pixels
+lat_conv_mw_max_pixels = int(_os.environ.get("M4D_LAT_CONV_MW_PX", "0"))
 
 # DSCV and SNCV of a small level (<= 6000 pixels) in one launch (m4d_dscv_sncv_fwd).  0 = two launches.
 fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
@@ -388,10 +391,17 @@ class _Conv3x3SameTF(torch.nn.Module):
         if not (self.small_maps_ok and conv_arith == "bf16x3" and cin >= 16 and cin % 4 == 0 and self.stride in (1, 2)):
             return False
         eff_b = self.dispatch_batch if self.per_image_dispatch else b
-        if self.stride == 2:                              # the coarse stride-2 encoder layers: by OUTPUT pixels
-            return small_map_stride2 and eff_b * (-(-h // 2)) * (-(-w // 2)) <= lat_conv_s2_max_pixels
+        if self.stride == 2:                              # the stride-2 encoder layers: by OUTPUT pixels
+            opx = eff_b * (-(-h // 2)) * (-(-w // 2))
+            return self._lat_mw(b, h, w, cin) or (small_map_stride2 and opx <= lat_conv_s2_max_pixels)
         limit = max(lat_conv_max_pixels, lat_conv_narrow_max_pixels) if self.out_channels <= 32 else lat_conv_max_pixels
         return eff_b * h * w <= limit
+
+    def _lat_mw(self, b, h, w, cin):
+        """The M-over-waves form of the latency-first kernel for this (stride-2, narrow, short-K) layer?"""
+        eff_b = self.dispatch_batch if self.per_image_dispatch else b
+        return (self.stride == 2 and cin % 16 == 0 and cin <= 64 and self.out_channels <= 64
+                and small_map_conv_pixels < eff_b * (-(-h // 2)) * (-(-w // 2)) <= lat_conv_mw_max_pixels)
 
     def _packed_weights_wino6(self, cin_pad=None):
         """(wu6 int16 bits, CoutPad) for m4d_conv3x3_wino6_bias_act: U = G g G^T split into three bf16 terms on the host."""
@@ -441,7 +451,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         if self.lat_eligible(b_, h_, w_, cin_):
             wl = self._packed_weights_lat(cin_)
             # (configuration from the per-image grid x the dispatch batch, like the kernel choice: the same in every launch mode)
-            cfg = nops.lat_config(eff_b, h_, w_, cin_, self.out_channels, final, self.stride)
+            cfg = nops.lat_config(eff_b, h_, w_, cin_, self.out_channels, final, self.stride, mw=self._lat_mw(b_, h_, w_, cin_))
             return _timed("conv", self.tag, lambda: nops.conv3x3_lat(x_nhwc, wl, self.bias, self.out_channels, act, config=cfg,
                                                                      stride=self.stride))
         wino = _use_winograd(eff_b, h_, w_, cin_, self.out_channels, self.stride)
@@ -1023,7 +1033,7 @@ class M4Depth(torch.nn.Module):
                     conv._packed_weights_small6()
                 if conv.small_maps_ok and conv_arith == "bf16x3" and cin >= 16 and cin % 4 == 0 and (
                         (conv.stride == 1 and max(lat_conv_max_pixels, lat_conv_narrow_max_pixels) > 0)
-                        or (conv.stride == 2 and lat_conv_s2_max_pixels > 0)):
+                        or (conv.stride == 2 and max(lat_conv_s2_max_pixels, lat_conv_mw_max_pixels) > 0)):
                     conv._packed_weights_lat()
                 if cin == 3 or (conv.stride == 2 and cin == 16 and conv.out_channels == 16):
                     conv._hwio_device()                # the encoder's level-0 kernels read the TF layout directly

@@ -397,7 +397,7 @@ class PartialAct:
 
 
 def _lat_halo_pixels(mt, stride):
-    mtx, mty = (2 if mt == 4 else 1), (2 if mt >= 2 else 1)
+    mtx, mty = (2 if mt >= 4 else 1), (2 if mt >= 2 else 1)
     return ((8 * mtx - 1) * stride + 3) * ((4 * mty - 1) * stride + 3)
 
 
@@ -406,15 +406,18 @@ import os as _os
 lat_max_workgroups = int(_os.environ.get("M4D_LAT_MAX_WG", "256"))
 
 
-def lat_config(b, h, w, cin, cout, final=False, stride=1):
+def lat_config(b, h, w, cin, cout, final=False, stride=1, mw=False):
     """(mt, kw, s_out) of m4d_conv3x3_lat / m4d_conv3x3s_lat for a layer -- the rule the sweep of tools/bench_lat_convs.py
-    reads out (profiles/r05_lat_conv_sweep.txt): as many K slices over workgroups as there can be (s_out <= 4 partial slabs, no
+    reads out (profiles/r05_lat_conv_sweep.txt; ``mw``: the M-over-waves form for narrow short-K layers on larger maps, see
+    csrc/m4d_convlat.hip): as many K slices over workgroups as there can be (s_out <= 4 partial slabs, no
     empty slice; ``final`` forces 1: the consumer cannot add slabs), one chunk per wave where the slice allows it (kw = 1 / 2 /
     4 K sub-slices over the waves of a workgroup), and a grid of at most one workgroup per CU: on larger maps first the waves
     stop splitting K (kw -> 1: four cout groups share one staged halo), then a wave takes 2 / 4 M-tiles.  (h, w) = the INPUT
     size; two staged rounds of kw chunks must fit the 160 KB of LDS."""
     n_chunks, n_groups = -(-cin // 16), -(-cout // 32)
     oh, ow = -(-h // stride), -(-w // stride)
+    if mw:                                              # "M over waves": mt code 8, one cout group per workgroup, K unsplit
+        return 8, 1, 1
     s_out = 1 if final else min(4, n_chunks)
     while s_out > 1 and (s_out - 1) * (-(-n_chunks // s_out)) >= n_chunks:
         s_out -= 1                                      # no empty K slice

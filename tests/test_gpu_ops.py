@@ -607,6 +607,8 @@ def test_latency_conv_vs_oracle(M, dev, b, h, w, cin, cout, slope):
                 else:
                     same_order[key] = out
     assert tried >= 6
+    mw = nops.conv3x3_lat(xd, wd, bd, cout, slope, config=(8, 1, 1))       # "M over waves": the kw = 1, s_out = 1 order
+    assert torch.equal(mw, same_order[(1, 1)])
     default = nops.conv3x3_lat(xd, wd, bd, cout, slope, final=True)
     cfg = nops.lat_config(b, h, w, cin, cout, final=True)
     assert cfg[2] == 1 and torch.equal(default, same_order[(cfg[1], 1)])
@@ -651,6 +653,10 @@ def test_latency_conv_stride2_vs_oracle(M, dev, b, h, w, cin, cout):
                 else:
                     same_order[key] = out
     assert tried >= 4
+    for s_out in (1, 2):                                # "M over waves" (mt code 8): K unsplit inside the workgroup = the kw 1 order
+        if (1, s_out) in same_order:
+            out = nops.conv3x3_lat(xd, wd, bd, cout, 0.1, config=(8, 1, s_out), stride=2)
+            assert torch.equal(out.dense() if s_out > 1 else out, same_order[(1, s_out)]), ("mw", s_out)
     default = nops.conv3x3_lat(xd, wd, bd, cout, 0.1, final=True, stride=2)
     cfg = nops.lat_config(b, h, w, cin, cout, True, 2)
     assert torch.equal(default, same_order[(cfg[1], 1)])

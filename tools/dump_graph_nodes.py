@@ -47,7 +47,7 @@ shutil.copy(best, out)
 cnt = collections.Counter(names)
 foreign = [n for n in cnt if not (n.startswith("_ZN12_GLOBAL__N_1") or "conv3x3_wino" in n)]
 print(f"batch {a.batch}, {a.height}x{a.width}, {a.levels} levels, {a.frames} frames: {len(names)} kernel nodes, {len(cnt)} distinct kernels, "
-      f"{len(foreign)} not from libm4depth_hip.so; library launches per step {int(net.lib.m4d_launch_count())} since load")
+      f"{len(foreign)} not from libm4depth_hip.so; {int(net.lib.m4d_launch_count())} library launches since load")
 for n, c in cnt.most_common():
     print(f"  {c:4d}  {n[:120]}")
 shutil.rmtree(work, ignore_errors=True)
