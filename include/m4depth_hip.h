@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -257,6 +257,10 @@ int m4d_bias_act_bwd(const float* g, const float* out, long long rows, int C, fl
  * memory of an OIHW parameter) -> [ceil(K/16)][9][Npad][16]; transpose = 0: K = I, N = O (forward),
  * 1: K = O, N = I with the taps rotated by 180 degrees (data gradient of the stride-1 layer). */
 int m4d_pack_conv_weights(const float* w_ohwi, int O, int I, int transpose, float* wp, void* stream);
+/* ... in the layout of m4d_conv3x3_lat ([N/32][K/16][9][3 parts][64 lanes][8] bf16, every weight split exactly into three bf16
+ * terms: what network_ops.pack_conv_weights_lat builds on the host), for the forward (transpose = 0: K = I, N = O) or the data
+ * gradient (transpose = 1: the rotated / transposed kernel, K = O, N = I); wp: ceil(N/32) * ceil(K/16) * 27 KB. */
+int m4d_pack_conv_weights_lat(const float* w_ohwi, int O, int I, int transpose, void* wp, void* stream);
 /* One level's term of m4depth_loss (m4depth_network.py:491-536), unweighted:
  * mean |resize(log clip(gt)) - log clip(pred)| ('map': tf.image.resize bilinear, :532) or the
  * hole-aware block mean of velodyne ground truth (:514-527).  out2 = (term, point count);

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "m4d_normalize_cuts_bwd": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_bias_act_bwd": [_c_fp, _c_fp, ctypes.c_longlong, _c_int, _c_f, _c_fp, _c_fp, _c_fp, _c_fp],
     "m4d_pack_conv_weights": [_c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp],
+    "m4d_pack_conv_weights_lat": [_c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_loss_level_fwd": [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
     "m4d_loss_level_bwd": [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_decode_rgb8_resize": [_c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_fp],

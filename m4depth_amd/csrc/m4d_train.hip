@@ -180,6 +180,43 @@ pack_conv_weights_kernel(const float* __restrict__ w, int O, int I, int transpos
   wp[idx] = v;
 }
 
+// The same parameter in the layout of m4d_conv3x3_lat (network_ops.pack_conv_weights_lat, built on the host for inference):
+// [N/32 groups][K/16 chunks][9 taps][3 parts][64 lanes][8] bf16, lane = k_half * 32 + n % 32, element e = channel 8 k_half + e,
+// every float32 weight split exactly into three bf16 terms (m4d_split3_pair: the host splitter's roundings).  One thread per
+// (group, chunk, tap, lane): 8 weights -> 3 x 16 bytes.
+__global__ void __launch_bounds__(256)
+pack_conv_weights_lat_kernel(const float* __restrict__ w, int O, int I, int transpose, int n_chunks, long long total,
+                             uint4* __restrict__ wp) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  long long r = idx >> 6;
+  const int t = (int)(r % 9); r /= 9;
+  const int c = (int)(r % n_chunks);
+  const int g = (int)(r / n_chunks);
+  const int K = transpose ? O : I, N = transpose ? I : O;
+  const int n = g * 32 + (lane & 31), k0 = c * 16 + (lane >> 5) * 8;
+  const int tap = transpose ? 8 - t : t;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int kc = k0 + e;
+    float x = 0.f;
+    if (kc < K && n < N) {
+      const int o = transpose ? kc : n, i = transpose ? n : kc;
+      x = w[((long long)o * 9 + tap) * I + i];
+    }
+    v[e] = x;
+  }
+  unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m4d_split3_pair(v[2 * e], v[2 * e + 1], hi[e], mid[e], lo[e]);
+  uint4* dst = wp + (((long long)(g * n_chunks + c) * 9 + t) * 3) * 64 + lane;
+  dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  dst[64] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+  dst[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
 // ---- m4depth_loss, one pyramid level -------------------------------------------------------
 struct LossAxis { int lo, hi; float lerp; };
 __device__ __forceinline__ LossAxis half_pixel_axis(int o, float scale, int in_n) {
@@ -340,6 +377,16 @@ extern "C" int m4d_pack_conv_weights(const float* w_ohwi, int O, int I, int tran
   const long long total = (long long)((K + 15) / 16) * 9 * n_pad * 16;
   m4d_launch(pack_conv_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      w_ohwi, O, I, transpose, n_pad, total, wp);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_pack_conv_weights_lat(const float* w_ohwi, int O, int I, int transpose, void* wp, void* stream) {
+  M4D_CHECK_ARG(w_ohwi && wp && O > 0 && I > 0);
+  const int K = transpose ? O : I, N = transpose ? I : O;
+  const int n_chunks = (K + 15) / 16, n_groups = (N + 31) / 32;
+  const long long total = (long long)n_groups * n_chunks * 9 * 64;
+  m4d_launch(pack_conv_weights_lat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+             w_ohwi, O, I, transpose, n_chunks, total, reinterpret_cast<uint4*>(wp));
   return M4D_LAUNCH_RESULT();
 }
 

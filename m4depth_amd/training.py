@@ -52,14 +52,45 @@ def _packed(cache, weight, transpose):
     return hit
 
 
+def _packed_lat(cache, weight, transpose):
+    """The parameter in m4d_conv3x3_lat's fragment-major bf16-split layout (int16 bits), re-packed on the device per step."""
+    key = ("bwd_lat" if transpose else "fwd_lat", weight.data_ptr(), weight._version)
+    hit = cache.get(key)
+    if hit is None:
+        O, I = weight.shape[0], weight.shape[1]
+        w_ohwi = weight.detach().permute(0, 2, 3, 1).contiguous()
+        K, N = (O, I) if transpose else (I, O)
+        hit = torch.empty((-(-N // 32), -(-K // 16), 9, 3, 64, 8), dtype=torch.int16, device=weight.device)
+        check(lib.m4d_pack_conv_weights_lat(dptr(w_ohwi, "weight"), O, I, int(transpose), dptr(hit, "wp", torch.int16), stream_ptr()),
+              "m4d_pack_conv_weights_lat")
+        cache[key] = hit
+    return hit
+
+
+def _lat_ok(b, h, w, cin, stride):
+    """Small maps (the coarse levels of a training crop) run forward and data gradient on the latency-first kernel
+    (csrc/m4d_convlat.hip: float32 operands as exact 3 x bf16 splits) instead of the fp32-MFMA split-K pair."""
+    from . import network as net
+    return (stride == 1 and net.conv_arith == "bf16x3" and cin >= 16 and cin % 4 == 0 and b * h * w <= net.lat_conv_max_pixels
+            and train_lat_convs)
+
+
+import os as _os
+train_lat_convs = _os.environ.get("M4D_TRAIN_LAT_CONVS", "1") == "1"
+
+
 class _ConvBiasAct(torch.autograd.Function):
     """leaky_relu(conv3x3_same_tf(x, w) + bias, slope) on NHWC activations, OIHW weights (channels-last strides)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, slope, cache):
         cout = weight.shape[0]
-        wp, n_pad = _packed(cache, weight, False)
-        out = nops.conv3x3_bias_act(x, wp, bias.detach(), cout, n_pad, slope, stride=stride)
+        b, h, w, cin = x.shape
+        if _lat_ok(b, h, w, cin, stride):
+            out = nops.conv3x3_lat(x, _packed_lat(cache, weight, False), bias.detach(), cout, slope, final=True)
+        else:
+            wp, n_pad = _packed(cache, weight, False)
+            out = nops.conv3x3_bias_act(x, wp, bias.detach(), cout, n_pad, slope, stride=stride)
         ctx.save_for_backward(x, weight, out)
         ctx.cfg = (stride, slope, cache)
         return out
@@ -84,7 +115,6 @@ class _ConvBiasAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # adjoint of a 'SAME' 3x3 correlation = the stride-1 correlation with k'[ky,kx,o,i] = k[2-ky,2-kx,i,o] of the
             # gradient (stride 2: of the gradient spread onto the input grid with zeros in between)
-            wp, n_pad = _packed(cache, weight, True)
             zero = cache.get(("zero", cin))
             if zero is None:
                 zero = torch.zeros(cin, dtype=torch.float32, device=x.device)
@@ -93,7 +123,11 @@ class _ConvBiasAct(torch.autograd.Function):
             if stride == 2:
                 gd = torch.empty((b, h, w, cout), dtype=torch.float32, device=g.device)
                 check(lib.m4d_dilate2(dptr(g), b, oh, ow, cout, h, w, dptr(gd), stream_ptr()), "m4d_dilate2")
-            g_x = nops.conv3x3_bias_act(gd, wp, zero, cin, n_pad, 1.0, stride=1)
+            if _lat_ok(b, h, w, cout, 1) and stride == 1:
+                g_x = nops.conv3x3_lat(gd, _packed_lat(cache, weight, True), zero, cin, 1.0, final=True)
+            else:
+                wp, n_pad = _packed(cache, weight, True)
+                g_x = nops.conv3x3_bias_act(gd, wp, zero, cin, n_pad, 1.0, stride=1)
         g_w = None
         if ctx.needs_input_grad[1]:
             # gradient in the parameter's own memory layout: OIHW tensor with channels-last strides = [O][ky][kx][I]

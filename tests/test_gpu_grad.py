@@ -108,6 +108,23 @@ def test_pack_conv_weights_kernel_matches_host_packer(M, dev):
         assert npad_t == cpad_t and np.array_equal(npy(got_t), want_t)
 
 
+def test_pack_conv_weights_lat_kernel_matches_host_packer(M, dev):
+    """m4d_pack_conv_weights_lat (the per-step device packer of the training path: fragment-major layout of m4d_conv3x3_lat,
+    every weight split exactly into three bf16 terms) against network_ops.pack_conv_weights_lat, forward and data-gradient
+    (rotated / transposed) forms, bit for bit."""
+    from m4depth_amd import network_ops as nops, training as TR
+    rng = np.random.default_rng(1)
+    for O, I in ((45, 37), (128, 122), (5, 16), (96, 128)):
+        w = torch.from_numpy(rng.normal(size=[O, I, 3, 3]).astype(F)).to(dev).contiguous(memory_format=torch.channels_last)
+        hwio = npy(w).transpose(2, 3, 1, 0)
+        want = nops.pack_conv_weights_lat(hwio).view(np.int16)
+        got = TR._packed_lat({}, w, False)
+        assert got.shape == want.shape and np.array_equal(npy(got), want)
+        want_t = nops.pack_conv_weights_lat(np.ascontiguousarray(hwio[::-1, ::-1].transpose(0, 1, 3, 2))).view(np.int16)
+        got_t = TR._packed_lat({}, w, True)
+        assert got_t.shape == want_t.shape and np.array_equal(npy(got_t), want_t)
+
+
 def test_glue_backward_kernels_match_autodiff_of_the_restatement(M, dev):
     from m4depth_amd import training as TR
     rng = np.random.default_rng(4)
@@ -178,7 +195,9 @@ def test_bias_act_backward_kernel(M, dev):
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,stride", [
-    (2, 16, 24, 32, 64, 1),       # whole 32-blocks
+    (2, 16, 24, 32, 64, 1),       # whole 32-blocks (a small map: forward and data gradient on the latency-first kernel)
+    (3, 24, 24, 128, 96, 1),      # level 4 of a 384x384 training crop at batch 3: the same kernels, partly filled last cout group
+    (1, 40, 60, 32, 64, 1),       # above the small-map threshold: the fp32-MFMA pair
     (1, 9, 21, 122, 96, 1),       # ragged tiles, Cin not a multiple of 4 (the training graph's exact-width refiner input)
     (3, 12, 16, 16, 16, 2),       # stride 2, even size: TF pads bottom / right only
     (1, 11, 13, 64, 64, 2),       # stride 2, odd sizes: one before, one after
