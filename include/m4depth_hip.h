@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -403,6 +403,21 @@ int m4d_conv3x3_lat(const float* x, int s_in, long long x_slab_floats, const flo
 int m4d_conv3x3s_lat(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
                      const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, int stride, float slope,
                      int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream);
+/* A CHAIN of m4d_conv3x3_lat layers (stride 1, one M-tile per wave) in ONE launch: layer l reads what layer l - 1 writes (its
+ * partial slabs or finished activation: layers[l].x == layers[l-1].out, s_in == s_out of the layer before).  A few workgroups
+ * (workgroups_per_xcd, all on ONE XCD: the first to arrive picks it, 8 x workgroups_per_xcd are launched) stay resident and
+ * draw the work items of the separate launches -- the same code in the same order: the SAME BITS as n_layers calls of
+ * m4d_conv3x3_lat -- from one ticket counter; the items of a layer wait for the completion counter of the layer before.  What it
+ * is for: beside other frames' chip-filling kernels every dependent launch waits tens of microseconds for its first workgroup, so
+ * a chain there costs its number of launches (csrc/m4d_convlat.hip).  ctrl: >= 16 zero-initialised 32-bit words per chain that
+ * may be in flight (the kernel leaves them zero); ctrl[3] != 0 afterwards = a bounded wait expired (results invalid). */
+typedef struct {
+  const float* x; int s_in; long long x_slab_floats; const float* x_bias; float x_slope;   /* input (as m4d_conv3x3_lat) */
+  const void* wp; const float* bias; int Cin, Cout; float slope;                         /* the layer */
+  int kw, s_out; float* out; long long out_slab_floats;                                  /* its K split and output */
+} m4d_lat_layer;
+int m4d_conv3x3_lat_chain(const m4d_lat_layer* layers, int n_layers, int b, int h, int w, unsigned* ctrl,
+                          int workgroups_per_xcd, void* stream);
 /* out = leaky_relu(bias + slab_0 + ... + slab_{s_in-1}, slope), slabs added in slab order: the finished form of a partial-sum
  * activation, for consumers that do not add the slabs themselves and for inspection.  C % 4 == 0. */
 int m4d_partial_finish(const float* x, int s_in, long long x_slab_floats, const float* bias, float slope,

@@ -23,6 +23,14 @@ _c_fp = ctypes.c_void_p       # device pointers travel as void*
 _c_int = ctypes.c_int
 _c_f = ctypes.c_float
 
+class LatLayer(ctypes.Structure):
+    """m4d_lat_layer of include/m4depth_hip.h (one layer of m4d_conv3x3_lat_chain)."""
+    _fields_ = [("x", ctypes.c_void_p), ("s_in", ctypes.c_int), ("x_slab_floats", ctypes.c_longlong), ("x_bias", ctypes.c_void_p),
+                ("x_slope", ctypes.c_float), ("wp", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("Cin", ctypes.c_int),
+                ("Cout", ctypes.c_int), ("slope", ctypes.c_float), ("kw", ctypes.c_int), ("s_out", ctypes.c_int),
+                ("out", ctypes.c_void_p), ("out_slab_floats", ctypes.c_longlong)]
+
+
 # name -> argtypes; mirrors include/m4depth_hip.h one for one.
 _SIGNATURES = {
     "m4d_backproject_fwd": [_c_fp, _c_fp, ctypes.POINTER(_c_int), _c_fp, _c_fp],
@@ -78,6 +86,7 @@ _SIGNATURES = {
                         _c_int, _c_int, _c_int, _c_fp, ctypes.c_longlong, _c_fp],
     "m4d_conv3x3s_lat": [_c_fp, _c_int, ctypes.c_longlong, _c_fp, _c_f, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                          _c_f, _c_int, _c_int, _c_int, _c_fp, ctypes.c_longlong, _c_fp],
+    "m4d_conv3x3_lat_chain": [ctypes.POINTER(LatLayer), _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp],
     "m4d_partial_finish": [_c_fp, _c_int, ctypes.c_longlong, _c_fp, _c_f, ctypes.c_longlong, _c_int, _c_fp, _c_fp],
     "m4d_conv3x3_wino_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino2_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],

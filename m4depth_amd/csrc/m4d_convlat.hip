@@ -20,6 +20,7 @@
 // Arithmetic = conv3x3_small6_kernel's: float32 operands as exact sums of three bf16 terms, 6 of the 9 term products on
 // v_mfma_f32_32x32x16_bf16, float32 accumulation; the summation ORDER over K differs (chunk -> (slice, wave, round) here), so the
 // two kernels agree to float32 rounding, not bitwise; every variant of THIS kernel with the same (kw, s_out) gives the same bits.
+#include <cstdlib>
 #include "m4d_common.h"
 #include "../../include/m4depth_hip.h"
 
@@ -94,24 +95,39 @@ __device__ __forceinline__ void lat_stage(const LatArgs& a, float* lds_a, int t,
 // MW ("M over waves", MTX * MTY = 4): the four waves of a workgroup are the four M-tiles of its 16x8-pixel tile, every wave all of
 // the K slice for the workgroup's ONE cout group (kw = cgw = 1) -- for narrow short-K layers on LARGER maps (the encoder's
 // 32 -> 32 and 64 -> 64 stride-2 layers: one or two cout groups, 2-4 chunks), where the other split leaves waves idle.
-template <int MTX, int MTY, int STRIDE, bool MW = false>
-__global__ void __launch_bounds__(256, 1)
-conv3x3_lat_kernel(const LatArgs a) {
+// In-launch hand-over between the layers of a chain (conv3x3_lat_chain_kernel below): thread 0 polls the producing layer's completion
+// counter (relaxed agent-scope loads, s_sleep, bounded), then ONE agent-scope acquire drops this CU's stale L1 lines, then the barrier
+// releases the workgroup to its (plain) halo loads.  Every workgroup of a chain runs on ONE XCD (one L2), see the kernel.
+__device__ __forceinline__ void lat_chain_wait(const unsigned* dep, unsigned need, unsigned* err) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    // (polled with a read-modify-write: it is served where the producers' adds are, never by a stale cached line)
+    while (__hip_atomic_fetch_or(const_cast<unsigned*>(dep), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 17)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never hang the GPU
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+template <int MTX, int MTY, int STRIDE, bool MW, bool CHAIN>
+__device__ __forceinline__ void lat_body(const LatArgs& a, const int bx, const int by, const int bz, float* lds_dyn,
+                                         const unsigned* dep, unsigned dep_need, unsigned* err) {
   constexpr int MT = MTX * MTY, MA = MW ? 1 : MT;     // M-tiles of the workgroup's tile / accumulators per wave
   static_assert(!MW || MT == 4, "one M-tile per wave");
   constexpr int TW = 8 * MTX, TH = 4 * MTY, HW = (TW - 1) * STRIDE + 3, HP = HW * ((TH - 1) * STRIDE + 3);   // output tile, input halo
   constexpr int kChunkF = HP * kLatRow;               // floats of one staged chunk
-  extern __shared__ __align__(16) float lds_dyn[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int cgw = MW ? 1 : 1 << a.cgw_log2, kw = MW ? 1 : 4 >> a.cgw_log2;
   const int cg = MW ? 0 : wave & (cgw - 1), ks = MW ? 0 : wave >> a.cgw_log2;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int bi = blockIdx.x / tiles, tile = blockIdx.x - bi * tiles;
+  const int bi = bx / tiles, tile = bx - bi * tiles;
   const int ty0 = (tile / a.tiles_x) * TH, tx0 = (tile % a.tiles_x) * TW;
-  const int g = blockIdx.y * cgw + cg;
+  const int g = by * cgw + cg;
   const bool active = g < a.n_groups;                 // Cout = 96: the fourth wave of a 4-group workgroup idles
-  const int c_begin = blockIdx.z * a.chunks_per_slice;
+  const int c_begin = bz * a.chunks_per_slice;
   const int c_end = min(a.n_chunks, c_begin + a.chunks_per_slice);
   const int n_slice = max(c_end - c_begin, 0);
   const int rounds = (n_slice + kw - 1) / kw;
@@ -144,7 +160,8 @@ conv3x3_lat_kernel(const LatArgs a) {
           for (int tp = 0; tp < 9; ++tp) bq[q][p][tp] = *reinterpret_cast<const float4*>(wc + (tp * 3 + p) * 1024);
       }
     }
-    // ---- the workgroup's halo of the same chunks
+    // ---- (chain: the weights are on their way; now wait for the producing layer) the workgroup's halo of the same chunks
+    if (CHAIN && r0 == 0 && dep != nullptr) lat_chain_wait(dep, dep_need, err);
     const int c0 = c_begin + r0 * kw;
     const int n_st = min(2 * kw, c_end - c0);
     switch (a.s_in) {
@@ -182,7 +199,6 @@ conv3x3_lat_kernel(const LatArgs a) {
     }
     if (r0 + 2 < rounds) __syncthreads();             // the next stage overwrites the halo
   }
-
   // ---- K sub-slices of the workgroup's waves, added in wave order through LDS
   if (kw > 1) {
     __syncthreads();                                  // the reduction buffer aliases the halo
@@ -202,21 +218,122 @@ conv3x3_lat_kernel(const LatArgs a) {
           for (int r = 0; r < 16; ++r) acc[m][r] += red[((((k - 1) * cgw + cg) * MT + m) * 16 + r) * 64 + lane];
     }
   }
-  if (ks != 0 || !active || co >= a.Cout) return;
-  float* op = a.out + blockIdx.z * a.out_slab + (long long)bi * a.oh * a.ow * a.Cout + co;
-  const bool final_out = a.s_out == 1;
+  if (ks == 0 && active && co < a.Cout) {
+    float* op = a.out + bz * a.out_slab + (long long)bi * a.oh * a.ow * a.Cout + co;
+    const bool final_out = a.s_out == 1;
 #pragma unroll
-  for (int m = 0; m < MA; ++m) {
-    const int mi = MW ? wave : m, my = mi / MTX, mx = mi % MTX;
+    for (int m = 0; m < MA; ++m) {
+      const int mi = MW ? wave : m, my = mi / MTX, mx = mi % MTX;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;  // C/D map of the 32x32 MFMA: col = lane & 31, row = mr
-      const int oy = ty0 + my * 4 + (mr >> 3), ox = tx0 + mx * 8 + (mr & 7);
-      if (oy < a.oh && ox < a.ow) {
-        float v = acc[m][r];
-        if (final_out) { v += my_bias; v = v > 0.f ? v : v * a.slope; }
-        op[((long long)oy * a.ow + ox) * a.Cout] = v;
+      for (int r = 0; r < 16; ++r) {
+        const int mr = (r & 3) + 8 * (r >> 2) + 4 * kh;  // C/D map of the 32x32 MFMA: col = lane & 31, row = mr
+        const int oy = ty0 + my * 4 + (mr >> 3), ox = tx0 + mx * 8 + (mr & 7);
+        if (oy < a.oh && ox < a.ow) {
+          float v = acc[m][r];
+          if (final_out) { v += my_bias; v = v > 0.f ? v : v * a.slope; }
+          op[((long long)oy * a.ow + ox) * a.Cout] = v;
+        }
       }
+    }
+  }
+}
+
+template <int MTX, int MTY, int STRIDE, bool MW = false>
+__global__ void __launch_bounds__(256, 1)
+conv3x3_lat_kernel(const LatArgs a) {
+  extern __shared__ __align__(16) float lds_dyn[];
+  lat_body<MTX, MTY, STRIDE, MW, false>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds_dyn, nullptr, 0u, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A CHAIN of those layers in ONE launch (round 5): the refiner layers 1-5 of a coarse level.  Why: beside another frame's level 1
+// (960 one-per-CU Winograd workgroups) every dependent launch of a chain waits ~25 us (up to 57) before its first workgroup runs
+// -- profiles/r05_queue_trace_b1_graph.txt: frame 3's levels 6-4 take 609 us there against 216 alone, 24 launches -- so what a
+// chain costs under contention is its NUMBER OF LAUNCHES.  Here a few workgroups stay resident for the whole chain and draw the
+// work items of the separate launches -- item = one workgroup of conv3x3_lat_kernel, same code, same summation order: the same
+// bits -- from ONE ticket counter in layer order; a layer's items wait for the completion counter of the layer before (after
+// their weight fragments are requested: the weight round trip hides behind the wait).
+//   * Progress needs no assumption about dispatch order or residency: a ticket's dependencies are tickets drawn EARLIER, by workgroups
+//     that are running; workgroups that arrive late just join.  Every spin is bounded (error word instead of a hang).
+//   * Visibility: all workers sit on ONE XCD -- the first workgroup to arrive registers its HW_REG_XCC_ID, workgroups on other XCDs
+//     exit at once -- so producer and consumer share an L2: plain stores drained by s_waitcnt vmcnt(0) (the vector L1 writes
+//     through) + a relaxed agent-scope counter add publish, one agent-scope acquire (L1 invalidate) per consuming item subscribes.
+//     No L2 write-back (buffer_wbl2 costs 38-100 us here: the L2 is full of the other frames' dirty activations, round 2).
+//   * The control block cleans itself: the LAST workgroup to leave (exit counter) zeroes it for the next launch.
+constexpr int kChainMaxLayers = 6;
+struct LatChainArgs {
+  LatArgs layer[kChainMaxLayers];
+  int n_layers;
+  int item_begin[kChainMaxLayers + 1];               // ticket range of every layer
+  int gx[kChainMaxLayers], gy[kChainMaxLayers];      // its grid (x = tiles, y = cout-group blocks; z = K slices)
+  unsigned* ctrl;                                    // [0] worker XCD + 1, [1] ticket, [2] exits, [3] error, [4 + l] items done of layer l
+  int lds_floats;                                    // the items' LDS; one more 16-byte slot behind it broadcasts the ticket
+};
+
+__global__ void __launch_bounds__(256, 1)
+conv3x3_lat_chain_kernel(const LatChainArgs c) {
+  extern __shared__ __align__(16) float lds_dyn[];
+  // (no static LDS: a static variable would sit in front of the dynamic region and misalign its 16-byte accesses)
+  volatile int& sh_word = *reinterpret_cast<volatile int*>(lds_dyn + c.lds_floats);
+  unsigned* ctrl = c.ctrl;
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 15u) + 1u;
+    unsigned expected = 0u;
+    const bool won = __hip_atomic_compare_exchange_strong(ctrl, &expected, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_word = (won || expected == xcc) ? 1 : 0;
+  }
+  __syncthreads();
+  // (readfirstlane: the value is the same in every lane, and the compiler must KNOW it -- a loop whose exit test looks lane-dependent
+  //  is structurised as a divergent loop, in which the lanes that skip a thread-0-only block run ahead into the next iteration's
+  //  barrier: that was a deadlock in bring-up)
+  const bool worker = __builtin_amdgcn_readfirstlane(sh_word) != 0;
+  __syncthreads();
+  if (worker) {
+    const int total = c.item_begin[c.n_layers];
+    // ONE thread-0 block per iteration, fenced by barriers on both sides (publish the finished item + draw the next ticket): with a
+    // thread-0 block at the loop's tail AND one at its head the compiler threads the lanes that skip both into an inner loop of
+    // their own -- barriers included -- and the workgroup deadlocks (bring-up, ROCm 7.2)
+    if (threadIdx.x == 0) sh_word = (int)__hip_atomic_fetch_add(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int item = __builtin_amdgcn_readfirstlane(sh_word);
+    __syncthreads();
+    while (item < total) {
+      int l = 0;
+      while (item >= c.item_begin[l + 1]) ++l;
+      const int idx = item - c.item_begin[l];
+      const int bx = idx % c.gx[l], r = idx / c.gx[l];
+      const int by = r % c.gy[l], bz = r / c.gy[l];
+      const unsigned* dep = l > 0 ? ctrl + 4 + (l - 1) : nullptr;
+      const unsigned need = l > 0 ? (unsigned)(c.item_begin[l] - c.item_begin[l - 1]) : 0u;
+      // (a constant layer index per call: the layer's arguments then come out of scalar registers like a separate launch's)
+      switch (l) {
+        case 0: lat_body<1, 1, 1, false, true>(c.layer[0], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
+        case 1: lat_body<1, 1, 1, false, true>(c.layer[1], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
+        case 2: lat_body<1, 1, 1, false, true>(c.layer[2], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
+        case 3: lat_body<1, 1, 1, false, true>(c.layer[3], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
+        case 4: lat_body<1, 1, 1, false, true>(c.layer[4], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
+        default: lat_body<1, 1, 1, false, true>(c.layer[5], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached the L2
+      __syncthreads();                                   // (also: the next item may overwrite the LDS)
+      if (threadIdx.x == 0) {
+        (void)__hip_atomic_fetch_add(ctrl + 4 + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_word = (int)__hip_atomic_fetch_add(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      item = __builtin_amdgcn_readfirstlane(sh_word);
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    const unsigned n = __hip_atomic_fetch_add(ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == gridDim.x - 1) {                          // the last workgroup out: nobody reads the block any more -- clean for the next launch
+      for (int l = 0; l < c.n_layers; ++l) __hip_atomic_store(ctrl + 4 + l, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctrl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctrl + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctrl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -260,9 +377,10 @@ void lat_launch(const LatArgs& a, int kw_in, hipStream_t s) {
 
 }  // namespace
 
-static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
-                          const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, int stride, float slope,
-                          int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream) {
+// argument checks + LatArgs of one layer (kw: 1 for the M-over-waves form)
+static int lat_make_args(LatArgs& a, int& kw, const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
+                         const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, int stride, float slope,
+                         int mt, int s_out, float* out, long long out_slab_floats) {
   M4D_CHECK_ARG(x && wp && bias && out && b > 0 && h > 0 && w > 0 && (stride == 1 || stride == 2));
   M4D_CHECK_ARG(Cin >= 16 && Cin % 4 == 0 && Cout >= 1);
   const int oh = (h + stride - 1) / stride, ow = (w + stride - 1) / stride;
@@ -270,7 +388,6 @@ static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, con
   M4D_CHECK_ARG(s_out >= 1 && (s_out == 1 || out_slab_floats >= (long long)b * oh * ow * Cout));
   M4D_CHECK_ARG((mt == 1 || mt == 2 || mt == 4 || mt == 8) && (kw == 1 || kw == 2 || kw == 4));   // mt 8 = "M over waves" (kw unused)
   if (mt == 8) kw = 1;
-  LatArgs a;
   a.x = x; a.x_slab = x_slab_floats; a.s_in = s_in; a.x_bias = x_bias; a.x_slope = x_slope;
   a.wp = reinterpret_cast<const unsigned char*>(wp); a.bias = bias; a.slope = slope;
   a.out = out; a.out_slab = out_slab_floats; a.s_out = s_out;
@@ -288,6 +405,16 @@ static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, con
   // LDS: two staged rounds of kw chunks each
   const size_t lds_a = (size_t)2 * kw * ((8 * mtx - 1) * stride + 3) * ((4 * mty - 1) * stride + 3) * kLatRow * 4;
   M4D_CHECK_ARG(lds_a <= 160 * 1024);
+  return 0;
+}
+
+static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
+                          const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, int stride, float slope,
+                          int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream) {
+  LatArgs a;
+  const int rc = lat_make_args(a, kw, x, s_in, x_slab_floats, x_bias, x_slope, wp, bias, b, h, w, Cin, Cout, stride, slope, mt, s_out,
+                               out, out_slab_floats);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (stride == 1) {
     if (mt == 1) lat_launch<1, 1, 1>(a, kw, s);
@@ -300,6 +427,39 @@ static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, con
     else if (mt == 4) lat_launch<2, 2, 2>(a, kw, s);
     else lat_launch<2, 2, 2, true>(a, kw, s);
   }
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_conv3x3_lat_chain(const m4d_lat_layer* layers, int n_layers, int b, int h, int w, unsigned* ctrl,
+                                     int workgroups_per_xcd, void* stream) {
+  M4D_CHECK_ARG(layers && ctrl && n_layers >= 1 && n_layers <= kChainMaxLayers && workgroups_per_xcd >= 1 && workgroups_per_xcd <= 32);
+  LatChainArgs c;
+  c.n_layers = n_layers; c.ctrl = ctrl; c.item_begin[0] = 0;
+  size_t lds = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const m4d_lat_layer& y = layers[l];
+    int kw = y.kw;
+    const int rc = lat_make_args(c.layer[l], kw, y.x, y.s_in, y.x_slab_floats, y.x_bias, y.x_slope, y.wp, y.bias, b, h, w, y.Cin, y.Cout,
+                                 1, y.slope, 1, y.s_out, y.out, y.out_slab_floats);
+    if (rc) return rc;
+    // a layer reads what the layer before it writes (the consumer's wait covers exactly that)
+    if (l > 0) M4D_CHECK_ARG(y.x == layers[l - 1].out && y.s_in == layers[l - 1].s_out && y.Cin == layers[l - 1].Cout);
+    const int cgw = 4 / kw;
+    c.gx[l] = b * c.layer[l].tiles_x * c.layer[l].tiles_y;
+    c.gy[l] = (c.layer[l].n_groups + cgw - 1) / cgw;
+    c.item_begin[l + 1] = c.item_begin[l] + c.gx[l] * c.gy[l] * y.s_out;
+    const size_t lds_a = (size_t)2 * kw * 60 * kLatRow * 4, lds_r = (size_t)(kw - 1) * cgw * 16 * 64 * 4;
+    lds = lds_a > lds ? lds_a : lds; lds = lds_r > lds ? lds_r : lds;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {                                  // (the kernel also has 4 bytes of static LDS: not the full 160 KB)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lat_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            128 * 1024) != hipSuccess) (void)hipGetLastError();
+    attr_done = true;
+  }
+  M4D_CHECK_ARG(lds <= 128 * 1024);
+  c.lds_floats = (int)(lds / 4);
+  m4d_launch(conv3x3_lat_chain_kernel, dim3((unsigned)(8 * workgroups_per_xcd)), dim3(256), lds + 16, (hipStream_t)stream, c);
   return M4D_LAUNCH_RESULT();
 }
 

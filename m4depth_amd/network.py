@@ -160,6 +160,13 @@ lat_conv_s2_max_pixels = int(_os.environ.get("M4D_LAT_CONV_S2_PX", "0"))
 # pyramid, fp32-MFMA direct kernels of ~25 us each at batch 1) in the kernel's M-over-waves form, up to this many OUTPUT pixels
 lat_conv_mw_max_pixels = int(_os.environ.get("M4D_LAT_CONV_MW_PX", "0"))
 
+# The five wide refiner layers of a level on the latency-first kernel as ONE launch (m4d_conv3x3_lat_chain: a few resident
+# workgroups draw the separate launches' work items from a ticket counter; the same bits).  Beside another frame's level 1 every
+# dependent launch waits tens of microseconds for its first workgroup, so there a chain costs its number of launches; alone on the
+# chip the separate launches (more workgroups) are faster.  "off" = separate launches; "all" = every frame; "late" = frames whose
+# chains run beside an earlier frame's level 1 (sequence position >= 2 in the frame pipeline).
+lat_chain = _os.environ.get("M4D_LAT_CHAIN", "off")
+
 # DSCV and SNCV of a small level (<= 6000 pixels) in one launch (m4d_dscv_sncv_fwd).  0 = two launches.
 fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
 # level_pre and the per-cut normalisation of a level in one launch (m4d_level_pre_normalize).  0 = two launches.
@@ -784,10 +791,21 @@ class DepthEstimatorLevel(torch.nn.Module):
         if (fused_refiner_tail and dev.type == "cuda" and len(convs) == 7 and convs[5].weight is not None
                 and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16)):
             x = f_input
-            for ci, conv in enumerate(convs[:5]):
-                x = conv(x, slope=0.1, final=(ci == 4))                   # the fused tail reads a finished tensor
-                if debug_tap is not None:
-                    debug_tap(f"refiner_conv{ci + 1}", self.lvl_depth, x.dense() if isinstance(x, nops.PartialAct) else x)
+            chain = (lat_chain == "all" or (lat_chain == "late" and getattr(self, "sequence_position", 0) >= 2)) \
+                and debug_tap is None and not kt_on and all(cv.lat_eligible(b, h, w, ci_) and cv.stride == 1 for cv, ci_ in
+                                                            zip(convs[:5], [F_st] + [cv.out_channels for cv in convs[:4]]))
+            if chain:
+                cins = [F_st] + [cv.out_channels for cv in convs[:4]]
+                cfgs = [nops.lat_config(b, h, w, ci_, cv.out_channels, final=(i == 4)) for i, (cv, ci_) in enumerate(zip(convs[:5], cins))]
+                chain = all(cfg[0] == 1 for cfg in cfgs)
+            if chain:
+                layers = [(cv._packed_weights_lat(ci_), cv.bias, cv.out_channels, 0.1, cfg) for cv, ci_, cfg in zip(convs[:5], cins, cfgs)]
+                x, self._chain_ctrl = nops.conv3x3_lat_chain(x, layers, key=("lvl", self.lvl_depth))
+            else:
+                for ci, conv in enumerate(convs[:5]):
+                    x = conv(x, slope=0.1, final=(ci == 4))               # the fused tail reads a finished tensor
+                    if debug_tap is not None:
+                        debug_tap(f"refiner_conv{ci + 1}", self.lvl_depth, x.dense() if isinstance(x, nops.PartialAct) else x)
             split = tail_split and conv_arith == "bf16x3"
             w6p, w7p = self._tail_weights(convs, split)
             tail_fn = nops.refiner_tail6 if split else nops.refiner_tail
@@ -858,6 +876,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
                     d_est_prev = d_est_seq[-1][-l - 1]["depth"]
                 local_camera = local_cameras[lvl]
                 d_est = None if d_est_curr is None else dict(d_est_curr[-1])
+                level.sequence_position = seq_i
                 est = level(f_maps_curr, d_est, rot, trans, local_camera, sample["new_traj"],
                             prev_f_maps=f_maps_prev, prev_t_depth=d_est_prev)
                 d_est_curr = [est] if d_est_curr is None else d_est_curr + [est]
@@ -951,6 +970,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
                 if seq_i > 0 and stream_of[seq_i - 1] != stream_of[seq_i]:
                     st.wait_event(done[(seq_i - 1, lvl)])           # (same stream: ordered by the stream itself)
                 prev = None if d_est[seq_i] is None else dict(d_est[seq_i][-1])
+                self.levels[lvl].sequence_position = seq_i                 # (kernel-choice hint only: network.lat_chain)
                 est = self.levels[lvl](f_pyrs[seq_i][lvl], prev, sample['rot'], sample['trans'], local_cameras[lvl],
                                        sample["new_traj"])
                 ev = torch.cuda.Event()

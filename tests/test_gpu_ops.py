@@ -615,6 +615,35 @@ def test_latency_conv_vs_oracle(M, dev, b, h, w, cin, cout, slope):
     assert torch.equal(default, nops.conv3x3_lat(xd, wd, bd, cout, slope, final=True))     # deterministic
 
 
+@pytest.mark.parametrize("b,h,w,cin0", [(1, 6, 20, 472), (1, 12, 40, 240), (1, 24, 80, 240), (2, 7, 9, 128), (1, 3, 5, 64)])
+@pytest.mark.parametrize("wgs", [16, 2])
+def test_latency_conv_chain_launch_is_bitwise_the_separate_launches(M, dev, b, h, w, cin0, wgs, monkeypatch):
+    """m4d_conv3x3_lat_chain (round 5: the refiner layers 1-5 of a coarse level in ONE launch -- resident workgroups on one XCD draw
+    the separate launches' work items from a ticket counter, a layer's items wait for the completion counter of the layer before)
+    against the five m4d_conv3x3_lat launches it replaces: the same bits, for every level geometry, with many and with very few
+    workers (2 per XCD: every worker walks dozens of items through every layer), repeated 20 times behind warm caches (the consumer's
+    L1 holds the previous repetition's slabs: a missing acquire reads those), the control block left clean, no expired wait."""
+    from m4depth_amd import network_ops as nops
+    monkeypatch.setattr(nops, "lat_chain_workgroups", wgs)
+    rng = np.random.default_rng(cin0 + h)
+    chans = [cin0, 128, 128, 96, 64, 32]
+    ks = [(rng.standard_normal([3, 3, ci, co]) * np.sqrt(2.0 / (9 * ci))).astype(F) for ci, co in zip(chans[:-1], chans[1:])]
+    wds = [torch.from_numpy(nops.pack_conv_weights_lat(k).view(np.int16)).to(dev) for k in ks]
+    bds = [to_dev((0.1 * rng.standard_normal([co])).astype(F), dev) for co in chans[1:]]
+    cfgs = [nops.lat_config(b, h, w, ci, co, final=(i == 4)) for i, (ci, co) in enumerate(zip(chans[:-1], chans[1:]))]
+    assert all(c[0] == 1 for c in cfgs)
+    layers = [(wds[i], bds[i], chans[i + 1], 0.1, cfgs[i]) for i in range(5)]
+    for rep in range(20):
+        x = to_dev(rng.standard_normal([b, h, w, cin0]).astype(F), dev)
+        ref = x
+        for i in range(5):
+            ref = nops.conv3x3_lat(ref, wds[i], bds[i], chans[i + 1], 0.1, config=cfgs[i])
+        got, ctrl = nops.conv3x3_lat_chain(x, layers, key=("test", cin0, h))
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), f"repetition {rep}"
+        assert not npy(ctrl).view(np.uint32).any(), f"repetition {rep}: control block {npy(ctrl).view(np.uint32)[:10]}"
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout", [(2, 48, 160, 96, 96), (2, 24, 80, 128, 128), (1, 12, 40, 192, 192), (1, 96, 320, 64, 64),
                                             (1, 13, 17, 32, 40), (3, 7, 10, 100, 20), (1, 8, 9, 16, 32)])
 def test_latency_conv_stride2_vs_oracle(M, dev, b, h, w, cin, cout):
