@@ -352,6 +352,12 @@ def eager_timed_steps(model, data, timer, batch, steps, torch):
     """``steps`` eager test_steps with the kernel timer on, each queued behind a GPU-side spin (see main)."""
     timer.enabled = True
     spin_cycles = int(60e6 * max(1, batch) ** 0.5)
+    # one pass that is NOT kept: with the timer on the forward takes its single-stream, separately-launched form, whose first call
+    # allocates scratch and output buffers (a host stall of milliseconds between an event and the launch it brackets would be read
+    # as kernel time: one 58-ms "launch" among the six of a batch-32 leg, round 5)
+    model.test_step(data)
+    torch.cuda.synchronize()
+    timer.reset()
     for _ in range(steps):
         torch.cuda._sleep(spin_cycles)
         model.test_step(data)
