@@ -341,8 +341,8 @@ def kernel_rooflines(args, batch, timer, net, eager_steps):
             "note": "SURVEY 8(d) bytes of one full frame (all levels; x batch) / the summed HIP-event time of the hand-written "
                     "level kernels of that frame (level_pre + normalise, DSCV, SNCV, refiner tail) / 8 TB/s.  The tail kernel "
                     "also contains the last two refiner convolutions (32->16, 16->5), so `frac` is a lower bound for the "
-                    "path proper; frac_excluding_tail drops that kernel's time but keeps its level_post bytes.  Eager "
-                    "launches: levels <= 6000 pixels run DSCV and SNCV as two launches here, one merged launch in the graph"}
+                    "path proper; frac_excluding_tail drops that kernel's time but keeps its level_post bytes.  The "
+                    "kernels timed are the ones the graph replays (levels <= 6000 pixels: DSCV and SNCV as ONE launch, dscv_sncv)"}
     if "roofline" not in rep and "roofline_hotpath" in rep:
         rep["roofline"] = rep["roofline_hotpath"]
     return rep
