@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain, m4d_pyramid_reset(_supported); 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -311,6 +311,24 @@ int m4d_level_pre_normalize(const float* prev_l_depth, const float* prev_l_paral
                             float* f_input, int f_stride, int log_off, int other_off, float log_scale,
                             float* depth_state_reset,
                             const float* norm_x, int C, int nbre_cuts, float* norm_out, void* stream);
+
+/* The reset frame of a whole pyramid in ONE launch (m4depth_network.py:207-214 for every level of DepthEstimatorPyramid.call's
+ * loop, :305-321, on a new trajectory): per level, prev_f_maps := the per-cut normalised features, depth_prev_t := 1000, and the
+ * level's estimate -- the x2 upsampling chain of :202-204 started from the constants of :198-200, i.e. the constant maps
+ * parallax = parallax_value (the caller passes 2^(number of coarser levels)), depth = 1000, other = 0.  Bit-identical to
+ * m4d_level_pre_normalize called level by level, coarse to fine.  levels[] is read on the host during the call. */
+typedef struct m4d_reset_level {
+  const float* features;   /* [b,h,w,C] raw encoder features */
+  float* state_features;   /* [b,h,w,C] <- normalised (becomes prev_f_maps) */
+  float* depth_state;      /* [b,h,w,1] <- 1000 */
+  float* parallax;         /* [b,h,w,1] <- parallax_value */
+  float* depth;            /* [b,h,w,1] <- 1000 */
+  float* other;            /* [b,h,w,4] <- 0 */
+  int h, w, C, nbre_cuts;
+  float parallax_value;
+} m4d_reset_level;
+int m4d_pyramid_reset_supported(int C, int nbre_cuts);      /* C / nbre_cuts in {8, 16, 24, 32} */
+int m4d_pyramid_reset(const m4d_reset_level* levels, int n_levels, int b, void* stream);
 
 /* The fused level front (m4depth_network.py:179-242 in one launch, default settings: all ablation blocks on, DSCV range 4,
  * SNCV range 3): per-cut normalisation of raw_f [b,h,w,C] -> norm_out (the buffer that becomes prev_f_maps, :211/:259);

@@ -31,6 +31,14 @@ class LatLayer(ctypes.Structure):
                 ("out", ctypes.c_void_p), ("out_slab_floats", ctypes.c_longlong)]
 
 
+class ResetLevel(ctypes.Structure):
+    """m4d_reset_level of include/m4depth_hip.h (one level of m4d_pyramid_reset)."""
+    _fields_ = [("features", ctypes.c_void_p), ("state_features", ctypes.c_void_p), ("depth_state", ctypes.c_void_p),
+                ("parallax", ctypes.c_void_p), ("depth", ctypes.c_void_p), ("other", ctypes.c_void_p),
+                ("h", ctypes.c_int), ("w", ctypes.c_int), ("C", ctypes.c_int), ("nbre_cuts", ctypes.c_int),
+                ("parallax_value", ctypes.c_float)]
+
+
 # name -> argtypes; mirrors include/m4depth_hip.h one for one.
 _SIGNATURES = {
     "m4d_backproject_fwd": [_c_fp, _c_fp, ctypes.POINTER(_c_int), _c_fp, _c_fp],
@@ -111,6 +119,8 @@ _SIGNATURES = {
                                 _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_f, _c_fp,
                                 _c_fp, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_level_front_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
+    "m4d_pyramid_reset_supported": [_c_int, _c_int],
+    "m4d_pyramid_reset": [ctypes.POINTER(ResetLevel), _c_int, _c_int, _c_fp],
     "m4d_level_front": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
                         _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_f, _c_fp],
     "m4d_level_front_r": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,

@@ -186,6 +186,84 @@ level_pre_normalize_kernel(const LevelPreArgs a, int pre_gx, int pre_blocks, con
   else normalize_cuts_group_body<LPG>(nx, items, nout, blk - pre_blocks);
 }
 
+// ---- the reset frame of a whole pyramid in ONE launch ------------------------------
+// On a new trajectory every level only seeds its memories (m4depth_network.py:207-214): prev_f_maps := the per-cut normalised
+// features, depth_prev_t := 1000, and the level's estimate is the x2 upsampling of the coarser level's -- which starts from the
+// constants of :198-200 at the coarsest level, and resize_sample of a constant map is that constant exactly (tl + (tr - tl) * a),
+// so level l's estimate is the constant map (parallax 2^(levels below it), depth 1000, other 0) whatever the sizes.  Six dependent
+// launches of ~5 us each (the upsampling chain) on the critical path of a batch-1 step become one.
+constexpr int kResetMaxLevels = 8;
+struct PyramidResetArgs {
+  const float* features[kResetMaxLevels]; float* state_f[kResetMaxLevels]; float* depth_state[kResetMaxLevels];
+  float* parallax[kResetMaxLevels]; float* depth[kResetMaxLevels]; float* other[kResetMaxLevels];
+  long long pixels[kResetMaxLevels];            // b * h * w
+  long long items[kResetMaxLevels];             // b * h * w * cuts
+  int fill_blocks[kResetMaxLevels], first_block[kResetMaxLevels + 1], lpg[kResetMaxLevels];
+  float parallax_value[kResetMaxLevels];
+  int n_levels;
+};
+
+__global__ void __launch_bounds__(256)
+pyramid_reset_kernel(const PyramidResetArgs a) {
+  int l = 0;
+  while (l + 1 < a.n_levels && (int)blockIdx.x >= a.first_block[l + 1]) ++l;      // block-uniform
+  const int blk = (int)blockIdx.x - a.first_block[l];
+  if (blk < a.fill_blocks[l]) {
+    const float pv = a.parallax_value[l];
+    float* __restrict__ para = a.parallax[l]; float* __restrict__ depth = a.depth[l]; float* __restrict__ other = a.other[l];
+    float* __restrict__ dstate = a.depth_state[l];
+    for (long long p = (long long)blk * 256 + threadIdx.x; p < a.pixels[l]; p += (long long)a.fill_blocks[l] * 256) {
+      para[p] = pv; depth[p] = 1000.0f;
+      *reinterpret_cast<float4*>(other + p * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      dstate[p] = 1000.0f;
+    }
+    return;
+  }
+  const long long nb = blk - a.fill_blocks[l];
+  switch (a.lpg[l]) {
+    case 2: normalize_cuts_group_body<2>(a.features[l], a.items[l], a.state_f[l], nb); break;
+    case 4: normalize_cuts_group_body<4>(a.features[l], a.items[l], a.state_f[l], nb); break;
+    case 6: normalize_cuts_group_body<6>(a.features[l], a.items[l], a.state_f[l], nb); break;
+    default: normalize_cuts_group_body<8>(a.features[l], a.items[l], a.state_f[l], nb); break;
+  }
+}
+
+extern "C" int m4d_pyramid_reset_supported(int C, int nbre_cuts) {
+  if (C <= 0 || nbre_cuts <= 0 || C % nbre_cuts != 0) return 0;
+  const int nc = C / nbre_cuts;
+  return (nc == 8 || nc == 16 || nc == 24 || nc == 32) ? 1 : 0;
+}
+
+extern "C" int m4d_pyramid_reset(const m4d_reset_level* levels, int n_levels, int b, void* stream) {
+  M4D_CHECK_ARG(levels && n_levels > 0 && n_levels <= kResetMaxLevels && b > 0);
+  PyramidResetArgs a;
+  int blocks = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const m4d_reset_level& v = levels[l];
+    M4D_CHECK_ARG(v.features && v.state_features && v.depth_state && v.parallax && v.depth && v.other && v.h > 0 && v.w > 0);
+    M4D_CHECK_ARG(m4d_pyramid_reset_supported(v.C, v.nbre_cuts));
+    M4D_CHECK_ARG(((((uintptr_t)v.features | (uintptr_t)v.state_features | (uintptr_t)v.other)) & 15u) == 0);
+    M4D_CHECK_ARG(v.features != v.state_features);
+    a.features[l] = v.features; a.state_f[l] = v.state_features; a.depth_state[l] = v.depth_state;
+    a.parallax[l] = v.parallax; a.depth[l] = v.depth; a.other[l] = v.other; a.parallax_value[l] = v.parallax_value;
+    a.pixels[l] = (long long)b * v.h * v.w;
+    a.items[l] = a.pixels[l] * v.nbre_cuts;
+    a.lpg[l] = v.C / v.nbre_cuts / 4;
+    long long fb = (a.pixels[l] + 1023) / 1024;                                   // four pixels per thread
+    if (fb > 1024) fb = 1024;
+    a.fill_blocks[l] = (int)fb;
+    const long long gpw = 64 / a.lpg[l], waves = (a.items[l] + gpw - 1) / gpw, nblocks = (waves + 3) / 4;
+    M4D_CHECK_ARG(blocks + fb + nblocks < (1ll << 30));
+    a.first_block[l] = blocks;
+    blocks += (int)(fb + nblocks);
+  }
+  for (int l = n_levels; l <= kResetMaxLevels; ++l) a.first_block[l] = blocks;
+  for (int l = n_levels; l < kResetMaxLevels; ++l) { a.fill_blocks[l] = 0; a.lpg[l] = 8; a.items[l] = 0; a.pixels[l] = 0; }
+  a.n_levels = n_levels;
+  m4d_launch(pyramid_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return M4D_LAUNCH_RESULT();
+}
+
 // ---- fused "depth_estimator" tail (:247-260) --------------------------------------
 __global__ void __launch_bounds__(256)
 level_post_kernel(const float* __restrict__ ro, const float* __restrict__ rot, int rot_c,

@@ -211,6 +211,9 @@ pipeline_skip_implied_encoder_wait = _os.environ.get("M4D_PIPE_SKIP_ENC_WAIT", "
 # first full frame's coarse-to-fine chain then has no cross-stream wait in front of every level (round 5: each such wait is a
 # ~4.7 us gap in the executor's queue, profiles/r05_queue_trace_b1_graph.txt, on a chain that runs with the chip otherwise idle).
 pipeline_merge_reset_frame = _os.environ.get("M4D_PIPE_MERGE_RESET", "1") == "1"
+# The reset frame of all levels in ONE launch (m4d_pyramid_reset) instead of one state-seeding launch per level: the six launches
+# depend on each other only through the upsampling of constant maps, and they sit on the critical path of a batch-1 step.
+fused_pyramid_reset = _os.environ.get("M4D_FUSED_RESET", "1") == "1"
 # Encoding every frame on its own stream too (instead of one encoder pass batched over the frames, before the
 # decoder) was measured slightly slower (633 vs 643 frames/s at batch 1): the batched pass has 4x fewer launches.
 # Encoder level 0 (conv 3->16, DINL, conv 16->16 stride 2) as m4d_enc_level0_fwd: three passes that recompute the first
@@ -646,6 +649,23 @@ class DepthEstimatorLevel(torch.nn.Module):
         self.depth_prev_t = None
         self._spare_f = None
 
+    def reset_job(self, curr_f_maps):
+        """This level's buffers for the one-launch pyramid reset (``nops.pyramid_reset``), or None when its reset branch has to
+        go through ``forward`` (training, features kept raw, a cut width the group kernel does not cover)."""
+        if self.is_training or not fused_level_front or not self.ablation.normalize_features:
+            return None
+        if not isinstance(curr_f_maps, torch.Tensor) or not curr_f_maps.is_cuda or curr_f_maps.dim() != 4:
+            return None
+        b, h, w, c = curr_f_maps.shape
+        if not lib.m4d_pyramid_reset_supported(c, self.nbre_cuts):
+            return None
+        self._ensure_state((b, h, w, c), curr_f_maps.device)
+        return {"features": curr_f_maps, "cuts": self.nbre_cuts, "state_features": self._spare_f, "depth_state": self.depth_prev_t}
+
+    def reset_commit(self):
+        """After ``nops.pyramid_reset``: the normalised features ARE the new prev_f_maps (:211) -- the swap ``forward`` does."""
+        self._spare_f, self.prev_f_maps = self.prev_f_maps, self._spare_f
+
     def _tail_weights(self, convs, split=False):
         """Packed weights of the fused level tail (conv 32->16, conv 16->5), built once per device: the fp32-MFMA kernel's
         (m4d_refiner_tail) or, ``split``, the bf16-split kernel's B fragments (m4d_refiner_tail6)."""
@@ -866,6 +886,10 @@ class DepthEstimatorPyramid(torch.nn.Module):
             trans = sample['trans']
             cnter = float(n_lvls)
             d_est_curr = None
+            fused = self._reset_all_levels(f_pyr_curr, sample["new_traj"])
+            if fused is not None:
+                d_est_seq.append(fused[::-1])
+                continue
             for l in range(n_lvls):
                 lvl = n_lvls - 1 - l
                 f_maps_curr, level = f_pyr_curr[lvl], self.levels[lvl]
@@ -883,6 +907,27 @@ class DepthEstimatorPyramid(torch.nn.Module):
                 cnter -= 1.
             d_est_seq.append(d_est_curr[::-1])
         return d_est_seq
+
+    def _reset_all_levels(self, f_pyr, new_traj):
+        """A new-trajectory frame in one launch: every level's state seeded, the estimates returned coarse -> fine; None when the
+        frame is not a reset frame or a level cannot take part (then the per-level loop runs)."""
+        if not fused_pyramid_reset or self.is_training:
+            return None
+        nt = new_traj
+        if isinstance(nt, torch.Tensor):
+            nt = bool(nt.reshape(-1)[0].item())
+        elif not isinstance(nt, bool):
+            nt = bool(np.asarray(nt).reshape(-1)[0])
+        if not nt or not isinstance(f_pyr[0], torch.Tensor) or not f_pyr[0].is_cuda:
+            return None
+        order = list(range(len(self.levels) - 1, -1, -1))                             # coarse -> fine
+        jobs = [self.levels[lvl].reset_job(as_f32(f_pyr[lvl], "curr_f_maps")) for lvl in order]
+        if any(j is None for j in jobs):
+            return None
+        ests = _timed("pre", "reset", lambda: nops.pyramid_reset(jobs, jobs[0]["features"].shape[0]))
+        for lvl in order:
+            self.levels[lvl].reset_commit()
+        return ests
 
     def _forward_pipelined(self, f_maps_pyrs, traj_samples, local_cameras, n_streams, encoder=None):
         """The same loop as a wavefront over (frame, level) on ``n_streams`` HIP streams: frame t runs on
@@ -941,8 +986,11 @@ class DepthEstimatorPyramid(torch.nn.Module):
                     stream_of[f] = f + 1
             # a merged reset frame must be ISSUED before the frame it shares the stream with reaches the same level: issue the
             # whole reset frame first (it is six tiny launches)
-            merged = [f for f in range(n_fr) if stream_of[f] != f]
+            # (only the reset frame that OPENS the sequence: a later one waits on the frame before it, level by level, and keeps
+            # its place on the anti-diagonals -- still ahead of the frame it shares the stream with)
+            merged = [f for f in range(n_fr) if stream_of[f] != f and f == 0]
             order = [(f, l) for f in merged for l in range(n_lvls)] + [(f, l) for (f, l) in order if f not in merged]
+        fused_reset_frames = set()
         for seq_i, l in order:
             lvl = n_lvls - 1 - l
             sample = traj_samples[seq_i]
@@ -969,6 +1017,20 @@ class DepthEstimatorPyramid(torch.nn.Module):
                         st.wait_event(late_encoder[1])
                 if seq_i > 0 and stream_of[seq_i - 1] != stream_of[seq_i]:
                     st.wait_event(done[(seq_i - 1, lvl)])           # (same stream: ordered by the stream itself)
+                if l == 0 and seq_i == 0:
+                    # a reset frame that opens the sequence: ONE launch seeds every level (a later reset frame would have to wait
+                    # for all levels of the frame before it -- events that do not exist yet in this issue order -- and takes
+                    # the per-level path)
+                    fused = self._reset_all_levels(f_pyrs[seq_i], sample["new_traj"])
+                    if fused is not None:
+                        d_est[seq_i] = fused
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        for any_lvl in range(n_lvls):
+                            done[(seq_i, any_lvl)] = ev
+                        fused_reset_frames.add(seq_i)
+                if seq_i in fused_reset_frames:
+                    continue
                 prev = None if d_est[seq_i] is None else dict(d_est[seq_i][-1])
                 self.levels[lvl].sequence_position = seq_i                 # (kernel-choice hint only: network.lat_chain)
                 est = self.levels[lvl](f_pyrs[seq_i][lvl], prev, sample['rot'], sample['trans'], local_cameras[lvl],

@@ -86,6 +86,33 @@ def level_pre(prev_l_est, depth_prev_t, trans, camera, b, h, w, device, f_input=
     return para, depth, other, para_t
 
 
+def pyramid_reset(levels, b):
+    """The reset frame of every level in one launch (m4d_pyramid_reset).  ``levels`` = coarse -> fine list of dicts
+    ``features`` [b,h,w,C] raw, ``cuts``, ``state_features`` (receives the normalised features), ``depth_state`` [b,h,w,1].
+    Returns the per-level estimates (coarse -> fine) ``{"depth", "parallax", "other"}``: the constant maps the x2 upsampling
+    chain of m4depth_network.py:198-204 produces on a new trajectory."""
+    from ._lib import ResetLevel
+    n = len(levels)
+    arr = (ResetLevel * n)()
+    ests = []
+    pv = 1.0
+    for i, lv in enumerate(levels):
+        f = as_f32(lv["features"], "curr_f_maps")
+        bb, h, w, c = f.shape
+        if bb != b:
+            raise ValueError("pyramid_reset: batch mismatch")
+        para = torch.empty((b, h, w, 1), dtype=torch.float32, device=f.device)
+        depth = torch.empty_like(para)
+        other = torch.empty((b, h, w, 4), dtype=torch.float32, device=f.device)
+        arr[i] = ResetLevel(dptr(f, "curr_f_maps").value, dptr(lv["state_features"], "state_features").value,
+                            dptr(lv["depth_state"], "depth_state").value, dptr(para).value, dptr(depth).value, dptr(other).value,
+                            h, w, c, int(lv["cuts"]), pv)
+        ests.append({"depth": depth, "parallax": para, "other": other})
+        pv *= 2.0                                    # :203, exact
+    check(lib.m4d_pyramid_reset(arr, n, int(b), stream_ptr()), "m4d_pyramid_reset")
+    return ests
+
+
 def level_post(refiner_out, rot, trans, camera, scale, depth_state=None):
     """Fused tail of a level (m4depth_network.py:247-260): returns (parallax,
     depth, other); ``depth_state`` (optional) receives the depth as well."""

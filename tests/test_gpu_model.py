@@ -395,6 +395,51 @@ def test_frame_pipeline_is_bitwise_neutral(dev):
         net.level_pipeline_streams = old
 
 
+def test_one_launch_pyramid_reset_is_bitwise_the_per_level_reset(dev):
+    """m4d_pyramid_reset (the new-trajectory frame of every level in one launch) against the per-level reset branch
+    (m4d_level_pre_normalize level by level, m4depth_network.py:207-214): every estimate of the reset frame, every level's
+    seeded state, and the frames that follow are the same bits -- single stream, frame pipeline and hipGraph; a sequence with a
+    second reset frame in the middle takes the fused launch on the single-stream path and the per-level one in the pipeline."""
+    from m4depth_amd import network as net, _lib
+    old = (net.fused_pyramid_reset, net.level_pipeline_streams)
+    try:
+        L, H, Wd, b, T = 4, 96, 160, 2, 5
+        W = S.init_weights(L, seed=9)
+        samples, cam = S.make_sequence(b, T, H, Wd, seed=321)
+        samples[3]["new_traj"] = np.ones_like(samples[3]["new_traj"])              # a reset frame in mid-sequence
+        ds, dc = to_dev(samples, dev), to_dev(cam, dev)
+        results = {}
+        for fused in (False, True):
+            for streams in (0, 8):
+                net.fused_pyramid_reset, net.level_pipeline_streams = fused, streams
+                model = _build(dev, L, 4, 3, W)
+                n0 = _lib.lib.m4d_launch_count()
+                out = model([ds, dc])
+                launches = _lib.lib.m4d_launch_count() - n0
+                ests = [[{k: v.clone() for k, v in e.items()} for e in fr] for fr in model.last_estimates]
+                state = [(lv.prev_f_maps.clone(), lv.depth_prev_t.clone()) for lv in model.d_estimator.levels]
+                results[(fused, streams)] = (out["depth"].clone(), ests, state, launches)
+        ref = results[(False, 0)]
+        for key, got in results.items():
+            assert torch.equal(ref[0], got[0]), key
+            for fr_r, fr_g in zip(ref[1], got[1]):
+                for e_r, e_g in zip(fr_r, fr_g):
+                    for k in e_r:
+                        assert torch.equal(e_r[k], e_g[k]), (key, k)
+            for (f_r, d_r), (f_g, d_g) in zip(ref[2], got[2]):
+                assert torch.equal(f_r, f_g) and torch.equal(d_r, d_g), key
+        # the reset frame's estimates are the constants of :198-204
+        fr0 = ref[1][0]
+        for i, e in enumerate(fr0):                                                 # fine -> coarse
+            assert torch.all(e["depth"] == 1000.0) and torch.all(e["other"] == 0.0)
+            assert torch.all(e["parallax"] == 2.0 ** (L - 1 - i))
+        # launches: two reset frames x (L - 1) launches fewer on one stream, one reset frame's worth in the pipeline
+        assert results[(False, 0)][3] - results[(True, 0)][3] == 2 * (L - 1)
+        assert results[(False, 8)][3] - results[(True, 8)][3] == L - 1
+    finally:
+        net.fused_pyramid_reset, net.level_pipeline_streams = old
+
+
 @pytest.mark.parametrize("H,Wd,rd,rs,name", [(384, 1280, 4, 3, "configs[1]"), (768, 2560, 6, 6, "configs[4]")])
 def test_fullsize_configs_properties(dev, H, Wd, rd, rs, name):
     """BASELINE.json's full-size geometries, 6 levels, batch 1 (no oracle run at these sizes: size-independent
