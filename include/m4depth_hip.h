@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain, m4d_pyramid_reset(_supported); 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain, m4d_pyramid_reset(_supported), m4d_enc_level0_stats / _apply; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -484,6 +484,17 @@ int m4d_enc_level0_fwd(const float* images, int bsz, long long stride_b, long lo
                        const float* w1_hwio, const float* bias1, const float* dn_scale, const float* dn_bias,
                        float dn_slope, const float* w2_hwio, const float* bias2, float slope,
                        int b, int h, int w, float* workspace, float* out, void* stream);
+/* m4d_enc_level0_fwd as its two halves: the statistics passes (mean / var [b,16] of conv1's output per image and channel;
+ * workspace >= b * kDinlMaxBlocks * 16 floats = m4d_dinl_workspace_floats(b,16) minus the mean / var tail) and the fused
+ * normalise + stride-2 convolution pass reading them.  Per-image arithmetic: the statistics of all frames of a sequence may be
+ * taken in one call and the frames applied in several (same bits as m4d_enc_level0_fwd on any grouping). */
+int m4d_enc_level0_stats(const float* images, int bsz, long long stride_b, long long stride_t,
+                         const float* w1_hwio, const float* bias1, int b, int h, int w, float* workspace,
+                         float* mean, float* var, void* stream);
+int m4d_enc_level0_apply(const float* images, int bsz, long long stride_b, long long stride_t,
+                         const float* w1_hwio, const float* bias1, const float* mean, const float* var,
+                         const float* dn_scale, const float* dn_bias, float dn_slope, const float* w2_hwio,
+                         const float* bias2, float slope, int b, int h, int w, float* out, void* stream);
 int m4d_enc_head_fwd(const float* images, int bsz, long long stride_b, long long stride_t,
                      const float* w_hwio, const float* bias, int b, int h, int w, int C,
                      float* workspace, float* raw_out, void* stream);

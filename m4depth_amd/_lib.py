@@ -102,6 +102,10 @@ _SIGNATURES = {
     "m4d_conv3x3_wino6_bias_act_k": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_int, _c_fp],
     "m4d_enc_head_fwd": [_c_fp, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int,
                          _c_fp, _c_fp, _c_fp],
+    "m4d_enc_level0_stats": [_c_fp, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp,
+                             _c_fp],
+    "m4d_enc_level0_apply": [_c_fp, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_f, _c_fp,
+                             _c_fp, _c_f, _c_int, _c_int, _c_int, _c_fp, _c_fp],
     "m4d_enc_level0_fwd": [_c_fp, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_fp, _c_fp, _c_fp, _c_f, _c_fp, _c_fp, _c_f,
                            _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp],
     "m4d_conv3x3s2_dinl_bias_act": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_f, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int,

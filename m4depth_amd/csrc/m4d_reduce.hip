@@ -586,19 +586,19 @@ extern "C" int m4d_enc_head_fwd(const float* images, int bsz, long long stride_b
   return M4D_LAUNCH_RESULT();
 }
 
-extern "C" int m4d_enc_level0_fwd(const float* images, int bsz, long long stride_b, long long stride_t,
-                                   const float* w1_hwio, const float* bias1, const float* dn_scale, const float* dn_bias,
-                                   float dn_slope, const float* w2_hwio, const float* bias2, float slope,
-                                   int b, int h, int w, float* workspace, float* out, void* stream) {
-  M4D_CHECK_ARG(images && w1_hwio && bias1 && dn_scale && dn_bias && w2_hwio && bias2 && workspace && out);
+// The statistics passes (mean, variance of conv1's output per image and channel) and the fused pass, as separate entry points:
+// the statistics of EVERY frame of a sequence can then be taken in the first encoder batch's launches (m4d_enc_level0_stats over
+// all frames), off the later batch's dependency chain.  m4d_enc_level0_fwd = the two on one batch.
+extern "C" int m4d_enc_level0_stats(const float* images, int bsz, long long stride_b, long long stride_t,
+                                    const float* w1_hwio, const float* bias1, int b, int h, int w, float* workspace,
+                                    float* mean, float* var, void* stream) {
+  M4D_CHECK_ARG(images && w1_hwio && bias1 && workspace && mean && var);
   M4D_CHECK_ARG(b > 0 && h > 0 && w > 0 && bsz > 0 && b % bsz == 0 && stride_b >= 0 && stride_t >= 0);
   hipStream_t s = (hipStream_t)stream;
   const int C = 16, hw = h * w;
   const int tiles_x = (w + kE0TW - 1) / kE0TW, n_tiles = tiles_x * ((h + kE0TH - 1) / kE0TH);
   const int nblk = n_tiles < kDinlMaxBlocks ? n_tiles : kDinlMaxBlocks;
   float* partial = workspace;
-  float* mean = workspace + (long long)b * kDinlMaxBlocks * C;
-  float* var = mean + (long long)b * C;
   static int analytic_mean = -1;                   // M4D_ENC0_ANALYTIC_MEAN=0: the mean from a convolution pass instead
   if (analytic_mean < 0) { const char* e = getenv("M4D_ENC0_ANALYTIC_MEAN"); analytic_mean = e ? atoi(e) : 1; }
   if (analytic_mean && (h == 1 || w == 1)) analytic_mean = 0;      // (one border row / column would be excluded twice)
@@ -616,14 +616,36 @@ extern "C" int m4d_enc_level0_fwd(const float* images, int bsz, long long stride
   m4d_launch(enc0_stats_kernel<1>, dim3(nblk, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)mean, h, w, bsz,
                      stride_b, stride_t, tiles_x, n_tiles, partial);
   m4d_launch(dinl_finalize_kernel, dim3(b), dim3(256), 0, s, partial, nblk, C, hw, var);
+  return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_enc_level0_apply(const float* images, int bsz, long long stride_b, long long stride_t,
+                                    const float* w1_hwio, const float* bias1, const float* mean, const float* var,
+                                    const float* dn_scale, const float* dn_bias, float dn_slope, const float* w2_hwio,
+                                    const float* bias2, float slope, int b, int h, int w, float* out, void* stream) {
+  M4D_CHECK_ARG(images && w1_hwio && bias1 && mean && var && dn_scale && dn_bias && w2_hwio && bias2 && out);
+  M4D_CHECK_ARG(b > 0 && h > 0 && w > 0 && bsz > 0 && b % bsz == 0 && stride_b >= 0 && stride_t >= 0);
   const int oh = (h + 1) / 2, ow = (w + 1) / 2;
   const int ftx = (ow + kF0OW - 1) / kF0OW, fty = (oh + kF0OH - 1) / kF0OH;
   const int tot_y = (oh - 1) * 2 + 3 - h, tot_x = (ow - 1) * 2 + 3 - w;                 // TF 'SAME' total padding
   const int pad_y = (tot_y > 0 ? tot_y : 0) / 2, pad_x = (tot_x > 0 ? tot_x : 0) / 2;
-  m4d_launch(enc0_fused_kernel, dim3(ftx * fty, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)mean,
-                     (const float*)var, dn_scale, dn_bias, dn_slope, w2_hwio, bias2, slope, h, w, oh, ow, pad_y, pad_x, bsz, stride_b,
+  m4d_launch(enc0_fused_kernel, dim3(ftx * fty, b), dim3(256), 0, (hipStream_t)stream, images, w1_hwio, bias1, mean,
+                     var, dn_scale, dn_bias, dn_slope, w2_hwio, bias2, slope, h, w, oh, ow, pad_y, pad_x, bsz, stride_b,
                      stride_t, ftx, out);
   return M4D_LAUNCH_RESULT();
+}
+
+extern "C" int m4d_enc_level0_fwd(const float* images, int bsz, long long stride_b, long long stride_t,
+                                   const float* w1_hwio, const float* bias1, const float* dn_scale, const float* dn_bias,
+                                   float dn_slope, const float* w2_hwio, const float* bias2, float slope,
+                                   int b, int h, int w, float* workspace, float* out, void* stream) {
+  M4D_CHECK_ARG(workspace && b > 0);
+  float* mean = workspace + (long long)b * kDinlMaxBlocks * 16;
+  float* var = mean + (long long)b * 16;
+  const int rc = m4d_enc_level0_stats(images, bsz, stride_b, stride_t, w1_hwio, bias1, b, h, w, workspace, mean, var, stream);
+  if (rc != 0) return rc;
+  return m4d_enc_level0_apply(images, bsz, stride_b, stride_t, w1_hwio, bias1, mean, var, dn_scale, dn_bias, dn_slope, w2_hwio,
+                              bias2, slope, b, h, w, out, stream);
 }
 
 extern "C" long long m4d_metrics_workspace_bytes(void) { return (long long)kMetricBlocks * kMetricSums * sizeof(double); }

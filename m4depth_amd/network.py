@@ -222,6 +222,8 @@ fused_encoder_level0 = _os.environ.get("M4D_FUSED_ENC0", "1") == "1"
 pipeline_encoder_per_frame = _os.environ.get("M4D_PIPELINE_ENCODER", "0") == "1"
 # Encoder in two batches instead: frames [0, split) before the decoder, frames [split, T) on frame `split`'s stream.
 pipeline_encoder_split = int(_os.environ.get("M4D_PIPELINE_ENCODER_SPLIT", "2"))
+# With the split: level 0's DINL statistics of every frame are taken in the first batch's launches (per-image arithmetic, same bits).
+encoder_stats_up_front = _os.environ.get("M4D_ENC_STATS_UP_FRONT", "1") == "1"
 
 
 def _stack_frames(samples):
@@ -544,11 +546,23 @@ class FeaturePyramid(torch.nn.Module):
         for conv in list(self.conv_layers_s1) + list(self.conv_layers_s2):
             conv.dispatch_batch = b
 
-    def forward(self, images):
+    def _head_ok(self, images):
+        return (self.use_dinl and fused_encoder_head and images.is_cuda and images.shape[-1] == 3
+                and self.conv_layers_s1[0].out_channels == 16 and self.conv_layers_s2[0].out_channels <= 32
+                and self.conv_layers_s1[0].weight is not None)
+
+    def head_stats(self, images):
+        """DINL statistics (mean, var: [n,16]) of level 0 for all the ``images`` (a FrameStack of a whole sequence), or None
+        when level 0 does not run as ``nops.encoder_level0``.  ``forward(batch, head_stats=rows of it)`` then skips its own
+        statistics passes: the later encoder batch of a split sequence loses four dependent launches (~47 us)."""
+        if not (self._head_ok(images) and fused_encoder_level0 and self.conv_layers_s2[0].out_channels == 16):
+            return None
+        conv_s1 = self.conv_layers_s1[0]
+        return _timed("enc0_stats", 0, lambda: nops.encoder_level0_stats(images, conv_s1._hwio_device(), conv_s1.bias))
+
+    def forward(self, images, head_stats=None):
         """``images``: [b,H,W,3], or a ``network_ops.FrameStack`` (the frames of a sequence batch, encoded in one pass)."""
-        head_ok = (self.use_dinl and fused_encoder_head and images.is_cuda and images.shape[-1] == 3
-                   and self.conv_layers_s1[0].out_channels == 16 and self.conv_layers_s2[0].out_channels <= 32
-                   and self.conv_layers_s1[0].weight is not None)
+        head_ok = self._head_ok(images)
         if isinstance(images, nops.FrameStack):
             feature_maps = images if head_ok else images.dense()
         else:
@@ -563,7 +577,7 @@ class FeaturePyramid(torch.nn.Module):
                     # one call, no [b,H,W,16] intermediate: the 3 -> 16 convolution recomputed on the matrix cores per pass
                     feature_maps = _timed("enc0", 0, lambda: nops.encoder_level0(
                         feature_maps, conv_s1._hwio_device(), conv_s1.bias, dn_layer.scale, dn_layer.bias,
-                        conv_s2._hwio_device(), conv_s2.bias, 0.1))
+                        conv_s2._hwio_device(), conv_s2.bias, 0.1, stats=head_stats))
                     outputs.append(feature_maps)
                     continue
                 wp2, cpad2 = conv_s2._packed_weights()
@@ -1217,6 +1231,7 @@ class M4Depth(torch.nn.Module):
         # quarter of the launches), then hand each frame its slice.
         n_fr = len(traj_samples)
         dev = camera["f"].device
+        late_encoder_fn = self.encoder
         same_shape = all(s['RGB_im'].shape == traj_samples[0]['RGB_im'].shape for s in traj_samples)
         self.encoder.set_sequence_batch(traj_samples[0]['RGB_im'].shape[0])
         if pipeline_encoder_per_frame and self.d_estimator.pipeline_streams_for(traj_samples, dev) >= 2:
@@ -1227,7 +1242,15 @@ class M4Depth(torch.nn.Module):
             # the (launch-latency-bound) coarse levels of the first full frame instead of in front of them
             k = pipeline_encoder_split
             bsz = traj_samples[0]['RGB_im'].shape[0]
-            head = self.encoder(_stack_frames(traj_samples[:k]))
+            # the DINL statistics of ALL frames in the first batch's launches (frame-major rows): the second batch, whose
+            # duration is on the step's critical path, starts at its fused pass
+            stats = self.encoder.head_stats(_stack_frames(traj_samples)) if encoder_stats_up_front else None
+            if stats is not None:
+                head = self.encoder(_stack_frames(traj_samples[:k]), head_stats=(stats[0][:k * bsz], stats[1][:k * bsz]))
+                late_stats = (stats[0][k * bsz:], stats[1][k * bsz:])
+                late_encoder_fn = lambda images: self.encoder(images, head_stats=late_stats)
+            else:
+                head = self.encoder(_stack_frames(traj_samples[:k]))
             f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in head] for t in range(k)] + [None] * (n_fr - k)
         elif n_fr > 1 and same_shape:
             bsz = traj_samples[0]['RGB_im'].shape[0]
@@ -1235,7 +1258,7 @@ class M4Depth(torch.nn.Module):
             f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in stacked] for t in range(n_fr)]
         else:
             f_maps_pyrs = [self.encoder(sample['RGB_im']) for sample in traj_samples]
-        d_maps_pyrs = self.d_estimator(f_maps_pyrs, traj_samples, camera, training, encoder=self.encoder)
+        d_maps_pyrs = self.d_estimator(f_maps_pyrs, traj_samples, camera, training, encoder=late_encoder_fn)
         self.last_estimates = d_maps_pyrs          # per step, per level {depth, parallax, other} (fine -> coarse)
         if training:
             return d_maps_pyrs

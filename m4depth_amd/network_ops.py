@@ -616,26 +616,52 @@ def encoder_head(images, w_hwio, bias1, dn_scale, dn_bias, wp2, bias2, cout2, co
     return out
 
 
-def encoder_level0(images, w1_hwio, bias1, dn_scale, dn_bias, w2_hwio, bias2, slope=0.1):
-    """Encoder level 0 with DINL (m4depth_network.py:79-87) in one call that never writes the [b,h,w,16] map: the 3 -> 16
-    convolution is recomputed from the images on the matrix cores in each pass (sums, squared deviations, normalise +
-    stride-2 convolution).  16 -> 16 channels only (the reference's level 0).  ``images``: dense [b,h,w,3] or a ``FrameStack``."""
+def _image_batch_address(images):
+    """(pointer, bsz, stride_b, stride_t, (b, h, w, c), device) of a dense [b,h,w,3] batch or a ``FrameStack`` read in place."""
     if isinstance(images, FrameStack):
         fr = images.frames
         if not fr.is_cuda:
             raise RuntimeError("images: m4depth_amd ops run on the MI355X only; there is no CPU fallback")
-        bsz, stride_b, stride_t = fr.shape[0], fr.stride(0), fr.stride(1)
-        b, h, w, c3 = images.shape
-        img_ptr, images_dev = ctypes.c_void_p(fr.data_ptr()), fr.device
-    else:
-        images = as_f32(images, "images")
-        b, h, w, c3 = images.shape
-        bsz, stride_b, stride_t = b, h * w * c3, 0
-        img_ptr, images_dev = dptr(images, "images"), images.device
+        return ctypes.c_void_p(fr.data_ptr()), fr.shape[0], fr.stride(0), fr.stride(1), tuple(images.shape), fr.device
+    images = as_f32(images, "images")
+    b, h, w, c3 = images.shape
+    return dptr(images, "images"), b, h * w * c3, 0, (b, h, w, c3), images.device
+
+
+def encoder_level0_stats(images, w1_hwio, bias1):
+    """The DINL statistics of encoder level 0 (m4depth_network.py:44-48 on the 3 -> 16 convolution's output, which is never
+    written): (mean, var), each [b,16], per image.  ``images`` may hold MORE frames than the ``encoder_level0`` call that
+    consumes a slice of the rows: the statistics of a whole sequence ride in the first encoder batch's launches."""
+    img_ptr, bsz, stride_b, stride_t, (b, h, w, c3), dev = _image_batch_address(images)
+    if c3 != 3 or bias1.numel() != 16:
+        raise ValueError("encoder_level0_stats expects RGB images and a 3->16 convolution")
+    ws = _workspace("dinl", 4 * int(lib.m4d_dinl_workspace_floats(b, 16)), dev)
+    mean = torch.empty((b, 16), dtype=torch.float32, device=dev)
+    var = torch.empty((b, 16), dtype=torch.float32, device=dev)
+    check(lib.m4d_enc_level0_stats(img_ptr, int(bsz), int(stride_b), int(stride_t), dptr(w1_hwio, "w1_hwio"), dptr(bias1, "bias1"),
+                                   b, h, w, dptr(ws), dptr(mean), dptr(var), stream_ptr()), "m4d_enc_level0_stats")
+    return mean, var
+
+
+def encoder_level0(images, w1_hwio, bias1, dn_scale, dn_bias, w2_hwio, bias2, slope=0.1, stats=None):
+    """Encoder level 0 with DINL (m4depth_network.py:79-87) in one call that never writes the [b,h,w,16] map: the 3 -> 16
+    convolution is recomputed from the images on the matrix cores in each pass (sums, squared deviations, normalise +
+    stride-2 convolution).  16 -> 16 channels only (the reference's level 0).  ``images``: dense [b,h,w,3] or a ``FrameStack``.
+    ``stats`` = (mean, var) [b,16] of these images from ``encoder_level0_stats``: only the last pass runs."""
+    img_ptr, bsz, stride_b, stride_t, (b, h, w, c3), images_dev = _image_batch_address(images)
     if c3 != 3 or bias1.numel() != 16 or bias2.numel() != 16 or tuple(w2_hwio.shape) != (3, 3, 16, 16):
         raise ValueError("encoder_level0 expects RGB images and 3->16 / 16->16 convolutions")
-    ws = _workspace("dinl", 4 * int(lib.m4d_dinl_workspace_floats(b, 16)), images_dev)
     out = torch.empty((b, -(-h // 2), -(-w // 2), 16), dtype=torch.float32, device=images_dev)
+    if stats is not None:
+        mean, var = stats
+        if tuple(mean.shape) != (b, 16) or tuple(var.shape) != (b, 16):
+            raise ValueError(f"encoder_level0: statistics of {tuple(mean.shape)} for {b} images")
+        check(lib.m4d_enc_level0_apply(img_ptr, int(bsz), int(stride_b), int(stride_t), dptr(w1_hwio, "w1_hwio"), dptr(bias1, "bias1"),
+                                       dptr(mean, "mean"), dptr(var, "var"), dptr(dn_scale.reshape(-1), "dn_scale"),
+                                       dptr(dn_bias.reshape(-1), "dn_bias"), float(slope), dptr(w2_hwio, "w2_hwio"),
+                                       dptr(bias2, "bias2"), float(slope), b, h, w, dptr(out), stream_ptr()), "m4d_enc_level0_apply")
+        return out
+    ws = _workspace("dinl", 4 * int(lib.m4d_dinl_workspace_floats(b, 16)), images_dev)
     check(lib.m4d_enc_level0_fwd(img_ptr, int(bsz), int(stride_b), int(stride_t), dptr(w1_hwio, "w1_hwio"), dptr(bias1, "bias1"),
                                  dptr(dn_scale.reshape(-1), "dn_scale"), dptr(dn_bias.reshape(-1), "dn_bias"), float(slope),
                                  dptr(w2_hwio, "w2_hwio"), dptr(bias2, "bias2"), float(slope), b, h, w, dptr(ws), dptr(out),

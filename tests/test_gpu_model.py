@@ -395,6 +395,40 @@ def test_frame_pipeline_is_bitwise_neutral(dev):
         net.level_pipeline_streams = old
 
 
+def test_encoder_statistics_up_front_are_bitwise_neutral(dev):
+    """Level 0's DINL statistics of all frames taken in the first encoder batch's launches (m4d_enc_level0_stats over the whole
+    sequence, m4d_enc_level0_apply per batch) against each batch computing its own (m4d_enc_level0_fwd): same feature maps and
+    depth, bit for bit; and four launches fewer are not claimed -- the same kernels run, on more images at once."""
+    from m4depth_amd import network as net, network_ops as nops
+    old = net.encoder_stats_up_front
+    try:
+        L, H, Wd, b, T = 3, 64, 96, 2, 4
+        W = S.init_weights(L, seed=12)
+        samples, cam = S.make_sequence(b, T, H, Wd, seed=77)
+        ds, dc = to_dev(samples, dev), to_dev(cam, dev)
+        # frames as views of one [b,T,H,W,3] tensor (test_step's unstacking): the FrameStack path
+        seq = torch.stack([s["RGB_im"] for s in ds], dim=1).contiguous()
+        for t in range(T):
+            ds[t]["RGB_im"] = seq[:, t]
+        outs = {}
+        for flag in (False, True):
+            net.encoder_stats_up_front = flag
+            model = _build(dev, L, 4, 3, W)
+            outs[flag] = model([ds, dc])["depth"].clone()
+        assert torch.equal(outs[False], outs[True])
+        enc = model.encoder
+        stack = net._stack_frames(ds)
+        assert isinstance(stack, nops.FrameStack)
+        mean, var = enc.head_stats(stack)
+        whole = enc(stack)
+        for a, z in ((0, 2), (2, 4), (1, 2)):
+            part = enc(net._stack_frames(ds[a:z]), head_stats=(mean[a * b:z * b], var[a * b:z * b]))
+            for lw, lp in zip(whole, part):
+                assert torch.equal(lw[a * b:z * b], lp)
+    finally:
+        net.encoder_stats_up_front = old
+
+
 def test_one_launch_pyramid_reset_is_bitwise_the_per_level_reset(dev):
     """m4d_pyramid_reset (the new-trajectory frame of every level in one launch) against the per-level reset branch
     (m4d_level_pre_normalize level by level, m4depth_network.py:207-214): every estimate of the reset frame, every level's
