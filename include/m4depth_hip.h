@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain, m4d_pyramid_reset(_supported), m4d_enc_level0_stats / _apply; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain, m4d_pyramid_reset(_supported), m4d_enc_level0_stats / _apply, m4d_wino6_set_stagger; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -189,6 +189,12 @@ int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, const float* b
 long long m4d_wino6_persistent_min_units(void);
 /* Profiling only (tools/wino6_phases.py): per-position cycle stamps of the first 64 workgroups; NULL switches it off. */
 void m4d_wino6_set_stamps(unsigned long long* device_buffer);
+/* The one-workgroup-per-unit kernel starts its first 256 workgroups (one per CU) in `phases` groups (a power of two <= 32)
+ * spread over range_us microseconds on launches of at least min_workgroups workgroups at batch <= 4: identical workgroups would
+ * otherwise free every CU at the same instant once per unit time, and the small kernels of another frame's coarse levels wait
+ * for that instant (csrc/m4d_wino6.hip).  Process-wide tuning state, default (9, 16, 200) or M4D_WINO6_STAGGER_US / _PHASES /
+ * _MIN_WG; range_us = 0 switches it off; results are the same bits either way. */
+void m4d_wino6_set_stagger(int range_us, int phases, int min_workgroups);
 
 /* The tail of a level in one kernel: the last two DispRefiner convolutions (32 -> 16 + leaky_relu(0.1), 16 -> 5;
  * m4depth_network.py:109-135) and m4d_level_post (:247-260).  x32 [b,h,w,32]; w6p [9][16][32] = kernel[ky][kx][k][n] as

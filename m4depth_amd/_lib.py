@@ -149,7 +149,8 @@ _LL_SIGNATURES = {"m4d_launch_count": [], "m4d_wino6_persistent_min_units": [], 
                   "m4d_conv3x3_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]}
 _VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
                     "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp], "m4d_wino_set_stamps": [_c_fp],
-                    "m4d_front_set_stamps": [_c_fp], "m4d_wino6_set_stamps": [_c_fp]}
+                    "m4d_front_set_stamps": [_c_fp], "m4d_wino6_set_stamps": [_c_fp],
+                    "m4d_wino6_set_stagger": [_c_int, _c_int, _c_int]}
 
 EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES) + list(_VOID_SIGNATURES) + list(_LL_SIGNATURES)
 

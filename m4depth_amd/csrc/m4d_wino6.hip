@@ -53,6 +53,8 @@ struct Wino6Args {
   int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y;
   float slope;
   unsigned long long* stamps;   // profiling only (m4d_wino6_set_stamps, tools/wino6_phases.py): 64 workgroups x 1280 words
+  int phases;                   // power of two <= 32
+  int stagger;                  // > 0: the first-round workgroups start up to this many 100-MHz ticks apart (see the launcher)
 };
 
 constexpr int kT = 16, kH = kT + 2;              // output tile, halo (pixels)
@@ -101,6 +103,14 @@ conv3x3_wino6_kernel(const Wino6Args a) {
   // every kernel argument fetched by the FIRST scalar loads (hipcc issued the load of the pointers ~100 instructions later, behind
   // the tile decode's divisions: a scalar-memory round trip right in front of the first DMA of every unit)
   asm volatile("" : : "s"(a.x), "s"(a.wu), "s"(a.out), "s"(a.bias));
+  if (a.stagger > 0 && blockIdx.y == 0 && blockIdx.x < 256) {
+    // One-per-CU workgroups of identical duration run in lock step: every CU frees at the same instant, once per unit time, and a
+    // small kernel of another queue that arrives in between waits for that instant.  The first round's workgroups (the CUs of
+    // an XCD take consecutive ids / 8) start in eight phases instead.
+    const unsigned phase = (blockIdx.x >> 3) & (unsigned)(a.phases - 1);
+    const unsigned long long t_end = wall_clock64() + (unsigned long long)(phase * (unsigned)a.stagger) / (unsigned)a.phases;
+    while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16);
+  }
   float4* raw = reinterpret_cast<float4*>(lds);                      // [2][kRawSlots]
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address (for M0)
 
@@ -526,6 +536,33 @@ int g_wino6_variant = 0;                           // 0 / 1 = this file's kernel
 
 extern "C" void m4d_wino6_set_stamps(unsigned long long* device_buffer) { g_wino6_stamps = device_buffer; }
 
+// ---- staggered first round ---------------------------------------------------------------------------------------------------
+// A launch of this kernel puts ONE workgroup on every CU (154 KB of LDS) and all of them take the same time: the CUs free in
+// lock step, once per unit time (17-27 us), and a small kernel of another hipGraph branch -- a coarse-level kernel of the NEXT
+// frame, whose latency chain is on the critical path of a batch-1 step -- that becomes ready in between waits for that instant
+// (measured: ~25 us per dependent launch).  The first 256 workgroups therefore start in `phases` groups
+// spread over `range_us`: the lock step is broken for the whole launch, CUs free every range / phases us.  Costs the launch
+// ~range / 2 at most (level-1 layers +0..3 us each, tools/bench_wino6.py); results unchanged (it is a delay).
+struct Wino6Stagger { int range_us, phases, min_workgroups, max_batch; };
+static Wino6Stagger& wino6_stagger() {
+  static Wino6Stagger st = [] {
+    Wino6Stagger v{9, 16, 200, 4};
+    if (const char* e = getenv("M4D_WINO6_STAGGER_US")) v.range_us = atoi(e);
+    if (const char* e = getenv("M4D_WINO6_STAGGER_PHASES")) v.phases = atoi(e);
+    if (const char* e = getenv("M4D_WINO6_STAGGER_MIN_WG")) v.min_workgroups = atoi(e);
+    if (const char* e = getenv("M4D_WINO6_STAGGER_MAX_BATCH")) v.max_batch = atoi(e);
+    if (v.phases < 1 || v.phases > 32 || (v.phases & (v.phases - 1))) v.phases = 16;
+    return v;
+  }();
+  return st;
+}
+extern "C" void m4d_wino6_set_stagger(int range_us, int phases, int min_workgroups) {
+  Wino6Stagger& st = wino6_stagger();
+  st.range_us = range_us < 0 ? 0 : range_us;
+  if (phases >= 1 && phases <= 32 && !(phases & (phases - 1))) st.phases = phases;
+  if (min_workgroups > 0) st.min_workgroups = min_workgroups;
+}
+
 #if M4D_EXPERIMENTS
 // include/m4depth_hip_experiments.h: bit-identical alternatives, measured not faster end to end (DESIGN_HISTORY.md)
 // m4d_wino6w.hip: 16x16 pixels x all 96 / 128 output channels per workgroup, two passes over the position rows
@@ -585,6 +622,12 @@ extern "C" int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, con
   a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.n_chunks = Cin / 16; a.slope = slope;
   a.tiles_x = (w + kT - 1) / kT; a.tiles_y = (h + kT - 1) / kT;
   a.stamps = g_wino6_stamps;
+  {
+    const Wino6Stagger& st = wino6_stagger();
+    const long long wgs = (long long)b * a.tiles_x * a.tiles_y * (CoutPad / 64);
+    a.stagger = (st.range_us > 0 && wgs >= st.min_workgroups && b <= st.max_batch) ? st.range_us * 100 : 0;   // 100-MHz ticks
+    a.phases = st.phases;
+  }
   constexpr size_t lds_epi = (size_t)(4 * 4 * 2 * 32 * 36 + 32) * sizeof(float);        // epilogue staging 147 KB (+ N-tile 1's skew)
   constexpr size_t lds_loop = (size_t)kBRingOff + 4 * kBRingBytes;                      // K loop: raw halo x 2 + fragment rings (154 KB)
   constexpr size_t lds = lds_epi > lds_loop ? lds_epi : lds_loop;

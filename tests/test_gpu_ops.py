@@ -492,6 +492,29 @@ def test_persistent_winograd_is_bitwise_the_one_tile_kernel(M, dev, b, h, w, cin
     assert np.max(np.abs(npy(per[0]) - ref)) < 1e-5 * max(1.0, np.abs(ref).max())
 
 
+def test_winograd_staggered_first_round_changes_no_bit(M, dev):
+    """m4d_wino6_set_stagger: the first 256 workgroups of a launch start in phases (a delay in front of the kernel body, so that
+    the CUs do not free in lock step, csrc/m4d_wino6.hip) -- off, the default and an extreme setting give the same bits on a
+    multi-round grid (960 units), a single-round one (240) and one below the threshold."""
+    from m4depth_amd import network_ops as nops, _lib
+    rng = np.random.default_rng(5)
+    try:
+        for (h, w, cin, cout) in ((192, 640, 32, 128), (96, 320, 64, 128), (48, 160, 32, 64)):
+            x = to_dev(rng.standard_normal([1, h, w, cin]).astype(F), dev)
+            k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+            bias = to_dev((0.1 * rng.standard_normal([cout])).astype(F), dev)
+            wu6, cpad = nops.pack_conv_weights_wino6(k)
+            wud = torch.from_numpy(wu6.view("int16")).to(dev)
+            outs = []
+            for cfg in ((0, 16, 200), (9, 16, 200), (40, 32, 1), (13, 8, 200)):
+                _lib.lib.m4d_wino6_set_stagger(*cfg)
+                outs.append(nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1, kernel=1))
+            for o in outs[1:]:
+                assert torch.equal(o, outs[0])
+    finally:
+        _lib.lib.m4d_wino6_set_stagger(9, 16, 200)
+
+
 @pytest.mark.parametrize("cin,cout", [(128, 128), (32, 128), (16, 128), (128, 96)])
 def test_winograd_bf16_split_determinism_under_memory_pressure(M, dev, cin, cout):
     """Regression test of round 3's non-determinism: the level-1 refiner layer geometry at batch 32,
