@@ -5,7 +5,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 heads = [i for i, r in enumerate(rows) if "enc0_rgb_total_kernel" in r["Kernel_Name"] or "enc_head_conv_kernel" in r["Kernel_Name"]]
 # a step = two encoder batches; take the third-last complete step
-i0, i1 = heads[-7], heads[-5]
+n_fin = sum(1 for r in rows if "metrics_finalize_kernel" in r["Kernel_Name"])
+per_step = max(1, round(len(heads) / n_fin)) if n_fin else 2          # head kernels per step (1 with the statistics up front)
+i0, i1 = heads[-(3 * per_step + 1)], heads[-(2 * per_step + 1)]
 t0 = int(rows[i0]["Start_Timestamp"])
 lim = float(sys.argv[2]) if len(sys.argv) > 2 else 1000.0
 for r in rows[i0:i1]:

@@ -5,8 +5,9 @@ import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 print("columns:", [c for c in rows[0].keys()], file=sys.stderr)
-heads = [i for i, r in enumerate(rows) if "enc0_rgb_total_kernel" in r["Kernel_Name"]]
-i0, i1 = heads[-7], heads[-5]
+# a step ends with the metric pass's finalisation (one per step, launched after the graph): the window is one whole step
+ends = [i for i, r in enumerate(rows) if "metrics_finalize_kernel" in r["Kernel_Name"]]
+i0, i1 = ends[-4] + 1, ends[-3] + 1
 t0 = int(rows[i0]["Start_Timestamp"])
 qs = {}
 for r in rows[i0:i1]:

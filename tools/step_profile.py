@@ -10,7 +10,10 @@ heads = [e[0] for e in ev if "enc0_rgb_total_kernel" in e[3]] or [e[0] for e in 
 if len(heads) < 4:
     sys.exit("step_profile: no encoder-batch head kernels (enc0_rgb_total_kernel / enc_head_conv_kernel) in the trace -- nothing to profile")
 # steps = consecutive head launches with a regular spacing (the timed graph replays): keep gaps within 20 % of the median
-per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 2         # encoder batches per step (network.pipeline_encoder_split)
+# head kernels per step: 2 when each encoder batch takes its own DINL statistics, 1 with network.encoder_stats_up_front --
+# counted against the once-per-step metrics_finalize_kernel unless given
+n_fin = sum(1 for e in ev if "metrics_finalize_kernel" in e[3])
+per_step = int(sys.argv[3]) if len(sys.argv) > 3 else (max(1, round(len(heads) / n_fin)) if n_fin else 2)
 heads = heads[len(heads) % per_step::per_step][-13:]             # the last 12 steps: the timed graph replays
 gaps = [b - a for a, b in zip(heads, heads[1:])]
 med = sorted(gaps)[len(gaps) // 2]
