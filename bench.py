@@ -511,7 +511,7 @@ def main():
         else:
             n0 = int(_lib.lib.m4d_launch_count())
             runner = net.GraphedSequence(model, data, warmup=1)
-            launches_per_step = (int(_lib.lib.m4d_launch_count()) - n0) // 2          # one eager warm-up pass + the capture pass
+            launches_per_step = (int(_lib.lib.m4d_launch_count()) - n0) // (1 + runner.capture_passes)   # one eager warm-up pass + the capture pass(es)
         # the batch lives in the graph's own input buffers (inputs resident in HBM before the timed region: no hand-over copy)
         data.update({k: v for k, v in runner.input_buffers().items()})
         step = lambda: model.graphed_test_step(data, runner)
@@ -615,6 +615,14 @@ def main():
                                                   "hipGraph replay of the sequence forward; frames pipelined over the decoder "
                                                   "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)"),
     })
+    tuned = getattr(runner, "stagger_autotune_ms", None) if not args.eager else None
+    if tuned is not None:
+        out["winograd_first_round"] = {
+            "chosen": f"staggered over {runner.stagger_us} us" if runner.stagger_us else "lock step (no stagger)",
+            "ms_per_step_at_capture": {("staggered" if k else "lock_step"): v for k, v in tuned.items()},
+            "note": "GraphedSequence captures the sequence with and without the staggered first round of the one-per-CU Winograd "
+                    "kernel (m4d_wino6_set_stagger; same bits) and keeps the faster graph -- before the warm-up, outside the "
+                    "timed region: which one wins depends on the box (DESIGN.md section 6)"}
     out["config"].update({
         "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",
         "kernels": "every kernel of the captured forward is hand-written HIP (libm4depth_hip.so, gfx950): MFMA "

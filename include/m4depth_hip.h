@@ -193,7 +193,8 @@ void m4d_wino6_set_stamps(unsigned long long* device_buffer);
  * spread over range_us microseconds on launches of at least min_workgroups workgroups at batch <= 4: identical workgroups would
  * otherwise free every CU at the same instant once per unit time, and the small kernels of another frame's coarse levels wait
  * for that instant (csrc/m4d_wino6.hip).  Process-wide tuning state, default (9, 16, 200) or M4D_WINO6_STAGGER_US / _PHASES /
- * _MIN_WG; range_us = 0 switches it off; results are the same bits either way. */
+ * _MIN_WG; range_us = 0 switches it off, phases / min_workgroups <= 0 keep their value; results are the same bits either way.
+ * Whether it pays depends on the box: network.GraphedSequence captures both ways and keeps the faster. */
 void m4d_wino6_set_stagger(int range_us, int phases, int min_workgroups);
 
 /* The tail of a level in one kernel: the last two DispRefiner convolutions (32 -> 16 + leaky_relu(0.1), 16 -> 5;

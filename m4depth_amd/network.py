@@ -211,6 +211,10 @@ pipeline_skip_implied_encoder_wait = _os.environ.get("M4D_PIPE_SKIP_ENC_WAIT", "
 # first full frame's coarse-to-fine chain then has no cross-stream wait in front of every level (round 5: each such wait is a
 # ~4.7 us gap in the executor's queue, profiles/r05_queue_trace_b1_graph.txt, on a chain that runs with the chip otherwise idle).
 pipeline_merge_reset_frame = _os.environ.get("M4D_PIPE_MERGE_RESET", "1") == "1"
+# The staggered first round of the one-per-CU Winograd kernel (csrc/m4d_wino6.hip, m4d_wino6_set_stagger): range in us, and whether
+# GraphedSequence captures the sequence both ways and keeps the faster graph (the effect's sign depends on the box).
+wino6_stagger_us = int(_os.environ.get("M4D_WINO6_STAGGER_US", "9"))
+wino6_stagger_autotune = _os.environ.get("M4D_STAGGER_AUTOTUNE", "1") == "1"
 # The reset frame of all levels in ONE launch (m4d_pyramid_reset) instead of one state-seeding launch per level: the six launches
 # depend on each other only through the upsampling of constant maps, and they sit on the critical path of a batch-1 step.
 fused_pyramid_reset = _os.environ.get("M4D_FUSED_RESET", "1") == "1"
@@ -1421,10 +1425,58 @@ class GraphedSequence:
                 self._run()
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.depth = self._run()
+        self.stagger_us = None                      # what the captured Winograd launches carry (None: the library's setting)
+        self.capture_passes = 1                     # forward passes issued under capture (2 when both forms were captured)
+        batch = int(self.static["RGB_im"].shape[0])
+        if wino6_stagger_autotune and wino6_stagger_us > 0 and batch <= 4:
+            self._capture_autotuned()
+        else:
+            self.graph, self.depth = self._capture()
         self.weights_stamp = model.weights_stamp()
+
+    def _capture(self):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=self.stream):
+            out = self._run()
+        return graph, out
+
+    def _capture_autotuned(self):
+        """Two captures -- the Winograd launches with their first round staggered (m4d_wino6_set_stagger) and without -- timed
+        against each other here, the faster one kept.  Whether the stagger pays depends on the BOX: on some MI355X boxes of the
+        pool the coarse-level kernels of the next frame queue behind the lock-step rounds of a level-1 layer and the stagger is
+        worth +4.5 %; on others they do not (the same library runs 7 % faster there to begin with) and it costs 3 %
+        (DESIGN.md section 6).  The launch arguments are baked into the graph: the choice is per captured sequence."""
+        cands = []
+        self.capture_passes = 2
+        for us in (wino6_stagger_us, 0):
+            lib.m4d_wino6_set_stagger(int(us), 0, 0)
+            graph, out = self._capture()
+            cands.append([us, graph, out, []])
+        # Timed the way the graph will be used: back-to-back replays on a device that has been busy for a while.  (A few replays
+        # right after the capture, on a chip that idled through it, run in another regime -- boosted clocks, the lock-step form
+        # faster than it is in steady state -- and picked the wrong graph on every box tried.)  ~0.4 s in all; the first round
+        # of blocks only warms up.
+        reps = 24
+        with torch.cuda.stream(self.stream):
+            for rnd in range(4):                      # interleaved blocks: clocks and neighbours drift
+                for c in cands:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        c[1].replay()
+                    e1.record()
+                    e1.synchronize()
+                    if rnd > 0:
+                        c[3].append(e0.elapsed_time(e1))
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.synchronize()
+        best = min(cands, key=lambda c: min(c[3]))
+        self.stagger_us, self.graph, self.depth = best[0], best[1], best[2]
+        self.stagger_autotune_ms = {int(c[0]): round(min(c[3]) / reps, 4) for c in cands}
+        lib.m4d_wino6_set_stagger(int(self.stagger_us), 0, 0)       # eager launches from here on follow the choice
+        for c in cands:
+            if c is not best:
+                c[1].reset()                            # the loser's graph and its memory pool
 
     def _samples(self):
         nt = torch.unbind(self.new_traj, dim=1)

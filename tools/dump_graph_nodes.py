@@ -13,6 +13,7 @@ ap.add_argument("--out", required=True)
 a = ap.parse_args()
 out = os.path.abspath(a.out)
 os.environ["DEBUG_HIP_GRAPH_DOT_PRINT"] = "1"            # read by the HIP runtime when it instantiates a graph
+os.environ.setdefault("M4D_STAGGER_AUTOTUNE", "0")       # one capture (the two forms differ in a launch argument, not in nodes)
 work = tempfile.mkdtemp(prefix="m4d_dot_")
 os.chdir(work)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
