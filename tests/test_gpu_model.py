@@ -222,12 +222,16 @@ def test_test_step_semantics(dev):
     assert np.isfinite(ref) and ref > 0
 
 
-def test_graphed_sequence_matches_eager(dev):
+@pytest.mark.parametrize("keep", ["", "staggered", "lock_step"])
+def test_graphed_sequence_matches_eager(dev, keep, monkeypatch):
     """hipGraph replay of the sequence forward (the bench's launch path) against the
     eager forward of the same batch, bit for bit, and replay on a second batch copied into the
-    static buffers; a batch with another shape or new_traj pattern is refused."""
+    static buffers; a batch with another shape or new_traj pattern is refused.  GraphedSequence captures the sequence twice (the
+    Winograd first round staggered / in lock step) and keeps the faster graph: whichever it keeps (``keep`` forces one), the
+    replay, ``model.last_estimates`` and the returned depth are that graph's."""
     import m4depth_amd as M
     from m4depth_amd import network as net
+    monkeypatch.setattr(net, "wino6_stagger_force", keep)
     L, H, Wd, T, b = 3, 64, 96, 2, 2
     W = S.init_weights(L, seed=8)
     model = _build(dev, L, 4, 3, W)
@@ -253,6 +257,9 @@ def test_graphed_sequence_matches_eager(dev):
         torch.cuda.synchronize()
         assert_bits_equal(npy(model.last_estimates[-1][0]["parallax"]), ref, "graph replay vs eager")
     assert model.compiled_metrics[0].count == 3 and np.isfinite(float(res["AbsRel"]))
+    assert runner.capture_passes == 2 and runner.stagger_us == {"staggered": net.wino6_stagger_us, "lock_step": 0}.get(keep, runner.stagger_us)
+    assert torch.equal(runner(d2), model([[{k: d2[k][:, t] for k in ("RGB_im", "rot", "trans", "new_traj")} for t in range(T)],
+                                          d2["camera"]])["depth"])
     bad = dict(d1)
     bad["new_traj"] = torch.zeros_like(d1["new_traj"])
     with pytest.raises(ValueError):
