@@ -109,7 +109,7 @@ conv3x3_wino6_kernel(const Wino6Args a) {
     // an XCD take consecutive ids / 8) start in eight phases instead.
     const unsigned phase = (blockIdx.x >> 3) & (unsigned)(a.phases - 1);
     const unsigned long long t_end = wall_clock64() + (unsigned long long)(phase * (unsigned)a.stagger) / (unsigned)a.phases;
-    while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(16);
+    for (int spin = 0; spin < 512 && wall_clock64() < t_end; ++spin) __builtin_amdgcn_s_sleep(16);   // (bounded: a delay, never a hang)
   }
   float4* raw = reinterpret_cast<float4*>(lds);                      // [2][kRawSlots]
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address (for M0)
