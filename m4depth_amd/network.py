@@ -1453,30 +1453,32 @@ class GraphedSequence:
             lib.m4d_wino6_set_stagger(int(us), 0, 0)
             graph, out = self._capture()
             cands.append([us, graph, out, [], self.model.last_estimates])
-        # Timed the way the graph will be used: back-to-back replays on a device that has been busy for a while.  (A few replays
-        # right after the capture, on a chip that idled through it, run in another regime -- boosted clocks, the lock-step form
-        # faster than it is in steady state -- and picked the wrong graph on every box tried.)  ~0.4 s in all; the first round
-        # of blocks only warms up.
-        reps = 24
+        # Timed the way the graph will be used: back-to-back replays in ITS OWN steady state.  (A few replays right after the
+        # capture, on a chip that idled through it, picked the wrong graph on every box; so did interleaved blocks of 24 replays
+        # -- the lock-step form runs ~2.5 % faster for its first ~100 ms than it does afterwards, as if the synchronised load
+        # were throttled with a delay.)  Per candidate and round: `settle` untimed replays, then `reps` timed; two rounds,
+        # their sum counts; ~1 s in all at 384x1280.
+        settle, reps = 60, 40
         with torch.cuda.stream(self.stream):
-            for rnd in range(4):                      # interleaved blocks: clocks and neighbours drift
+            for rnd in range(2):
                 for c in cands:
+                    for _ in range(settle):
+                        c[1].replay()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(reps):
                         c[1].replay()
                     e1.record()
                     e1.synchronize()
-                    if rnd > 0:
-                        c[3].append(e0.elapsed_time(e1))
+                    c[3].append(e0.elapsed_time(e1))
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
-        best = min(cands, key=lambda c: min(c[3]))
+        best = min(cands, key=lambda c: sum(c[3]))
         if wino6_stagger_force in ("staggered", "lock_step"):          # tests: either graph must serve
             best = cands[0] if wino6_stagger_force == "staggered" else cands[1]
         self.stagger_us, self.graph, self.depth = best[0], best[1], best[2]
         self.model.last_estimates = best[4]            # (the per-level estimates the kept graph writes, not the last capture's)
-        self.stagger_autotune_ms = {int(c[0]): round(min(c[3]) / reps, 4) for c in cands}
+        self.stagger_autotune_ms = {int(c[0]): [round(v / reps, 4) for v in c[3]] for c in cands}
         lib.m4d_wino6_set_stagger(int(self.stagger_us), 0, 0)       # eager launches from here on follow the choice
         for c in cands:
             if c is not best:
