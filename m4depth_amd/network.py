@@ -1454,11 +1454,12 @@ class GraphedSequence:
             graph, out = self._capture()
             cands.append([us, graph, out, [], self.model.last_estimates])
         # Timed the way the graph will be used: back-to-back replays in ITS OWN steady state.  (A few replays right after the
-        # capture, on a chip that idled through it, picked the wrong graph on every box; so did interleaved blocks of 24 replays
-        # -- the lock-step form runs ~2.5 % faster for its first ~100 ms than it does afterwards, as if the synchronised load
-        # were throttled with a delay.)  Per candidate and round: `settle` untimed replays, then `reps` timed; two rounds,
-        # their sum counts; ~1 s in all at 384x1280.
-        settle, reps = 60, 40
+        # capture, on a chip that idled through it, picked the wrong graph on every box; so did interleaved blocks of 24 replays,
+        # and 60 + 40 replays per form on one box in six: the lock-step form runs ~2.5-4 % faster for its first 100-400 ms --
+        # longer after the staggered form has run -- than it does afterwards, as if the synchronised load were throttled with a
+        # delay.)  Per candidate and round: `settle` untimed replays, then `reps` timed; two rounds, the LAST one decides;
+        # ~1.4 s in all at 384x1280 (kept short: the device's rate sags ~1 % over seconds of load, and the timed region follows).
+        settle, reps = 100, 40
         with torch.cuda.stream(self.stream):
             for rnd in range(2):
                 for c in cands:
@@ -1473,7 +1474,7 @@ class GraphedSequence:
                     c[3].append(e0.elapsed_time(e1))
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
-        best = min(cands, key=lambda c: sum(c[3]))
+        best = min(cands, key=lambda c: c[3][-1])
         if wino6_stagger_force in ("staggered", "lock_step"):          # tests: either graph must serve
             best = cands[0] if wino6_stagger_force == "staggered" else cands[1]
         self.stagger_us, self.graph, self.depth = best[0], best[1], best[2]
