@@ -80,6 +80,8 @@ def parse():
                    help="graph (default) = ONE hipGraph per step, the frames pipelined on the graph's internal streams; tape = the same "
                         "(frame, level) wavefront as launch tapes of libm4depth_hip.so replayed as plain stream launches (no hipGraph; "
                         "measured 3 %% slower, kept as the graph-free launcher)")
+    p.add_argument("--repeat-regions", type=int, default=3,
+                   help="timed regions of --steps steps run back to back; the first is the line's value, all are in ms_per_step_runs")
     p.add_argument("--in-flight", type=int, default=1,
                    help="independent sequence batches in flight (each on its own stream and model state); 1 = the quoted number")
     return p.parse_args()
@@ -450,14 +452,72 @@ def timed_region(step, steps, D, dev, sync):
     return dt, per_rank_s
 
 
+def workload_name(args, world):
+    """Which BASELINE.json configuration this run IS -- decided from the whole geometry, not from (GPUs, batch) alone (round 5
+    labelled the 768x2560 ranges-6/6 line configs[1])."""
+    geo = (args.height, args.width, args.levels, args.seq_len, args.dscv_range, args.sncv_range)
+    if geo == (384, 1280, 6, 4, 4, 3):
+        if (world, args.batch) == (1, 1):
+            return "BASELINE.json configs[1]"
+        if (world, args.batch) == (1, 32):
+            return "BASELINE.json configs[2]"
+        if world > 1 and args.batch == 32:
+            return "BASELINE.json configs[3] (32 sequences per rank)"
+        return "the configs[1] geometry at a custom batch"
+    if geo[:3] == (768, 2560, 6) and geo[4] == 6 and (world, args.batch) == (1, 1):
+        return "BASELINE.json configs[4]" + ("" if geo[3] == 4 and geo[5] == 6 else " (custom seq_len / SNCV range)")
+    if geo[:3] == (128, 256, 3) and geo[4] == 2 and (world, args.batch) == (1, 1):
+        return "BASELINE.json configs[0] geometry"
+    return "custom workload"
+
+
+def run_spread(ms_runs):
+    """min / median / max of the repeated timed regions' ms per step (the first one is the line's ``ms_per_step``)."""
+    v = sorted(float(x) for x in ms_runs)
+    return {"runs": [round(float(x), 3) for x in ms_runs], "min": round(v[0], 3), "median": round(float(np.median(v)), 3),
+            "max": round(v[-1], 3), "spread_pct": round(100.0 * (v[-1] - v[0]) / v[0], 2) if v[0] > 0 else None}
+
+
+def box_kind_probe(stagger_autotune_ms, chosen_us):
+    """The capture-time timings of the lock-step and the staggered graph (GraphedSequence._capture_autotuned) as ONE record: the
+    boxes of the pool come in two kinds -- on the 'lock-step-slow' kind the unstaggered graph runs ~4.5 % slower than the staggered
+    one, on the 'lock-step-fast' kind ~3 % faster and the whole step ~7 % faster -- so a reader can tell a
+    box difference from a code change.  None when the graph was captured once."""
+    if not stagger_autotune_ms:
+        return None
+    lock = stagger_autotune_ms.get(0)
+    stag = next((v for k, v in stagger_autotune_ms.items() if k), None)
+    if not lock or not stag:
+        return None
+    ratio = lock[-1] / stag[-1]
+    return {"lock_step_ms_per_step": lock, "staggered_ms_per_step": stag, "lock_step_over_staggered": round(ratio, 4),
+            "kind": "lock-step-slow (staggered graph kept)" if ratio > 1.0 else "lock-step-fast (lock-step graph kept)",
+            "chosen_stagger_us": chosen_us}
+
+
+def timed_job(step, args, D, dev, sync, stagger_us=None):
+    """The timed part of a run, identical on every rank (every call inside is a collective or rank-local; nothing waits for
+    rank 0's report work): the contract's timed region -- ``value`` comes from THIS one --, then the same region
+    ``--repeat-regions`` - 1 more times back to back in the same process (the boxes of the pool differ by up
+    to 7 % and one 50-ms region cannot separate a 3 % change from run-to-run noise), then one small gather of every rank's
+    Winograd first-round choice (the graph a rank replays depends on ITS capture-time timing at batch <= 4; -1 = not applicable).
+    Returns (dt, per_rank_s, ms_per_step of every region, per-rank stagger us)."""
+    dt, per_rank_s = timed_region(step, args.steps, D, dev, sync)
+    ms_runs = [1e3 * dt / args.steps]
+    for _ in range(max(int(getattr(args, "repeat_regions", 1)) - 1, 0)):
+        dt_r, _ = timed_region(step, args.steps, D, dev, sync)
+        ms_runs.append(1e3 * dt_r / args.steps)
+    per_rank_stagger = D.all_gather_floats(-1.0 if stagger_us is None else float(stagger_us), dev)
+    return dt, per_rank_s, ms_runs, per_rank_stagger
+
+
 def report_head(args, world, dt, per_rank_s):
     """The contract fields of the JSON line: whole-job frames/s = frames of ALL ranks / max-over-ranks time."""
     if world != args.gpus or len(per_rank_s) != world:
         raise SystemExit(f"bench.py: world size {world} / {len(per_rank_s)} gathered ranks, but --gpus {args.gpus}")
     frames = world * args.batch * args.seq_len * args.steps
     value = frames / dt
-    cfg_name = ("BASELINE.json configs[1]" if (world, args.batch) == (1, 1) else "configs[2]" if (world, args.batch) == (1, 32)
-                else "configs[3] (32 sequences per rank)" if args.batch == 32 else "custom batch")
+    cfg_name = workload_name(args, world)
     return {
         "metric": "frames/s", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -553,7 +613,8 @@ def main():
     for mr in replicas:
         for m in mr.compiled_metrics:
             m.reset_state()
-    dt, per_rank_s = timed_region(step, args.steps, D, dev, torch.cuda.synchronize)
+    stag = getattr(runner, "stagger_us", None) if runner is not None else None
+    dt, per_rank_s, ms_runs, per_rank_stagger = timed_job(step, args, D, dev, torch.cuda.synchronize, stag)
     for mr in replicas[1:]:                                                   # fold the replicas' Keras-Mean accumulators together
         for m, m2 in zip(model.compiled_metrics, mr.compiled_metrics):
             if m2.total is not None:
@@ -584,7 +645,7 @@ def main():
     # event records while the GPU spins, so an event pair brackets the kernel's execution, not the host's launch latency
     # (without it the small kernels of the coarse levels read 3-10x too long: the GPU runs ahead of the eager host loop).
     n_eager = 0
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and rank == 0:          # (report work of rank 0 alone: the other ranks are done after the gathers)
         n_eager = eager_timed_steps(model, data, timer, args.batch, min(args.steps, 5), torch)
 
     roof1 = kernel_rooflines(args, args.batch, timer, net, n_eager) if (timer.events and rank == 0) else {}
@@ -615,14 +676,18 @@ def main():
                                                   "hipGraph replay of the sequence forward; frames pipelined over the decoder "
                                                   "levels on one HIP stream per frame (M4D_LEVEL_PIPELINE)"),
     })
+    out["ms_per_step_runs"] = run_spread(ms_runs)
+    out["per_rank_winograd_stagger_us"] = [int(v) for v in per_rank_stagger]
     tuned = getattr(runner, "stagger_autotune_ms", None) if not args.eager else None
+    probe = box_kind_probe(tuned, getattr(runner, "stagger_us", None))
+    out["box_kind_probe"] = probe
     if tuned is not None:
         out["winograd_first_round"] = {
             "chosen": f"staggered over {runner.stagger_us} us" if runner.stagger_us else "lock step (no stagger)",
             "ms_per_step_at_capture": {("staggered" if k else "lock_step"): v for k, v in tuned.items()},
             "note": "GraphedSequence captures the sequence with and without the staggered first round of the one-per-CU Winograd "
-                    "kernel (m4d_wino6_set_stagger; same bits) and keeps the faster graph -- before the warm-up, outside the "
-                    "timed region: which one wins depends on the box (DESIGN.md section 6)"}
+                    "kernel (a per-launch argument of m4d_conv3x3_wino6_bias_act_ks; same bits) and keeps the faster graph -- "
+                    "before the warm-up, outside the timed region: which one wins depends on the box (DESIGN.md section 6)"}
     out["config"].update({
         "weights": "random-init (He normal), seed 42", "frame0": "new_traj (state reset only)",
         "kernels": "every kernel of the captured forward is hand-written HIP (libm4depth_hip.so, gfx950): MFMA "
@@ -654,6 +719,8 @@ def main():
         rf["configs2_front_hbm_frac"] = (c2.get("roofline_front") or {}).get("frac")
         rf["configs2_hotpath_hbm_frac"] = (c2.get("roofline_hotpath") or {}).get("frac")
         rf["launches_per_step"] = launches_per_step
+        rf["ms_per_step_runs"] = out["ms_per_step_runs"]
+        rf["box_kind_probe"] = probe
     if not args.no_cpu_baseline and world == 1:
         cb, (W, samples, cam, ref, ref_seq) = cpu_baseline(args.height, args.width, args.levels, args.dscv_range, args.sncv_range,
                                                            seq_len=args.seq_len, keep=True)

@@ -22,7 +22,10 @@
  *     The ONLY process-wide state is the profiling / debugging hooks named
  *     m4d_*_set_* (cycle-stamp buffers, the DSCV kernel selector, ablation masks):
  *     all off by default, not meant to be flipped while another thread launches,
- *     and never touched by the product's dispatch (m4depth_amd/network.py).  The
+ *     and never touched by the product's dispatch (m4depth_amd/network.py) -- every
+ *     tuning choice of the dispatch (which Winograd kernel, its staggered first
+ *     round) is an ARGUMENT of the call (ABI 6 removed round 5's
+ *     m4d_wino6_set_stagger, the one setter the dispatch did touch).  The
  *     measured-and-not-dispatched alternative kernels and the launch tape are not
  *     in this library: `make EXPERIMENTS=1`, include/m4depth_hip_experiments.h;
  *   - return value: 0 on success, otherwise a hipError_t code (1 =
@@ -45,7 +48,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 5   /* 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain, m4d_pyramid_reset(_supported), m4d_enc_level0_stats / _apply, m4d_wino6_set_stagger; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 6   /* 6 (round 6): + m4d_conv3x3_wino6_bias_act_ks (the staggered first round as a per-launch argument), - m4d_wino6_set_stagger (process-wide state on the launch path), - m4d_conv3x3_lat_chain (measured 12.5 us per hand-over, never dispatched: deleted); 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain, m4d_pyramid_reset(_supported), m4d_enc_level0_stats / _apply, m4d_wino6_set_stagger; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -189,13 +192,17 @@ int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, const float* b
 long long m4d_wino6_persistent_min_units(void);
 /* Profiling only (tools/wino6_phases.py): per-position cycle stamps of the first 64 workgroups; NULL switches it off. */
 void m4d_wino6_set_stamps(unsigned long long* device_buffer);
-/* The one-workgroup-per-unit kernel starts its first 256 workgroups (one per CU) in `phases` groups (a power of two <= 32)
- * spread over range_us microseconds on launches of at least min_workgroups workgroups at batch <= 4: identical workgroups would
- * otherwise free every CU at the same instant once per unit time, and the small kernels of another frame's coarse levels wait
- * for that instant (csrc/m4d_wino6.hip).  Process-wide tuning state, default (9, 16, 200) or M4D_WINO6_STAGGER_US / _PHASES /
- * _MIN_WG; range_us = 0 switches it off, phases / min_workgroups <= 0 keep their value; results are the same bits either way.
- * Whether it pays depends on the box: network.GraphedSequence captures both ways and keeps the faster. */
-void m4d_wino6_set_stagger(int range_us, int phases, int min_workgroups);
+/* The same call with a STAGGERED FIRST ROUND as well (ABI 6; replaces round 5's process-wide m4d_wino6_set_stagger): with
+ * stagger_us > 0 the one-workgroup-per-unit kernel starts its first 256 workgroups (one per CU) in stagger_phases groups (a
+ * power of two <= 32) spread over stagger_us microseconds (<= 1000): identical workgroups would otherwise free every CU at the
+ * same instant once per unit time, and the small kernels of another frame's coarse levels wait for that instant
+ * (csrc/m4d_wino6.hip).  A per-launch argument like `kernel`: nothing is remembered between calls, two callers with different
+ * settings never see each other's (tests/test_gpu_ops.py::test_winograd_stagger_is_per_call).  Ignored by the persistent
+ * kernel; results are the same bits either way.  Which launches should carry it is the caller's policy (network.py: grids of
+ * >= 200 workgroups at batch <= 4; whether it pays depends on the box). */
+int m4d_conv3x3_wino6_bias_act_ks(const float* x, const void* wu6, const float* bias, int b, int h, int w,
+                                  int Cin, int Cout, int CoutPad, float slope, float* out, int kernel,
+                                  int stagger_us, int stagger_phases, void* stream);
 
 /* The tail of a level in one kernel: the last two DispRefiner convolutions (32 -> 16 + leaky_relu(0.1), 16 -> 5;
  * m4depth_network.py:109-135) and m4d_level_post (:247-260).  x32 [b,h,w,32]; w6p [9][16][32] = kernel[ky][kx][k][n] as
@@ -428,21 +435,6 @@ int m4d_conv3x3_lat(const float* x, int s_in, long long x_slab_floats, const flo
 int m4d_conv3x3s_lat(const float* x, int s_in, long long x_slab_floats, const float* x_bias, float x_slope,
                      const void* wp, const float* bias, int b, int h, int w, int Cin, int Cout, int stride, float slope,
                      int mt, int kw, int s_out, float* out, long long out_slab_floats, void* stream);
-/* A CHAIN of m4d_conv3x3_lat layers (stride 1, one M-tile per wave) in ONE launch: layer l reads what layer l - 1 writes (its
- * partial slabs or finished activation: layers[l].x == layers[l-1].out, s_in == s_out of the layer before).  A few workgroups
- * (workgroups_per_xcd, all on ONE XCD: the first to arrive picks it, 8 x workgroups_per_xcd are launched) stay resident and
- * draw the work items of the separate launches -- the same code in the same order: the SAME BITS as n_layers calls of
- * m4d_conv3x3_lat -- from one ticket counter; the items of a layer wait for the completion counter of the layer before.  What it
- * is for: beside other frames' chip-filling kernels every dependent launch waits tens of microseconds for its first workgroup, so
- * a chain there costs its number of launches (csrc/m4d_convlat.hip).  ctrl: >= 16 zero-initialised 32-bit words per chain that
- * may be in flight (the kernel leaves them zero); ctrl[3] != 0 afterwards = a bounded wait expired (results invalid). */
-typedef struct {
-  const float* x; int s_in; long long x_slab_floats; const float* x_bias; float x_slope;   /* input (as m4d_conv3x3_lat) */
-  const void* wp; const float* bias; int Cin, Cout; float slope;                         /* the layer */
-  int kw, s_out; float* out; long long out_slab_floats;                                  /* its K split and output */
-} m4d_lat_layer;
-int m4d_conv3x3_lat_chain(const m4d_lat_layer* layers, int n_layers, int b, int h, int w, unsigned* ctrl,
-                          int workgroups_per_xcd, void* stream);
 /* out = leaky_relu(bias + slab_0 + ... + slab_{s_in-1}, slope), slabs added in slab order: the finished form of a partial-sum
  * activation, for consumers that do not add the slabs themselves and for inspection.  C % 4 == 0. */
 int m4d_partial_finish(const float* x, int s_in, long long x_slab_floats, const float* bias, float slope,

@@ -17,19 +17,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_FLAVOUR = os.environ.get("M4D_LIB_FLAVOUR", "product")
 LIB_PATH = os.path.join(_HERE, "libm4depth_hip_exp.so" if LIB_FLAVOUR == "experiments" else "libm4depth_hip.so")
 
-ABI_VERSION = 5               # M4D_ABI_VERSION of include/m4depth_hip.h this binding was written for
+ABI_VERSION = 6               # M4D_ABI_VERSION of include/m4depth_hip.h this binding was written for
 
 _c_fp = ctypes.c_void_p       # device pointers travel as void*
 _c_int = ctypes.c_int
 _c_f = ctypes.c_float
-
-class LatLayer(ctypes.Structure):
-    """m4d_lat_layer of include/m4depth_hip.h (one layer of m4d_conv3x3_lat_chain)."""
-    _fields_ = [("x", ctypes.c_void_p), ("s_in", ctypes.c_int), ("x_slab_floats", ctypes.c_longlong), ("x_bias", ctypes.c_void_p),
-                ("x_slope", ctypes.c_float), ("wp", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("Cin", ctypes.c_int),
-                ("Cout", ctypes.c_int), ("slope", ctypes.c_float), ("kw", ctypes.c_int), ("s_out", ctypes.c_int),
-                ("out", ctypes.c_void_p), ("out_slab_floats", ctypes.c_longlong)]
-
 
 class ResetLevel(ctypes.Structure):
     """m4d_reset_level of include/m4depth_hip.h (one level of m4d_pyramid_reset)."""
@@ -94,12 +86,13 @@ _SIGNATURES = {
                         _c_int, _c_int, _c_int, _c_fp, ctypes.c_longlong, _c_fp],
     "m4d_conv3x3s_lat": [_c_fp, _c_int, ctypes.c_longlong, _c_fp, _c_f, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                          _c_f, _c_int, _c_int, _c_int, _c_fp, ctypes.c_longlong, _c_fp],
-    "m4d_conv3x3_lat_chain": [ctypes.POINTER(LatLayer), _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_fp],
     "m4d_partial_finish": [_c_fp, _c_int, ctypes.c_longlong, _c_fp, _c_f, ctypes.c_longlong, _c_int, _c_fp, _c_fp],
     "m4d_conv3x3_wino_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino2_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino6_bias_act": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_fp],
     "m4d_conv3x3_wino6_bias_act_k": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_int, _c_fp],
+    "m4d_conv3x3_wino6_bias_act_ks": [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_f, _c_fp, _c_int,
+                                      _c_int, _c_int, _c_fp],
     "m4d_enc_head_fwd": [_c_fp, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int,
                          _c_fp, _c_fp, _c_fp],
     "m4d_enc_level0_stats": [_c_fp, _c_int, ctypes.c_longlong, ctypes.c_longlong, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_fp, _c_fp, _c_fp,
@@ -149,8 +142,7 @@ _LL_SIGNATURES = {"m4d_launch_count": [], "m4d_wino6_persistent_min_units": [], 
                   "m4d_conv3x3_wgrad_workspace_floats": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]}
 _VOID_SIGNATURES = {"m4d_dscv_set_variant": [_c_int], "m4d_dscv_set_fallback_counter": [_c_fp],
                     "m4d_dscv_set_ablation": [_c_int], "m4d_dscv_set_stamps": [_c_fp], "m4d_wino_set_stamps": [_c_fp],
-                    "m4d_front_set_stamps": [_c_fp], "m4d_wino6_set_stamps": [_c_fp],
-                    "m4d_wino6_set_stagger": [_c_int, _c_int, _c_int]}
+                    "m4d_front_set_stamps": [_c_fp], "m4d_wino6_set_stamps": [_c_fp]}
 
 EXPORTED_SYMBOLS = ["m4d_abi_version", "m4d_build_info"] + list(_SIGNATURES) + list(_VOID_SIGNATURES) + list(_LL_SIGNATURES)
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <atomic>
 
 #define M4D_CHECK_ARG(cond) do { if (!(cond)) return (int)hipErrorInvalidValue; } while (0)
 #define M4D_LAUNCH_RESULT() ((int)hipGetLastError())
@@ -51,6 +52,40 @@ inline void m4d_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t l
   }
 #endif
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
+}
+
+// ---- the > 64 KB dynamic-LDS opt-in of a kernel: per FUNCTION and per DEVICE, from any host thread --------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device only, and a process may drive several GPUs from
+// several threads (round 5 kept `static bool attr_set` flags: one device, unsynchronised -- ADVICE r5).  `done` = one bit per
+// device ordinal; a lost race sets the attribute twice, which is harmless.  A failure is not swallowed: the launch that follows
+// fails with the same condition and the entry point returns it (M4D_LAUNCH_RESULT).
+inline void m4d_lds_opt_in_once(std::atomic<unsigned long long>& done, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+  if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess)
+    done.fetch_or(1ull << dev, std::memory_order_release);
+}
+#define M4D_LDS_OPT_IN_BYTES(bytes, ...)                                                                     \
+  do {                                                                                                       \
+    static std::atomic<unsigned long long> m4d_lds_done_{0};                                                 \
+    m4d_lds_opt_in_once(m4d_lds_done_, reinterpret_cast<const void*>(__VA_ARGS__), (int)(bytes));            \
+  } while (0)
+#define M4D_LDS_OPT_IN(...) M4D_LDS_OPT_IN_BYTES(160 * 1024, __VA_ARGS__)
+
+// compute units of the CURRENT device (cached per device ordinal; atomics: any host thread)
+inline int m4d_device_cus() {
+  static std::atomic<int> cus_of[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int c = cus_of[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    c = 256;
+    (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+    if (c <= 0) c = 256;
+    cus_of[dev].store(c, std::memory_order_relaxed);
+  }
+  return c;
 }
 
 // a compile-time integer as a value: picks the instantiation of a generic lambda (`body(m4d_int<2>{})`)

@@ -670,13 +670,7 @@ void launch_conv(const ConvArgs& a, dim3 grid, hipStream_t s) {
   constexpr bool DB = false;   // double-buffered weight stages: implemented, bit-identical, measured 2-4 % SLOWER (b=1 and b=32) -> off
   constexpr int HP = ((kTW - 1) * STRIDE + 3) * ((kTH - 1) * STRIDE + 3);
   constexpr size_t lds = (size_t)(HP * kRS + (DB ? 2 : 1) * TS * 32 * NT * kRS) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<NT, TS, STRIDE, DB, MINB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (lds > 64 * 1024) M4D_LDS_OPT_IN(&conv3x3_mfma_kernel<NT, TS, STRIDE, DB, MINB>);
   m4d_launch((conv3x3_mfma_kernel<NT, TS, STRIDE, DB, MINB>), grid, dim3(256), lds, s, a);
 }
 
@@ -724,12 +718,8 @@ static int launch_conv3x3_small(const float* x, const float* wp, const float* bi
   a.ksplit = 1; a.chunks_per_split = a.n_chunks; a.ws = nullptr;
   const int halo = ((kSW - 1) * stride + 3) * ((kSH - 1) * stride + 3);
   const size_t lds = (size_t)4 * (halo * kRS + kSB) * sizeof(float);                    // 111 / 141 KB
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (stride == 1) M4D_LDS_OPT_IN(&conv3x3_small_kernel<1>);
+  else M4D_LDS_OPT_IN(&conv3x3_small_kernel<2>);
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b);
   if (stride == 1) m4d_launch(conv3x3_small_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
   else m4d_launch(conv3x3_small_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, a);
@@ -759,12 +749,7 @@ extern "C" int m4d_conv3x3_small6_bias_act(const float* x, const void* wp6, cons
   a.tiles_x = (w + kSW - 1) / kSW; a.tiles_y = (h + kSH - 1) / kSH;
   a.ksplit = 1; a.chunks_per_split = a.n_chunks; a.ws = nullptr;
   constexpr size_t lds = (size_t)4 * (kS6A + kS6B) * sizeof(float);                     // 134 KB
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+  M4D_LDS_OPT_IN(&conv3x3_small6_kernel);
   m4d_launch(conv3x3_small6_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y), (unsigned)(CoutPad / 32), (unsigned)b), dim3(256),
                      lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
@@ -800,13 +785,7 @@ extern "C" int m4d_conv3x3s2_dinl_bias_act(const float* x_raw, const float* mean
   a.dn_mean = mean; a.dn_var = var; a.dn_scale = dn_scale; a.dn_bias = dn_bias; a.dn_slope = dn_slope;
   constexpr int HP = ((kTW - 1) * 2 + 3) * ((kTH - 1) * 2 + 3);
   constexpr size_t lds = (size_t)(HP * kRS + 9 * 32 * kRS) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<1, 9, 2, false, 2, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  if (lds > 64 * 1024) M4D_LDS_OPT_IN(&conv3x3_mfma_kernel<1, 9, 2, false, 2, true>);
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y), 1, (unsigned)b);
   m4d_launch((conv3x3_mfma_kernel<1, 9, 2, false, 2, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();

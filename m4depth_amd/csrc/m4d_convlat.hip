@@ -95,25 +95,8 @@ __device__ __forceinline__ void lat_stage(const LatArgs& a, float* lds_a, int t,
 // MW ("M over waves", MTX * MTY = 4): the four waves of a workgroup are the four M-tiles of its 16x8-pixel tile, every wave all of
 // the K slice for the workgroup's ONE cout group (kw = cgw = 1) -- for narrow short-K layers on LARGER maps (the encoder's
 // 32 -> 32 and 64 -> 64 stride-2 layers: one or two cout groups, 2-4 chunks), where the other split leaves waves idle.
-// In-launch hand-over between the layers of a chain (conv3x3_lat_chain_kernel below): thread 0 polls the producing layer's completion
-// counter (relaxed agent-scope loads, s_sleep, bounded), then ONE agent-scope acquire drops this CU's stale L1 lines, then the barrier
-// releases the workgroup to its (plain) halo loads.  Every workgroup of a chain runs on ONE XCD (one L2), see the kernel.
-__device__ __forceinline__ void lat_chain_wait(const unsigned* dep, unsigned need, unsigned* err) {
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    // (polled with a read-modify-write: it is served where the producers' adds are, never by a stale cached line)
-    while (__hip_atomic_fetch_or(const_cast<unsigned*>(dep), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 17)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never hang the GPU
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-}
-
-template <int MTX, int MTY, int STRIDE, bool MW, bool CHAIN>
-__device__ __forceinline__ void lat_body(const LatArgs& a, const int bx, const int by, const int bz, float* lds_dyn,
-                                         const unsigned* dep, unsigned dep_need, unsigned* err) {
+template <int MTX, int MTY, int STRIDE, bool MW>
+__device__ __forceinline__ void lat_body(const LatArgs& a, const int bx, const int by, const int bz, float* lds_dyn) {
   constexpr int MT = MTX * MTY, MA = MW ? 1 : MT;     // M-tiles of the workgroup's tile / accumulators per wave
   static_assert(!MW || MT == 4, "one M-tile per wave");
   constexpr int TW = 8 * MTX, TH = 4 * MTY, HW = (TW - 1) * STRIDE + 3, HP = HW * ((TH - 1) * STRIDE + 3);   // output tile, input halo
@@ -160,8 +143,7 @@ __device__ __forceinline__ void lat_body(const LatArgs& a, const int bx, const i
           for (int tp = 0; tp < 9; ++tp) bq[q][p][tp] = *reinterpret_cast<const float4*>(wc + (tp * 3 + p) * 1024);
       }
     }
-    // ---- (chain: the weights are on their way; now wait for the producing layer) the workgroup's halo of the same chunks
-    if (CHAIN && r0 == 0 && dep != nullptr) lat_chain_wait(dep, dep_need, err);
+    // ---- the workgroup's halo of the same chunks (the weights are on their way)
     const int c0 = c_begin + r0 * kw;
     const int n_st = min(2 * kw, c_end - c0);
     switch (a.s_in) {
@@ -242,101 +224,12 @@ template <int MTX, int MTY, int STRIDE, bool MW = false>
 __global__ void __launch_bounds__(256, 1)
 conv3x3_lat_kernel(const LatArgs a) {
   extern __shared__ __align__(16) float lds_dyn[];
-  lat_body<MTX, MTY, STRIDE, MW, false>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds_dyn, nullptr, 0u, nullptr);
+  lat_body<MTX, MTY, STRIDE, MW>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, lds_dyn);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// A CHAIN of those layers in ONE launch (round 5): the refiner layers 1-5 of a coarse level.  Why: beside another frame's level 1
-// (960 one-per-CU Winograd workgroups) every dependent launch of a chain waits ~25 us (up to 57) before its first workgroup runs
-// -- profiles/r05_queue_trace_b1_graph.txt: frame 3's levels 6-4 take 609 us there against 216 alone, 24 launches -- so what a
-// chain costs under contention is its NUMBER OF LAUNCHES.  Here a few workgroups stay resident for the whole chain and draw the
-// work items of the separate launches -- item = one workgroup of conv3x3_lat_kernel, same code, same summation order: the same
-// bits -- from ONE ticket counter in layer order; a layer's items wait for the completion counter of the layer before (after
-// their weight fragments are requested: the weight round trip hides behind the wait).
-//   * Progress needs no assumption about dispatch order or residency: a ticket's dependencies are tickets drawn EARLIER, by workgroups
-//     that are running; workgroups that arrive late just join.  Every spin is bounded (error word instead of a hang).
-//   * Visibility: all workers sit on ONE XCD -- the first workgroup to arrive registers its HW_REG_XCC_ID, workgroups on other XCDs
-//     exit at once -- so producer and consumer share an L2: plain stores drained by s_waitcnt vmcnt(0) (the vector L1 writes
-//     through) + a relaxed agent-scope counter add publish, one agent-scope acquire (L1 invalidate) per consuming item subscribes.
-//     No L2 write-back (buffer_wbl2 costs 38-100 us here: the L2 is full of the other frames' dirty activations, round 2).
-//   * The control block cleans itself: the LAST workgroup to leave (exit counter) zeroes it for the next launch.
-constexpr int kChainMaxLayers = 6;
-struct LatChainArgs {
-  LatArgs layer[kChainMaxLayers];
-  int n_layers;
-  int item_begin[kChainMaxLayers + 1];               // ticket range of every layer
-  int gx[kChainMaxLayers], gy[kChainMaxLayers];      // its grid (x = tiles, y = cout-group blocks; z = K slices)
-  unsigned* ctrl;                                    // [0] worker XCD + 1, [1] ticket, [2] exits, [3] error, [4 + l] items done of layer l
-  int lds_floats;                                    // the items' LDS; one more 16-byte slot behind it broadcasts the ticket
-};
-
-__global__ void __launch_bounds__(256, 1)
-conv3x3_lat_chain_kernel(const LatChainArgs c) {
-  extern __shared__ __align__(16) float lds_dyn[];
-  // (no static LDS: a static variable would sit in front of the dynamic region and misalign its 16-byte accesses)
-  volatile int& sh_word = *reinterpret_cast<volatile int*>(lds_dyn + c.lds_floats);
-  unsigned* ctrl = c.ctrl;
-  if (threadIdx.x == 0) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc = (xcc & 15u) + 1u;
-    unsigned expected = 0u;
-    const bool won = __hip_atomic_compare_exchange_strong(ctrl, &expected, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh_word = (won || expected == xcc) ? 1 : 0;
-  }
-  __syncthreads();
-  // (readfirstlane: the value is the same in every lane, and the compiler must KNOW it -- a loop whose exit test looks lane-dependent
-  //  is structurised as a divergent loop, in which the lanes that skip a thread-0-only block run ahead into the next iteration's
-  //  barrier: that was a deadlock in bring-up)
-  const bool worker = __builtin_amdgcn_readfirstlane(sh_word) != 0;
-  __syncthreads();
-  if (worker) {
-    const int total = c.item_begin[c.n_layers];
-    // ONE thread-0 block per iteration, fenced by barriers on both sides (publish the finished item + draw the next ticket): with a
-    // thread-0 block at the loop's tail AND one at its head the compiler threads the lanes that skip both into an inner loop of
-    // their own -- barriers included -- and the workgroup deadlocks (bring-up, ROCm 7.2)
-    if (threadIdx.x == 0) sh_word = (int)__hip_atomic_fetch_add(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    int item = __builtin_amdgcn_readfirstlane(sh_word);
-    __syncthreads();
-    while (item < total) {
-      int l = 0;
-      while (item >= c.item_begin[l + 1]) ++l;
-      const int idx = item - c.item_begin[l];
-      const int bx = idx % c.gx[l], r = idx / c.gx[l];
-      const int by = r % c.gy[l], bz = r / c.gy[l];
-      const unsigned* dep = l > 0 ? ctrl + 4 + (l - 1) : nullptr;
-      const unsigned need = l > 0 ? (unsigned)(c.item_begin[l] - c.item_begin[l - 1]) : 0u;
-      // (a constant layer index per call: the layer's arguments then come out of scalar registers like a separate launch's)
-      switch (l) {
-        case 0: lat_body<1, 1, 1, false, true>(c.layer[0], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
-        case 1: lat_body<1, 1, 1, false, true>(c.layer[1], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
-        case 2: lat_body<1, 1, 1, false, true>(c.layer[2], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
-        case 3: lat_body<1, 1, 1, false, true>(c.layer[3], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
-        case 4: lat_body<1, 1, 1, false, true>(c.layer[4], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
-        default: lat_body<1, 1, 1, false, true>(c.layer[5], bx, by, bz, lds_dyn, dep, need, ctrl + 3); break;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have reached the L2
-      __syncthreads();                                   // (also: the next item may overwrite the LDS)
-      if (threadIdx.x == 0) {
-        (void)__hip_atomic_fetch_add(ctrl + 4 + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh_word = (int)__hip_atomic_fetch_add(ctrl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      item = __builtin_amdgcn_readfirstlane(sh_word);
-      __syncthreads();
-    }
-  }
-  if (threadIdx.x == 0) {
-    const unsigned n = __hip_atomic_fetch_add(ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n == gridDim.x - 1) {                          // the last workgroup out: nobody reads the block any more -- clean for the next launch
-      for (int l = 0; l < c.n_layers; ++l) __hip_atomic_store(ctrl + 4 + l, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(ctrl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(ctrl + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(ctrl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
+// (Round 5's one-launch CHAIN of these layers -- resident workgroups drawing the separate launches' work items from a ticket
+// counter, m4d_conv3x3_lat_chain -- was bit-identical and 2-6x slower than the launches it replaced: ~12.5 us of hand-over per
+// item, profiles/r05_lat_chain_vs_separate.txt, DESIGN_HISTORY.md.  Never dispatched; deleted in round 6, ABI 6.)
 
 // out = leaky_relu(bias + slab_0 + slab_1 + ...), slabs added in slab order: the dense form of a partial-sum activation
 // (what every consumer of m4d_conv3x3_lat's slabs computes while staging) for consumers that cannot, and for inspection
@@ -358,21 +251,17 @@ partial_finish_kernel(const float* __restrict__ x, long long slab, int s_in, con
 }
 
 template <int MTX, int MTY, int STRIDE, bool MW = false>
-void lat_launch(const LatArgs& a, int kw_in, hipStream_t s) {
+int lat_launch(const LatArgs& a, int kw_in, hipStream_t s) {
   constexpr int HP = ((8 * MTX - 1) * STRIDE + 3) * ((4 * MTY - 1) * STRIDE + 3), MT = MTX * MTY;
   const int kw = MW ? 1 : kw_in;
   const int cgw = MW ? 1 : 4 / kw;
   const size_t lds_a = (size_t)2 * kw * HP * kLatRow * 4;
   const size_t lds_r = (size_t)(kw - 1) * cgw * MT * 16 * 64 * 4;
   const size_t lds = lds_a > lds_r ? lds_a : lds_r;
-  static bool attr_done = false;                      // per instantiation; the attribute is per function, set once per process
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lat_kernel<MTX, MTY, STRIDE, MW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  if (lds > 64 * 1024) M4D_LDS_OPT_IN(&conv3x3_lat_kernel<MTX, MTY, STRIDE, MW>);    // per function and per device (m4d_common.h)
   const dim3 grid((unsigned)(a.b * a.tiles_x * a.tiles_y), (unsigned)((a.n_groups + cgw - 1) / cgw), (unsigned)a.s_out);
   m4d_launch(conv3x3_lat_kernel<MTX, MTY, STRIDE, MW>, grid, dim3(256), lds, s, a);
+  return 0;
 }
 
 }  // namespace
@@ -416,50 +305,19 @@ static int lat_launch_any(const float* x, int s_in, long long x_slab_floats, con
                                out, out_slab_floats);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  int rl;
   if (stride == 1) {
-    if (mt == 1) lat_launch<1, 1, 1>(a, kw, s);
-    else if (mt == 2) lat_launch<1, 2, 1>(a, kw, s);
-    else if (mt == 4) lat_launch<2, 2, 1>(a, kw, s);
-    else lat_launch<2, 2, 1, true>(a, kw, s);
+    if (mt == 1) rl = lat_launch<1, 1, 1>(a, kw, s);
+    else if (mt == 2) rl = lat_launch<1, 2, 1>(a, kw, s);
+    else if (mt == 4) rl = lat_launch<2, 2, 1>(a, kw, s);
+    else rl = lat_launch<2, 2, 1, true>(a, kw, s);
   } else {
-    if (mt == 1) lat_launch<1, 1, 2>(a, kw, s);
-    else if (mt == 2) lat_launch<1, 2, 2>(a, kw, s);
-    else if (mt == 4) lat_launch<2, 2, 2>(a, kw, s);
-    else lat_launch<2, 2, 2, true>(a, kw, s);
+    if (mt == 1) rl = lat_launch<1, 1, 2>(a, kw, s);
+    else if (mt == 2) rl = lat_launch<1, 2, 2>(a, kw, s);
+    else if (mt == 4) rl = lat_launch<2, 2, 2>(a, kw, s);
+    else rl = lat_launch<2, 2, 2, true>(a, kw, s);
   }
-  return M4D_LAUNCH_RESULT();
-}
-
-extern "C" int m4d_conv3x3_lat_chain(const m4d_lat_layer* layers, int n_layers, int b, int h, int w, unsigned* ctrl,
-                                     int workgroups_per_xcd, void* stream) {
-  M4D_CHECK_ARG(layers && ctrl && n_layers >= 1 && n_layers <= kChainMaxLayers && workgroups_per_xcd >= 1 && workgroups_per_xcd <= 32);
-  LatChainArgs c;
-  c.n_layers = n_layers; c.ctrl = ctrl; c.item_begin[0] = 0;
-  size_t lds = 0;
-  for (int l = 0; l < n_layers; ++l) {
-    const m4d_lat_layer& y = layers[l];
-    int kw = y.kw;
-    const int rc = lat_make_args(c.layer[l], kw, y.x, y.s_in, y.x_slab_floats, y.x_bias, y.x_slope, y.wp, y.bias, b, h, w, y.Cin, y.Cout,
-                                 1, y.slope, 1, y.s_out, y.out, y.out_slab_floats);
-    if (rc) return rc;
-    // a layer reads what the layer before it writes (the consumer's wait covers exactly that)
-    if (l > 0) M4D_CHECK_ARG(y.x == layers[l - 1].out && y.s_in == layers[l - 1].s_out && y.Cin == layers[l - 1].Cout);
-    const int cgw = 4 / kw;
-    c.gx[l] = b * c.layer[l].tiles_x * c.layer[l].tiles_y;
-    c.gy[l] = (c.layer[l].n_groups + cgw - 1) / cgw;
-    c.item_begin[l + 1] = c.item_begin[l] + c.gx[l] * c.gy[l] * y.s_out;
-    const size_t lds_a = (size_t)2 * kw * 60 * kLatRow * 4, lds_r = (size_t)(kw - 1) * cgw * 16 * 64 * 4;
-    lds = lds_a > lds ? lds_a : lds; lds = lds_r > lds ? lds_r : lds;
-  }
-  static bool attr_done = false;
-  if (!attr_done) {                                  // (the kernel also has 4 bytes of static LDS: not the full 160 KB)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lat_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            128 * 1024) != hipSuccess) (void)hipGetLastError();
-    attr_done = true;
-  }
-  M4D_CHECK_ARG(lds <= 128 * 1024);
-  c.lds_floats = (int)(lds / 4);
-  m4d_launch(conv3x3_lat_chain_kernel, dim3((unsigned)(8 * workgroups_per_xcd)), dim3(256), lds + 16, (hipStream_t)stream, c);
+  if (rl) return rl;
   return M4D_LAUNCH_RESULT();
 }
 

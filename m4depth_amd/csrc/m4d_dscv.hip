@@ -611,23 +611,13 @@ unsigned long long* g_dscv_stamps = nullptr;         // debug hook (m4d_dscv_set
 
 template <int LP, int G, int NCP>
 void launch_tile_ncp(const DscvTileArgs& ta, int b, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dscv_tile_kernel<LP, G, NCP>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  M4D_LDS_OPT_IN(&dscv_tile_kernel<LP, G, NCP>);
   m4d_launch((dscv_tile_kernel<LP, G, NCP>), dim3(ta.tiles, b), dim3(256), kDscvLdsBudget, s, ta);
 }
 
 template <int NC, int K, int NCP, int HPL>
 void launch_hyp_ncp(const DscvTileArgs& ta, int b, size_t lds, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dscv_hyp_kernel<NC, K, NCP, HPL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  M4D_LDS_OPT_IN(&dscv_hyp_kernel<NC, K, NCP, HPL>);
   m4d_launch((dscv_hyp_kernel<NC, K, NCP, HPL>), dim3(ta.tiles, b), dim3(256), lds, s, ta);
 }
 

@@ -405,12 +405,7 @@ int launch_front_acc(const FrontArgs& a0, hipStream_t s) {
   a.tiles_y = (a.h + TH - 1) / TH;
   const long long total = (long long)a.tiles_x * a.tiles_y * a.b;
   if (total > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&level_front_kernel<NC, K, TW, TH, YS, SEQ16, RD, RS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  M4D_LDS_OPT_IN(&level_front_kernel<NC, K, TW, TH, YS, SEQ16, RD, RS>);
   m4d_launch((level_front_kernel<NC, K, TW, TH, YS, SEQ16, RD, RS>), dim3((unsigned)total), dim3(Gm::NT), lds, s, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -294,12 +294,7 @@ bool launch_sncv7_ys(const float* c, int b, int h, int w, float* out, int out_st
   long long nwg = 256LL * (per_cu > 0 ? per_cu : 1);                // persistent: one resident wave of workgroups
   if (nwg > total) nwg = (total + 7) / 8 * 8;
   if (nwg < 8) nwg = 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sncv7_kernel<NC, K, TW, TH, YS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  M4D_LDS_OPT_IN(&sncv7_kernel<NC, K, TW, TH, YS>);
   m4d_launch((sncv7_kernel<NC, K, TW, TH, YS>), dim3((int)nwg), dim3(256 * YS), lds, s, c, b, h, w, out, out_stride,
                      tiles_x, tiles_y, 0);
   return true;
@@ -362,12 +357,7 @@ void launch_small(const SncvArgs& a, int b, hipStream_t s) {
 template <int NC, int MO>
 void launch_lds_mo(const SncvArgs& a, int b, size_t lds, hipStream_t s) {
   const int tiles = a.tiles_x * ((a.h + a.th - 1) / a.th);
-  static bool attr_set = false;     // raising the dynamic-LDS cap is idempotent; set once per instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sncv_lds_kernel<NC, MO>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  M4D_LDS_OPT_IN(&sncv_lds_kernel<NC, MO>);
   m4d_launch((sncv_lds_kernel<NC, MO>), dim3(tiles, b), dim3(256), lds, s, a);
 }
 

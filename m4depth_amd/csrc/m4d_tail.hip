@@ -182,12 +182,7 @@ extern "C" int m4d_refiner_tail(const float* x32, const float* w6p, const float*
   a.tiles_x = (w + kTW - 1) / kTW;
   const int tiles = a.tiles_x * ((h + kTH - 1) / kTH);
   constexpr size_t lds = (size_t)(kXP * kXS + kMP * kMS + kW6 + kW7) * sizeof(float);          // 75.5 KB
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&refiner_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+  M4D_LDS_OPT_IN(&refiner_tail_kernel);
   m4d_launch(refiner_tail_kernel, dim3(tiles, b), dim3(256), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

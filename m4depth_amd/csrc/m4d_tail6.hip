@@ -251,13 +251,8 @@ extern "C" int m4d_refiner_tail6(const float* x32, const void* w6f, const float*
   const long long items = (long long)a.tiles_per_image * b;
   M4D_CHECK_ARG(items < (1ll << 31));
   a.items = (int)items;
-  static const int max_wg = [] {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&refiner_tail6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    return 2 * cus;
-  }();
+  M4D_LDS_OPT_IN_BYTES(kLds, &refiner_tail6_kernel);
+  const int max_wg = 2 * m4d_device_cus();
   m4d_launch(refiner_tail6_kernel, dim3((unsigned)(items < max_wg ? items : max_wg)), dim3(256), (size_t)kLds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -444,12 +444,7 @@ extern "C" int m4d_conv3x3_wgrad(const float* x, const float* g, int b, int h, i
   const dim3 grid(a.mblk * a.nblk, a.slices);
 #define M4D_WGRAD_LAUNCH(S, G, X)                                                                                          \
   do {                                                                                                                     \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<S, G, X>),                            \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
-      attr_set = true;                                                                                                     \
-    }                                                                                                                      \
+    M4D_LDS_OPT_IN(&conv3x3_wgrad_kernel<S, G, X>);                                                                        \
     m4d_launch((conv3x3_wgrad_kernel<S, G, X>), grid, dim3(256), lds, s, a);                                      \
   } while (0)
   if (stride == 1) {

@@ -838,12 +838,7 @@ extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, cons
   a.tiles_x = (w + kT2 - 1) / kT2; a.tiles_y = (h + kT2 - 1) / kT2;
   a.ablate = 0; a.stamps = g_wino_stamps;
   constexpr size_t lds = (size_t)(kHP2 * kRS2 + 16 * kNT64 * kRS2) * sizeof(float);     // 15.2 + 48 KB
-  static bool attr_set = false;                    // more than 64 KB of dynamic LDS needs the opt-in
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr_set = true;
-  }
+  M4D_LDS_OPT_IN(&conv3x3_wino2_kernel);           // more than 64 KB of dynamic LDS needs the opt-in
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 32)), (unsigned)b);
   // Kernel 4 (512 threads, 64 couts, one workgroup per CU) where its grid still fills the chip and the K loop is long
   // enough to pay for its prologue (tools/bench_wino_variants.py: 3-13 % faster from 240 workgroups up; in isolation slower at 120 and
@@ -856,14 +851,8 @@ extern "C" int m4d_conv3x3_wino2_bias_act(const float* x, const float* wu8, cons
   if (variant == 4 && CoutPad % 64 == 0 && Cin >= 32 && Cin % 8 == 0 && (long long)a.tiles_x * a.tiles_y * (CoutPad / 64) * b >= min_wg4) {
     constexpr size_t lds4 = (size_t)(4 * 4 * 2 * 32 * 36) * sizeof(float);              // epilogue staging 147 KB (K loop: 126 KB)
     static_assert(lds4 >= (size_t)(2 * kRawF + 2 * kVF) * sizeof(float), "epilogue staging must cover the K-loop buffers");
-    static bool attr4_set = false;
-    if (!attr4_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-      attr4_set = true;
-    }
+    if (a.stamps) M4D_LDS_OPT_IN(&conv3x3_wino4_kernel<true>);
+    else M4D_LDS_OPT_IN(&conv3x3_wino4_kernel<false>);
     const dim3 grid4((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
     if (a.stamps) m4d_launch(conv3x3_wino4_kernel<true>, grid4, dim3(512), lds4, (hipStream_t)stream, a);
     else m4d_launch(conv3x3_wino4_kernel<false>, grid4, dim3(512), lds4, (hipStream_t)stream, a);

@@ -540,28 +540,11 @@ extern "C" void m4d_wino6_set_stamps(unsigned long long* device_buffer) { g_wino
 // A launch of this kernel puts ONE workgroup on every CU (154 KB of LDS) and all of them take the same time: the CUs free in
 // lock step, once per unit time (17-27 us), and a small kernel of another hipGraph branch -- a coarse-level kernel of the NEXT
 // frame, whose latency chain is on the critical path of a batch-1 step -- that becomes ready in between waits for that instant
-// (measured: ~25 us per dependent launch).  The first 256 workgroups therefore start in `phases` groups
-// spread over `range_us`: the lock step is broken for the whole launch, CUs free every range / phases us.  Costs the launch
-// ~range / 2 at most (level-1 layers +0..3 us each, tools/bench_wino6.py); results unchanged (it is a delay).
-struct Wino6Stagger { int range_us, phases, min_workgroups, max_batch; };
-static Wino6Stagger& wino6_stagger() {
-  static Wino6Stagger st = [] {
-    Wino6Stagger v{9, 16, 200, 4};
-    if (const char* e = getenv("M4D_WINO6_STAGGER_US")) v.range_us = atoi(e);
-    if (const char* e = getenv("M4D_WINO6_STAGGER_PHASES")) v.phases = atoi(e);
-    if (const char* e = getenv("M4D_WINO6_STAGGER_MIN_WG")) v.min_workgroups = atoi(e);
-    if (const char* e = getenv("M4D_WINO6_STAGGER_MAX_BATCH")) v.max_batch = atoi(e);
-    if (v.phases < 1 || v.phases > 32 || (v.phases & (v.phases - 1))) v.phases = 16;
-    return v;
-  }();
-  return st;
-}
-extern "C" void m4d_wino6_set_stagger(int range_us, int phases, int min_workgroups) {
-  Wino6Stagger& st = wino6_stagger();
-  st.range_us = range_us < 0 ? 0 : range_us;
-  if (phases >= 1 && phases <= 32 && !(phases & (phases - 1))) st.phases = phases;
-  if (min_workgroups > 0) st.min_workgroups = min_workgroups;
-}
+// (measured: ~25 us per dependent launch).  With stagger_us > 0 (an ARGUMENT of
+// m4d_conv3x3_wino6_bias_act_ks since ABI 6 -- round 5's process-wide setter is gone) the first 256 workgroups start in
+// `stagger_phases` groups spread over `stagger_us`: the lock step is broken for the whole launch, CUs free every range / phases
+// us.  Costs the launch ~range / 2 at most (level-1 layers +0..3 us each, tools/bench_wino6.py); results unchanged (a delay).
+// Which launches carry it is the caller's policy (network.py: grids of >= 200 workgroups at batch <= 4).
 
 #if M4D_EXPERIMENTS
 // include/m4depth_hip_experiments.h: bit-identical alternatives, measured not faster end to end (DESIGN_HISTORY.md)
@@ -592,11 +575,19 @@ extern "C" int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const
 
 extern "C" int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                             int Cin, int Cout, int CoutPad, float slope, float* out, int kernel, void* stream) {
+  return m4d_conv3x3_wino6_bias_act_ks(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, kernel, 0, 0, stream);
+}
+
+extern "C" int m4d_conv3x3_wino6_bias_act_ks(const float* x, const void* wu6, const float* bias, int b, int h, int w,
+                                             int Cin, int Cout, int CoutPad, float slope, float* out, int kernel,
+                                             int stagger_us, int stagger_phases, void* stream) {
   M4D_CHECK_ARG(x && wu6 && bias && out && b > 0 && h > 0 && w > 0 && Cin >= 16 && Cout > 0);
   M4D_CHECK_ARG(CoutPad % 64 == 0 && CoutPad >= Cout && Cin % 16 == 0);
   M4D_CHECK_ARG(((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu6) & 15u) == 0));
   M4D_CHECK_ARG((long long)h * w * Cin * 4 < (1ll << 31));                              // one image = one buffer descriptor
   M4D_CHECK_ARG(kernel >= 0 && kernel <= 2 && (kernel != 2 || Cin >= 32));
+  M4D_CHECK_ARG(stagger_us >= 0 && stagger_us <= 1000);
+  M4D_CHECK_ARG(stagger_us == 0 || (stagger_phases >= 1 && stagger_phases <= 32 && !(stagger_phases & (stagger_phases - 1))));
   {
     // kernel 0 = by grid size: the persistent kernel (m4d_wino6p.hip) on grids of many units per CU -- there it saves the
     // per-unit prologue, fetches a tile's halo once for its cout groups and stores 256-byte runs; smaller grids keep this
@@ -622,24 +613,16 @@ extern "C" int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, con
   a.b = b; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout; a.CoutPad = CoutPad; a.n_chunks = Cin / 16; a.slope = slope;
   a.tiles_x = (w + kT - 1) / kT; a.tiles_y = (h + kT - 1) / kT;
   a.stamps = g_wino6_stamps;
-  {
-    const Wino6Stagger& st = wino6_stagger();
-    const long long wgs = (long long)b * a.tiles_x * a.tiles_y * (CoutPad / 64);
-    a.stagger = (st.range_us > 0 && wgs >= st.min_workgroups && b <= st.max_batch) ? st.range_us * 100 : 0;   // 100-MHz ticks
-    a.phases = st.phases;
-  }
+  a.stagger = stagger_us * 100;                    // 100-MHz ticks (wall_clock64); the one-workgroup-per-unit kernel only
+  a.phases = stagger_us > 0 ? stagger_phases : 1;
   constexpr size_t lds_epi = (size_t)(4 * 4 * 2 * 32 * 36 + 32) * sizeof(float);        // epilogue staging 147 KB (+ N-tile 1's skew)
   constexpr size_t lds_loop = (size_t)kBRingOff + 4 * kBRingBytes;                      // K loop: raw halo x 2 + fragment rings (154 KB)
   constexpr size_t lds = lds_epi > lds_loop ? lds_epi : lds_loop;
   static_assert(lds <= 160 * 1024, "LDS budget of one CU");
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * (CoutPad / 64)), (unsigned)b);
   // more than 64 KB of dynamic LDS needs the opt-in, per kernel
-  static const bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return true;
-  }();                                             // function-local static: initialised once, thread-safe (C++11)
-  (void)attr_set;
+  if (a.stamps) M4D_LDS_OPT_IN(&conv3x3_wino6_kernel<true>);
+  else M4D_LDS_OPT_IN(&conv3x3_wino6_kernel<false>);
   if (a.stamps) m4d_launch(conv3x3_wino6_kernel<true>, grid, dim3(512), lds, (hipStream_t)stream, a);
   else m4d_launch(conv3x3_wino6_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();

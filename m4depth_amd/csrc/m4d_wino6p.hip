@@ -530,17 +530,8 @@ int m4d_wino6p_launch(const float* x, const void* wu6, const float* bias, int b,
   M4D_CHECK_ARG(units < (1ll << 31));
   a.units = (int)units;
   // CU count and the > 64 KB dynamic-LDS opt-in per DEVICE (a process may drive several GPUs)
-  static int cu_of_device[64] = {0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) dev = 0;
-  if (cu_of_device[dev] == 0) {
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino6p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    cu_of_device[dev] = cus > 0 ? cus : 256;
-  }
-  const int n_cu = cu_of_device[dev];
+  M4D_LDS_OPT_IN(&conv3x3_wino6p_kernel);
+  const int n_cu = m4d_device_cus();
   // One workgroup per CU at most (154 KB of LDS each).  Large grids: team mode on every CU (see the kernel).  Smaller ones: no
   // more workgroups than the longest range needs -- 960 units on 256 CUs are 4 per workgroup whichever way, so 240 workgroups
   // do it and 16 CUs stay free for the other frames' small kernels.

@@ -160,13 +160,6 @@ lat_conv_s2_max_pixels = int(_os.environ.get("M4D_LAT_CONV_S2_PX", "0"))
 # pyramid, fp32-MFMA direct kernels of ~25 us each at batch 1) in the kernel's M-over-waves form, up to this many OUTPUT pixels
 lat_conv_mw_max_pixels = int(_os.environ.get("M4D_LAT_CONV_MW_PX", "0"))
 
-# The five wide refiner layers of a level on the latency-first kernel as ONE launch (m4d_conv3x3_lat_chain: a few resident
-# workgroups draw the separate launches' work items from a ticket counter; the same bits).  Beside another frame's level 1 every
-# dependent launch waits tens of microseconds for its first workgroup, so there a chain costs its number of launches; alone on the
-# chip the separate launches (more workgroups) are faster.  "off" = separate launches; "all" = every frame; "late" = frames whose
-# chains run beside an earlier frame's level 1 (sequence position >= 2 in the frame pipeline).
-lat_chain = _os.environ.get("M4D_LAT_CHAIN", "off")
-
 # DSCV and SNCV of a small level (<= 6000 pixels) in one launch (m4d_dscv_sncv_fwd).  0 = two launches.
 fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
 # level_pre and the per-cut normalisation of a level in one launch (m4d_level_pre_normalize).  0 = two launches.
@@ -211,9 +204,16 @@ pipeline_skip_implied_encoder_wait = _os.environ.get("M4D_PIPE_SKIP_ENC_WAIT", "
 # first full frame's coarse-to-fine chain then has no cross-stream wait in front of every level (round 5: each such wait is a
 # ~4.7 us gap in the executor's queue, profiles/r05_queue_trace_b1_graph.txt, on a chain that runs with the chip otherwise idle).
 pipeline_merge_reset_frame = _os.environ.get("M4D_PIPE_MERGE_RESET", "1") == "1"
-# The staggered first round of the one-per-CU Winograd kernel (csrc/m4d_wino6.hip, m4d_wino6_set_stagger): range in us, and whether
-# GraphedSequence captures the sequence both ways and keeps the faster graph (the effect's sign depends on the box).
+# The staggered first round of the one-per-CU Winograd kernel (csrc/m4d_wino6.hip): an ARGUMENT of every launch
+# (m4d_conv3x3_wino6_bias_act_ks, ABI 6 -- no library state).  The value is a per-MODEL setting (M4Depth.set_wino6_stagger ->
+# every layer's ``wino6_stagger_us``); a layer that was never told falls back to this module default.  Which launches carry it:
+# grids of >= wino6_stagger_min_wg workgroups at a launch batch <= wino6_stagger_max_batch (the launches that put one workgroup on
+# every CU at batch 1-4: the level-1 / level-2 refiner layers and the encoder's 240-workgroup layers).  Whether GraphedSequence
+# captures the sequence both ways and keeps the faster graph (the effect's sign depends on the box): wino6_stagger_autotune.
 wino6_stagger_us = int(_os.environ.get("M4D_WINO6_STAGGER_US", "9"))
+wino6_stagger_phases = int(_os.environ.get("M4D_WINO6_STAGGER_PHASES", "16"))
+wino6_stagger_min_wg = int(_os.environ.get("M4D_WINO6_STAGGER_MIN_WG", "200"))
+wino6_stagger_max_batch = int(_os.environ.get("M4D_WINO6_STAGGER_MAX_BATCH", "4"))
 wino6_stagger_autotune = _os.environ.get("M4D_STAGGER_AUTOTUNE", "1") == "1"
 wino6_stagger_force = _os.environ.get("M4D_STAGGER_FORCE", "")           # "staggered" / "lock_step": keep that graph whatever the timing
 # The reset frame of all levels in ONE launch (m4d_pyramid_reset) instead of one state-seeding launch per level: the six launches
@@ -229,6 +229,9 @@ pipeline_encoder_per_frame = _os.environ.get("M4D_PIPELINE_ENCODER", "0") == "1"
 pipeline_encoder_split = int(_os.environ.get("M4D_PIPELINE_ENCODER_SPLIT", "2"))
 # With the split: level 0's DINL statistics of every frame are taken in the first batch's launches (per-image arithmetic, same bits).
 encoder_stats_up_front = _os.environ.get("M4D_ENC_STATS_UP_FRONT", "1") == "1"
+# A/B knob (rounds 5's behaviour): a stride-1 encoder layer on the latency-first kernel always hands partial slabs on, also when
+# its stride-2 consumer cannot add them (then m4d_partial_finish runs as a launch of its own).
+encoder_s1_partial_always = _os.environ.get("M4D_ENC_S1_PARTIAL", "0") == "1"
 
 
 def _stack_frames(samples):
@@ -320,6 +323,7 @@ class _Conv3x3SameTF(torch.nn.Module):
         self.small_maps_ok = False       # DispRefiner layers: may take the one-launch small-map kernel
         self.per_image_dispatch = False  # encoder layers: kernel choice from the per-image grid x dispatch_batch (see forward)
         self.dispatch_batch = 1
+        self.wino6_stagger_us = None     # this layer's Winograd launches: staggered first round (us); None = the module default
         if in_channels is not None:
             self._build(in_channels, None)
 
@@ -441,6 +445,15 @@ class _Conv3x3SameTF(torch.nn.Module):
         pw = max((-(-w // s) - 1) * s + 3 - w, 0)
         return (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)
 
+    def launch_stagger_us(self, b, h, w):
+        """The staggered-first-round argument of this layer's Winograd launch on a [b,h,w] map: the layer's (= its model's) setting
+        on launches that put a workgroup on every CU, 0 elsewhere.  Pure function of the layer and the shape -- no global state."""
+        us = wino6_stagger_us if self.wino6_stagger_us is None else self.wino6_stagger_us
+        if us <= 0 or b > wino6_stagger_max_batch:
+            return 0
+        units = b * (-(-h // 16)) * (-(-w // 16)) * (-(-self.out_channels // 64))
+        return int(us) if units >= wino6_stagger_min_wg else 0
+
     def forward(self, x_nhwc, slope=None, final=True):
         """Convolution + bias (+ leaky_relu(slope) when ``slope`` is given): ONE hand-written HIP kernel.  There is no CPU /
         framework form of this layer in the product: a CPU tensor raises (the host-logic tests patch a torch stand-in over
@@ -474,8 +487,10 @@ class _Conv3x3SameTF(torch.nn.Module):
         wino = _use_winograd(eff_b, h_, w_, cin_, self.out_channels, self.stride)
         if wino == 6:
             wu, cpad = self._packed_weights_wino6(cin_)
-            return _timed("conv", self.tag, lambda: nops.conv3x3_wino6_bias_act(x_nhwc, wu, self.bias, self.out_channels, cpad, act,
-                                                                                kernel=wino6_kernel))
+            stag = self.launch_stagger_us(b_, h_, w_)
+            return _timed("conv", self.tag, lambda: nops.conv3x3_wino6_bias_act(
+                x_nhwc, wu, self.bias, self.out_channels, cpad, act, kernel=wino6_kernel, stagger_us=stag,
+                stagger_phases=wino6_stagger_phases))
         if wino:
             wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8, cin_)     # cin_ > Cin: zero-padded input
             fn = nops.conv3x3_wino_bias_act if wino == 1 else nops.conv3x3_wino2_bias_act
@@ -593,8 +608,12 @@ class FeaturePyramid(torch.nn.Module):
             if self.use_dinl and i == 0:
                 tmp = dn_layer(conv_s1(feature_maps), slope=0.1)
             else:
-                # (consumed by conv_s2 alone: on the latency-first small-map kernels it may stay K-slice partial sums)
-                tmp = conv_s1(feature_maps, slope=0.1, final=False)
+                # (consumed by conv_s2 alone: on the latency-first small-map kernels it may stay K-slice partial sums -- but only
+                #  when conv_s2 is itself such a kernel and adds the slabs while it stages; otherwise the slabs would need a
+                #  finishing launch of their own, a dependent launch on the encoder's latency chain)
+                fb, fh, fw = feature_maps.shape[:3]
+                takes_slabs = conv_s2.lat_eligible(fb, fh, fw, conv_s1.out_channels)
+                tmp = conv_s1(feature_maps, slope=0.1, final=not (takes_slabs or encoder_s1_partial_always))
             feature_maps = conv_s2(tmp, slope=0.1)
             outputs.append(feature_maps)
         return outputs
@@ -654,6 +673,7 @@ class DepthEstimatorLevel(torch.nn.Module):
         self._spare_f = None
         self.last_f_input = None          # kept for inspection / parity tests
         self.last_cv_inputs = None
+        self.last_front_inputs = None
 
     # -- temporal memory (build(), :153-165) ------------------------------------------
     def _ensure_state(self, shape, device):
@@ -830,21 +850,10 @@ class DepthEstimatorLevel(torch.nn.Module):
         if (fused_refiner_tail and dev.type == "cuda" and len(convs) == 7 and convs[5].weight is not None
                 and tuple(convs[5].weight.shape[:2]) == (16, 32) and tuple(convs[6].weight.shape[:2]) == (5, 16)):
             x = f_input
-            chain = (lat_chain == "all" or (lat_chain == "late" and getattr(self, "sequence_position", 0) >= 2)) \
-                and debug_tap is None and not kt_on and all(cv.lat_eligible(b, h, w, ci_) and cv.stride == 1 for cv, ci_ in
-                                                            zip(convs[:5], [F_st] + [cv.out_channels for cv in convs[:4]]))
-            if chain:
-                cins = [F_st] + [cv.out_channels for cv in convs[:4]]
-                cfgs = [nops.lat_config(b, h, w, ci_, cv.out_channels, final=(i == 4)) for i, (cv, ci_) in enumerate(zip(convs[:5], cins))]
-                chain = all(cfg[0] == 1 for cfg in cfgs)
-            if chain:
-                layers = [(cv._packed_weights_lat(ci_), cv.bias, cv.out_channels, 0.1, cfg) for cv, ci_, cfg in zip(convs[:5], cins, cfgs)]
-                x, self._chain_ctrl = nops.conv3x3_lat_chain(x, layers, key=("lvl", self.lvl_depth))
-            else:
-                for ci, conv in enumerate(convs[:5]):
-                    x = conv(x, slope=0.1, final=(ci == 4))               # the fused tail reads a finished tensor
-                    if debug_tap is not None:
-                        debug_tap(f"refiner_conv{ci + 1}", self.lvl_depth, x.dense() if isinstance(x, nops.PartialAct) else x)
+            for ci, conv in enumerate(convs[:5]):
+                x = conv(x, slope=0.1, final=(ci == 4))                   # the fused tail reads a finished tensor
+                if debug_tap is not None:
+                    debug_tap(f"refiner_conv{ci + 1}", self.lvl_depth, x.dense() if isinstance(x, nops.PartialAct) else x)
             split = tail_split and conv_arith == "bf16x3"
             w6p, w7p = self._tail_weights(convs, split)
             tail_fn = nops.refiner_tail6 if split else nops.refiner_tail
@@ -965,16 +974,32 @@ class DepthEstimatorPyramid(torch.nn.Module):
         keep.append(fork)
         n_fr = len(traj_samples)
 
-        def needs_fork(f):
-            """Does the stream whose first frame is ``f`` wait for the fork event itself?  Frame 0 and a frame that launches
-            an encoder pass must; for the others the wait is implied by their wait for the previous frame's level -- but the
-            redundant edge is not neutral: ROCm 7.2's hipGraph executor assigns nodes to its four streams from the edges it
-            sees.  ``pipeline_fork_frames`` = the frames that keep the explicit wait."""
-            if f == 0 or f >= n_fr or f_maps_pyrs is None:
+        def is_reset(f):
+            nt = traj_samples[f]["new_traj"]
+            return bool(nt.reshape(-1)[0].item()) if isinstance(nt, torch.Tensor) else bool(np.asarray(nt).reshape(-1)[0])
+        # frame -> stream: one per frame; with pipeline_merge_reset_frame a reset frame rides on the next frame's stream
+        stream_of = list(range(n_fr))
+        if pipeline_merge_reset_frame:
+            for f in range(n_fr - 1):
+                if is_reset(f) and not is_reset(f + 1):
+                    stream_of[f] = f + 1
+
+        def launches_encoder(f):
+            """Frame ``f`` issues an encoder pass on its own stream (reads the input images, produced on the main stream)."""
+            return f_maps_pyrs is None or (f_maps_pyrs[f] is None and (f == 0 or f_maps_pyrs[f - 1] is not None))
+
+        def needs_fork(i_st):
+            """Does stream ``i_st`` wait for the fork event itself?  It MUST when it hosts frame 0 (nothing else orders it behind
+            the main stream's encoder -- also when a merged reset frame moved frame 0 onto it) or a frame that launches an encoder
+            pass.  For the others the wait is implied by their wait for the previous frame's level -- but the redundant edge is not
+            neutral: ROCm 7.2's hipGraph executor assigns nodes to its four streams from the edges it sees.
+            ``pipeline_fork_frames`` = the streams (= frames, one stream per frame under capture) that keep the explicit wait."""
+            hosted = [f for f in range(n_fr) if stream_of[f] % n_streams == i_st]
+            if i_st == 0 or i_st >= n_fr or f_maps_pyrs is None:
                 return True
-            if f_maps_pyrs[f] is None and f_maps_pyrs[f - 1] is not None:          # the first frame of the late encoder batch
+            if any(f == 0 or launches_encoder(f) for f in hosted):
                 return True
-            return pipeline_fork_frames is None or f in pipeline_fork_frames
+            return pipeline_fork_frames is None or i_st in pipeline_fork_frames
         for i_st, st in enumerate(streams):
             if needs_fork(i_st):
                 st.wait_event(fork)                   # encoder outputs / inputs are produced on the main stream
@@ -994,15 +1019,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
         order = [(seq_i, diag - seq_i) for diag in range(n_fr + n_lvls - 1)
                  for seq_i in range(max(0, diag - n_lvls + 1), min(n_fr, diag + 1))]
 
-        def is_reset(f):
-            nt = traj_samples[f]["new_traj"]
-            return bool(nt.reshape(-1)[0].item()) if isinstance(nt, torch.Tensor) else bool(np.asarray(nt).reshape(-1)[0])
-        # frame -> stream: one per frame; with pipeline_merge_reset_frame a reset frame rides on the next frame's stream
-        stream_of = list(range(n_fr))
         if pipeline_merge_reset_frame:
-            for f in range(n_fr - 1):
-                if is_reset(f) and not is_reset(f + 1):
-                    stream_of[f] = f + 1
             # a merged reset frame must be ISSUED before the frame it shares the stream with reaches the same level: issue the
             # whole reset frame first (it is six tiny launches)
             # (only the reset frame that OPENS the sequence: a later one waits on the frame before it, level by level, and keeps
@@ -1051,7 +1068,6 @@ class DepthEstimatorPyramid(torch.nn.Module):
                 if seq_i in fused_reset_frames:
                     continue
                 prev = None if d_est[seq_i] is None else dict(d_est[seq_i][-1])
-                self.levels[lvl].sequence_position = seq_i                 # (kernel-choice hint only: network.lat_chain)
                 est = self.levels[lvl](f_pyrs[seq_i][lvl], prev, sample['rot'], sample['trans'], local_cameras[lvl],
                                        sample["new_traj"])
                 ev = torch.cuda.Event()
@@ -1099,6 +1115,7 @@ class M4Depth(torch.nn.Module):
         self.step_counter = 0
         self.compiled_metrics = []
         self.last_estimates = None
+        self.wino6_stagger_us = None        # set_wino6_stagger: None = the module default
 
     # -- weights -----------------------------------------------------------------------
     def load_numpy_weights(self, weights, device):
@@ -1209,6 +1226,16 @@ class M4Depth(torch.nn.Module):
     def reset_state(self):
         for lvl in self.d_estimator.levels:
             lvl.reset_state()
+
+    def set_wino6_stagger(self, us):
+        """The staggered first round of THIS model's one-per-CU Winograd launches: ``us`` microseconds (0 = lock step, None = the
+        module default ``network.wino6_stagger_us``).  A per-model setting handed to every launch as an argument
+        (m4d_conv3x3_wino6_bias_act_ks): models with different settings, on different host threads, never see each other's."""
+        for conv in self.modules():
+            if isinstance(conv, _Conv3x3SameTF):
+                conv.wino6_stagger_us = None if us is None else int(us)
+        self.wino6_stagger_us = None if us is None else int(us)
+        return self
 
     # -- forward -------------------------------------------------------------------------
     def forward(self, data, training=False):
@@ -1405,7 +1432,10 @@ class GraphedSequence:
     copies), replays, and returns the static ``depth`` output tensor.  The batch must have the captured shapes and
     the captured ``new_traj`` pattern (it is control flow here); anything else raises."""
 
-    def __init__(self, model, example, warmup=2):
+    def __init__(self, model, example, warmup=2, autotune=None):
+        """``autotune``: None = the module setting (``wino6_stagger_autotune``: capture the sequence with and without the staggered
+        Winograd first round and keep the faster graph, batch <= 4 only); False = ONE capture with the model's own stagger
+        setting (``M4Depth.set_wino6_stagger``); True = force the double capture."""
         self.model = model
         nt = example["new_traj"]
         self.new_traj = nt.clone() if isinstance(nt, torch.Tensor) else torch.as_tensor(np.asarray(nt))
@@ -1426,13 +1456,17 @@ class GraphedSequence:
                 self._run()
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
-        self.stagger_us = None                      # what the captured Winograd launches carry (None: the library's setting)
         self.capture_passes = 1                     # forward passes issued under capture (2 when both forms were captured)
+        self.stagger_autotune_ms = None
         batch = int(self.static["RGB_im"].shape[0])
-        if wino6_stagger_autotune and wino6_stagger_us > 0 and batch <= 4:
-            self._capture_autotuned()
+        model_us = getattr(model, "wino6_stagger_us", None)
+        base_us = wino6_stagger_us if model_us is None else model_us
+        want = wino6_stagger_autotune if autotune is None else bool(autotune)
+        if want and base_us > 0 and batch <= wino6_stagger_max_batch:
+            self._capture_autotuned(base_us)
         else:
             self.graph, self.depth = self._capture()
+            self.stagger_us = base_us if batch <= wino6_stagger_max_batch else 0    # what the captured Winograd launches carry
         self.weights_stamp = model.weights_stamp()
 
     def _capture(self):
@@ -1441,18 +1475,32 @@ class GraphedSequence:
             out = self._run()
         return graph, out
 
-    def _capture_autotuned(self):
-        """Two captures -- the Winograd launches with their first round staggered (m4d_wino6_set_stagger) and without -- timed
-        against each other here, the faster one kept.  Whether the stagger pays depends on the BOX: on some MI355X boxes of the
-        pool the coarse-level kernels of the next frame queue behind the lock-step rounds of a level-1 layer and the stagger is
-        worth +4.5 %; on others they do not (the same library runs 7 % faster there to begin with) and it costs 3 %
-        (DESIGN.md section 6).  The launch arguments are baked into the graph: the choice is per captured sequence."""
+    def _inspection_state(self):
+        """The tensors a forward pass leaves on the model for inspection (per-level estimates, refiner inputs, ...): they live in
+        the memory pool of the capture that produced them."""
+        lv = self.model.d_estimator.levels
+        return (self.model.last_estimates,
+                [(l.last_f_input, l.last_cv_inputs, getattr(l, "last_front_inputs", None)) for l in lv])
+
+    def _restore_inspection_state(self, state):
+        self.model.last_estimates = state[0]
+        for l, (f_in, cv_in, front_in) in zip(self.model.d_estimator.levels, state[1]):
+            l.last_f_input, l.last_cv_inputs, l.last_front_inputs = f_in, cv_in, front_in
+
+    def _capture_autotuned(self, stagger_us):
+        """Two captures -- the Winograd launches with their first round staggered and without -- timed against each other here,
+        the faster one kept.  Whether the stagger pays depends on the BOX: on some MI355X boxes of the pool the coarse-level
+        kernels of the next frame queue behind the lock-step rounds of a level-1 layer and the stagger is worth +4.5 %; on others
+        they do not (the same library runs 7 % faster there to begin with) and it costs 3 %.  The stagger is
+        a launch ARGUMENT baked into the captured graph (ABI 6: no library state): the candidates differ in the per-model setting
+        (``M4Depth.set_wino6_stagger``) they were captured under, the model keeps the winner's, and no other model, thread or
+        later eager launch of another model is affected."""
         cands = []
         self.capture_passes = 2
-        for us in (wino6_stagger_us, 0):
-            lib.m4d_wino6_set_stagger(int(us), 0, 0)
+        for us in (stagger_us, 0):
+            self.model.set_wino6_stagger(us)
             graph, out = self._capture()
-            cands.append([us, graph, out, [], self.model.last_estimates])
+            cands.append([us, graph, out, [], self._inspection_state()])
         # Timed the way the graph will be used: back-to-back replays in ITS OWN steady state.  (A few replays right after the
         # capture, on a chip that idled through it, picked the wrong graph on every box; so did interleaved blocks of 24 replays,
         # and 60 + 40 replays per form on one box in six: the lock-step form runs ~2.5-4 % faster for its first 100-400 ms --
@@ -1478,11 +1526,13 @@ class GraphedSequence:
         if wino6_stagger_force in ("staggered", "lock_step"):          # tests: either graph must serve
             best = cands[0] if wino6_stagger_force == "staggered" else cands[1]
         self.stagger_us, self.graph, self.depth = best[0], best[1], best[2]
-        self.model.last_estimates = best[4]            # (the per-level estimates the kept graph writes, not the last capture's)
+        # the inspection tensors of the KEPT capture (the loser's pool is freed below: nothing may keep pointing into it)
+        self._restore_inspection_state(best[4])
         self.stagger_autotune_ms = {int(c[0]): [round(v / reps, 4) for v in c[3]] for c in cands}
-        lib.m4d_wino6_set_stagger(int(self.stagger_us), 0, 0)       # eager launches from here on follow the choice
+        self.model.set_wino6_stagger(self.stagger_us)  # this model's eager launches from here on follow the choice
         for c in cands:
             if c is not best:
+                c[4] = None
                 c[1].reset()                            # the loser's graph and its memory pool
 
     def _samples(self):

@@ -489,43 +489,6 @@ def conv3x3_lat(x, wp, bias, cout, slope=0.1, final=False, config=None, stride=1
     return out[0] if s_out == 1 else PartialAct(out, bias, act)
 
 
-# workgroups per XCD of m4d_conv3x3_lat_chain (all workers sit on one XCD; 8 x this many are launched)
-lat_chain_workgroups = int(_os.environ.get("M4D_LAT_CHAIN_WG", "16"))
-
-
-def conv3x3_lat_chain(x, layers, key):
-    """m4d_conv3x3_lat_chain: ``layers`` = [(wp, bias, cout, slope, (mt, kw, s_out)), ...] applied to the finished tensor ``x``
-    (every mt must be 1, the last s_out 1) in ONE launch; bit for bit what the same conv3x3_lat calls give one after the other.
-    ``key`` names the chain's control block (one per chain that may be in flight: per level and stream)."""
-    from ._lib import LatLayer
-    xs = as_f32(x, "x")
-    b, h, w, cin = xs.shape
-    n = len(layers)
-    arr = (LatLayer * n)()
-    keep = []
-    cur, cur_s, cur_slab, cur_bias, cur_slope, cur_c = xs, 1, 0, None, 1.0, cin
-    out = None
-    for l, (wp, bias, cout, slope, (mt, kw, s_out)) in enumerate(layers):
-        if mt != 1:
-            raise ValueError("conv3x3_lat_chain: one M-tile per wave only")
-        act = 1.0 if slope is None else float(slope)
-        out = torch.empty((s_out, b, h, w, int(cout)), dtype=torch.float32, device=xs.device)
-        keep.append(out)
-        y = arr[l]
-        y.x, y.s_in, y.x_slab_floats = cur.data_ptr(), cur_s, cur_slab
-        y.x_bias, y.x_slope = (None if cur_bias is None else dptr(cur_bias, "bias").value), float(cur_slope)
-        y.wp, y.bias = dptr(wp, "wp", torch.int16).value, dptr(bias, "bias").value
-        y.Cin, y.Cout, y.slope, y.kw, y.s_out = cur_c, int(cout), act, int(kw), int(s_out)
-        y.out, y.out_slab_floats = out.data_ptr(), b * h * w * int(cout)
-        cur, cur_s, cur_slab, cur_c = out, s_out, b * h * w * int(cout), int(cout)
-        cur_bias, cur_slope = (bias, act) if s_out > 1 else (None, 1.0)
-    if cur_s != 1:
-        raise ValueError("conv3x3_lat_chain: the last layer must write a finished activation (s_out = 1)")
-    ctrl = zeroed_workspace(("lat_chain_ctrl", key), (16,), xs.device)
-    check(lib.m4d_conv3x3_lat_chain(arr, n, b, h, w, dptr(ctrl, "ctrl"), lat_chain_workgroups, stream_ptr()), "m4d_conv3x3_lat_chain")
-    return out[0], ctrl
-
-
 def conv3x3_small6_bias_act(x, wp6, bias, cout, cout_pad, slope=0.1):
     """The one-launch small-map convolution with float32 operands split into three bf16 terms (csrc/m4d_conv.hip,
     conv3x3_small6_kernel): float32 accuracy at 2.7x less matrix-core time per wave."""
@@ -537,16 +500,19 @@ def conv3x3_small6_bias_act(x, wp6, bias, cout, cout_pad, slope=0.1):
     return out
 
 
-def conv3x3_wino6_bias_act(x, wu6, bias, cout, cout_pad, slope=0.1, kernel=0):
+def conv3x3_wino6_bias_act(x, wu6, bias, cout, cout_pad, slope=0.1, kernel=0, stagger_us=0, stagger_phases=16):
     """3x3 stride-1 TF-'SAME' convolution + bias + leaky_relu(slope): Winograd F(2x2,3x3), float32 operands split into
     three bf16 terms, six bf16 MFMA products per term pair, float32 accumulation.  ``kernel``: 0 = chosen from the grid,
-    1 = one workgroup per (tile, 64 couts) (csrc/m4d_wino6.hip), 2 = persistent workgroups (csrc/m4d_wino6p.hip); same bits."""
+    1 = one workgroup per (tile, 64 couts) (csrc/m4d_wino6.hip), 2 = persistent workgroups (csrc/m4d_wino6p.hip); same bits.
+    ``stagger_us`` > 0: the one-workgroup-per-unit kernel starts its first round of workgroups in ``stagger_phases`` groups spread
+    over that many microseconds (a per-launch ARGUMENT, m4d_conv3x3_wino6_bias_act_ks; same bits)."""
     x = as_f32(x, "x")
     b, h, w, cin = x.shape
     out = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
-    check(lib.m4d_conv3x3_wino6_bias_act_k(dptr(x, "x"), dptr(wu6, "wu6", torch.int16), dptr(bias, "bias"), b, h, w, cin,
-                                           int(cout), int(cout_pad), float(slope), dptr(out), int(kernel), stream_ptr()),
-          "m4d_conv3x3_wino6_bias_act_k")
+    check(lib.m4d_conv3x3_wino6_bias_act_ks(dptr(x, "x"), dptr(wu6, "wu6", torch.int16), dptr(bias, "bias"), b, h, w, cin,
+                                            int(cout), int(cout_pad), float(slope), dptr(out), int(kernel), int(stagger_us),
+                                            int(stagger_phases), stream_ptr()),
+          "m4d_conv3x3_wino6_bias_act_ks")
     return out
 
 

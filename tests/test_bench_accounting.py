@@ -68,3 +68,30 @@ def test_committed_traffic_file_is_well_formed():
             continue
         for name, ent in entries.items():
             assert ent["bytes"] > 0 and ent["kernel"] and all(os.path.isfile(os.path.join(ROOT, p)) for p in ent["sources"]), (key, name)
+
+
+def test_workload_names_follow_the_whole_geometry():
+    """config.workload names the BASELINE.json configuration from the geometry AND (GPUs, batch): the 768x2560
+    ranges-6/6 run is configs[4], never configs[1]."""
+    a = lambda **kw: types.SimpleNamespace(**dict(dict(height=384, width=1280, levels=6, seq_len=4, dscv_range=4, sncv_range=3, batch=1), **kw))
+    assert bench.workload_name(a(), 1) == "BASELINE.json configs[1]"
+    assert bench.workload_name(a(batch=32), 1) == "BASELINE.json configs[2]"
+    assert bench.workload_name(a(batch=32), 8).startswith("BASELINE.json configs[3]")
+    assert bench.workload_name(a(height=768, width=2560, dscv_range=6, sncv_range=6), 1) == "BASELINE.json configs[4]"
+    assert "configs[1]" not in bench.workload_name(a(height=768, width=2560, dscv_range=6, sncv_range=6), 1)
+    assert bench.workload_name(a(batch=8), 1) == "the configs[1] geometry at a custom batch"
+    assert bench.workload_name(a(height=192, width=640), 1) == "custom workload"
+    head = bench.report_head(a(height=768, width=2560, dscv_range=6, sncv_range=6, gpus=1, steps=5, warmup=1), 1, 1.0, [1.0])
+    assert head["config"]["workload"].endswith("= BASELINE.json configs[4]")
+
+
+def test_run_spread_and_box_kind_probe():
+    """the run-to-run spread of the repeated timed regions and the box-kind record (the capture-time timings of
+    the lock-step and the staggered graph) that tell a box difference from a code change."""
+    sp = bench.run_spread([2.43, 2.41, 2.47])
+    assert sp == {"runs": [2.43, 2.41, 2.47], "min": 2.41, "median": 2.43, "max": 2.47, "spread_pct": 2.49}
+    assert bench.box_kind_probe(None, None) is None and bench.box_kind_probe({}, 9) is None
+    slow = bench.box_kind_probe({9: [2.44, 2.408], 0: [2.46, 2.498]}, 9)
+    assert slow["kind"].startswith("lock-step-slow") and slow["lock_step_over_staggered"] == round(2.498 / 2.408, 4) and slow["chosen_stagger_us"] == 9
+    fast = bench.box_kind_probe({9: [2.40, 2.41], 0: [2.33, 2.34]}, 0)
+    assert fast["kind"].startswith("lock-step-fast") and fast["lock_step_over_staggered"] < 1.0

@@ -64,11 +64,17 @@ def _worker(rank, world, port, q):
         for m in mets:
             m.update_state(gt, gt * (1.0 + 0.01 * (r + 1)))
 
-    dt, per_rank_s = B.timed_region(step, args.steps, D, dev, lambda: None)
+    # bench.main's timed part as it runs on every rank: the contract's region, the repeated regions, the per-rank stagger gather
+    args.repeat_regions = 3
+    dt, per_rank_s, ms_runs, per_rank_stagger = B.timed_job(step, args, D, dev, lambda: None, stagger_us=(9 if r == 0 else 0))
     gathered = D.all_gather_metric_states(mets, dev)
     metrics = D.reduce_metric_states(gathered).tolist()
+    t_tail = time.perf_counter()
+    if r == 0:
+        time.sleep(0.5)                                    # rank 0's report work (cpu_baseline, parity, ...): nobody may wait for it
     head = B.report_head(args, w, dt, per_rank_s)
-    q.put((r, head, metrics, float(data["RGB_im"].sum()), tuple(data["RGB_im"].shape), dt, per_rank_s))
+    q.put((r, head, metrics, float(data["RGB_im"].sum()), tuple(data["RGB_im"].shape), dt, per_rank_s,
+           ms_runs, per_rank_stagger, time.perf_counter() - t_tail))
     torch.distributed.destroy_process_group()
 
 
@@ -84,7 +90,15 @@ def test_two_rank_bench_leg_over_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, head0, met0, sum0, shape0, dt0, prs0), (r1, head1, met1, sum1, shape1, dt1, prs1) = outs
+    (r0, head0, met0, sum0, shape0, dt0, prs0, runs0, stag0, tail0), (r1, head1, met1, sum1, shape1, dt1, prs1, runs1, stag1, tail1) = outs
+    # the straggler case configs[3]'s scaling hinges on: every region's time is the SLOW rank's, on both ranks alike; the repeated
+    # regions agree with the first; each rank's own Winograd first-round choice lands in the line; rank 1 never waits for rank 0's tail
+    assert len(runs0) == 3 and runs0 == runs1 and all(abs(v - runs0[0]) < 0.5 * runs0[0] for v in runs0)
+    assert all(v >= 1e3 * 0.02 for v in runs0)              # >= the slow rank's 20 ms per step
+    assert stag0 == stag1 == [9.0, 0.0]
+    assert tail1 < 0.25 <= tail0
+    spread = bench.run_spread(runs0)
+    assert spread["min"] <= spread["median"] <= spread["max"] and spread["runs"] == [round(v, 3) for v in runs0]
     assert shape0 == shape1 == (4, 3, 16, 32, 3)
     assert sum0 != sum1                                     # every rank generates ITS shard (seeded by rank), not a copy
     assert dt0 == dt1 and prs0 == prs1 and len(prs0) == 2   # max over ranks / gathered list: the same on every rank

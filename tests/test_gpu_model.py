@@ -247,6 +247,7 @@ def test_graphed_sequence_matches_eager(dev, keep, monkeypatch):
     d1, d2 = batch(31), batch(32)
     model.test_step(d1)
     eager1 = npy(model.last_estimates[-1][0]["parallax"])
+    fin1 = npy(model.d_estimator.levels[0].last_f_input)
     model.test_step(d2)
     eager2 = npy(model.last_estimates[-1][0]["parallax"])
     runner = net.GraphedSequence(model, d1)
@@ -256,8 +257,17 @@ def test_graphed_sequence_matches_eager(dev, keep, monkeypatch):
         res = model.graphed_test_step(d, runner)
         torch.cuda.synchronize()
         assert_bits_equal(npy(model.last_estimates[-1][0]["parallax"]), ref, "graph replay vs eager")
+    # the per-level inspection tensors are the KEPT capture's too (after the loser's pool is freed nothing may point into it)
+    assert_bits_equal(npy(model.d_estimator.levels[0].last_f_input), fin1, "level-1 refiner input of the kept graph")
     assert model.compiled_metrics[0].count == 3 and np.isfinite(float(res["AbsRel"]))
     assert runner.capture_passes == 2 and runner.stagger_us == {"staggered": net.wino6_stagger_us, "lock_step": 0}.get(keep, runner.stagger_us)
+    # the choice is THIS model's setting (a launch argument from here on), not library state
+    assert model.wino6_stagger_us == runner.stagger_us
+    assert all(c.wino6_stagger_us == runner.stagger_us for c in model.modules() if isinstance(c, net._Conv3x3SameTF))
+    # a caller can switch the double capture off: one capture, with the model's own setting
+    single = net.GraphedSequence(model, d1, autotune=False)
+    assert single.capture_passes == 1 and single.stagger_us == runner.stagger_us and single.stagger_autotune_ms is None
+    assert torch.equal(single(d2), runner(d2))
     assert torch.equal(runner(d2), model([[{k: d2[k][:, t] for k in ("RGB_im", "rot", "trans", "new_traj")} for t in range(T)],
                                           d2["camera"]])["depth"])
     bad = dict(d1)
@@ -268,6 +278,46 @@ def test_graphed_sequence_matches_eager(dev, keep, monkeypatch):
     bad["RGB_im"] = d1["RGB_im"][:1]
     with pytest.raises(ValueError):
         runner(bad)
+
+
+def test_two_models_two_threads_keep_their_own_stagger(dev, monkeypatch):
+    """two models with different staggered-first-round settings, each driven from its own host thread at the
+    same time, each hand THEIR OWN value to every Winograd launch (the argument of m4d_conv3x3_wino6_bias_act_ks; round 5 kept it
+    in a process-wide variable of the library that the last writer won) -- and compute the same bits."""
+    import threading
+    import m4depth_amd as M
+    from m4depth_amd import network as net, network_ops as nops
+    L, H, Wd, T, b = 2, 192, 640, 2, 1                   # level 1 = 96x320: 120 tiles x 2 cout groups = 240 workgroups >= 200
+    W = S.init_weights(L, seed=3)
+    models = {"a": _build(dev, L, 4, 3, W).set_wino6_stagger(0), "b": _build(dev, L, 4, 3, W).set_wino6_stagger(23)}
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=5)
+    seen = {"a": set(), "b": set()}
+    real = nops.conv3x3_wino6_bias_act
+    names = {}
+
+    def spy(*args, **kw):
+        seen[names[threading.get_ident()]].add(int(kw.get("stagger_us", 0)))
+        return real(*args, **kw)
+    monkeypatch.setattr(nops, "conv3x3_wino6_bias_act", spy)
+    outs, start = {}, threading.Barrier(2)
+
+    def worker(name):
+        names[threading.get_ident()] = name
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            start.wait()
+            for _ in range(3):
+                models[name].reset_state()
+                outs[name] = models[name]([to_dev(samples, dev), to_dev(cam, dev)])["depth"]
+            st.synchronize()
+    th = [threading.Thread(target=worker, args=(n,)) for n in ("a", "b")]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert seen["a"] == {0}, seen
+    assert 23 in seen["b"] and seen["b"] <= {0, 23}, seen       # (its small grids launch in lock step: the policy of launch_stagger_us)
+    assert torch.equal(outs["a"], outs["b"])
 
 
 def test_graphed_batch2_has_only_library_kernels(dev, tmp_path):

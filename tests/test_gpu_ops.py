@@ -493,26 +493,71 @@ def test_persistent_winograd_is_bitwise_the_one_tile_kernel(M, dev, b, h, w, cin
 
 
 def test_winograd_staggered_first_round_changes_no_bit(M, dev):
-    """m4d_wino6_set_stagger: the first 256 workgroups of a launch start in phases (a delay in front of the kernel body, so that
-    the CUs do not free in lock step, csrc/m4d_wino6.hip) -- off, the default and an extreme setting give the same bits on a
-    multi-round grid (960 units), a single-round one (240) and one below the threshold."""
-    from m4depth_amd import network_ops as nops, _lib
+    """m4d_conv3x3_wino6_bias_act_ks: with stagger_us > 0 the first 256 workgroups of a launch start in phases (a delay in front of
+    the kernel body, so that the CUs do not free in lock step, csrc/m4d_wino6.hip) -- off, the default and extreme settings give
+    the same bits on a multi-round grid (960 units), a single-round one (240) and a small one; bad arguments are refused."""
+    from m4depth_amd import network_ops as nops
     rng = np.random.default_rng(5)
-    try:
-        for (h, w, cin, cout) in ((192, 640, 32, 128), (96, 320, 64, 128), (48, 160, 32, 64)):
-            x = to_dev(rng.standard_normal([1, h, w, cin]).astype(F), dev)
-            k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
-            bias = to_dev((0.1 * rng.standard_normal([cout])).astype(F), dev)
-            wu6, cpad = nops.pack_conv_weights_wino6(k)
-            wud = torch.from_numpy(wu6.view("int16")).to(dev)
-            outs = []
-            for cfg in ((0, 16, 200), (9, 16, 200), (40, 32, 1), (13, 8, 200)):
-                _lib.lib.m4d_wino6_set_stagger(*cfg)
-                outs.append(nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1, kernel=1))
-            for o in outs[1:]:
-                assert torch.equal(o, outs[0])
-    finally:
-        _lib.lib.m4d_wino6_set_stagger(9, 16, 200)
+    for (h, w, cin, cout) in ((192, 640, 32, 128), (96, 320, 64, 128), (48, 160, 32, 64)):
+        x = to_dev(rng.standard_normal([1, h, w, cin]).astype(F), dev)
+        k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+        bias = to_dev((0.1 * rng.standard_normal([cout])).astype(F), dev)
+        wu6, cpad = nops.pack_conv_weights_wino6(k)
+        wud = torch.from_numpy(wu6.view("int16")).to(dev)
+        outs = [nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1, kernel=1, stagger_us=us, stagger_phases=ph)
+                for us, ph in ((0, 16), (9, 16), (40, 32), (13, 8), (300, 1))]
+        outs.append(nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1, kernel=2, stagger_us=9, stagger_phases=16))   # persistent: ignored
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+        for us, ph in ((-1, 16), (9, 3), (9, 64), (2000, 16)):
+            with pytest.raises(RuntimeError):
+                nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1, kernel=1, stagger_us=us, stagger_phases=ph)
+
+
+def test_winograd_stagger_is_per_call(M, dev):
+    """ABI 6: the staggered first round is an ARGUMENT of the launch, not library state.  Two host threads launch
+    the same layer at the same time on their own streams, one in lock step and one with a 400-us second phase: every launch of the
+    first stays short, every launch of the second carries its own delay (with round 5's process-wide setter both threads saw
+    whichever value was written last), and both get the same bits."""
+    import threading
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(11)
+    h, w, cin, cout = 48, 160, 32, 64                      # 30 workgroups: both threads' launches fit on the chip side by side
+    x = to_dev(rng.standard_normal([1, h, w, cin]).astype(F), dev)
+    k = (rng.standard_normal([3, 3, cin, cout]) * np.sqrt(2.0 / (9 * cin))).astype(F)
+    bias = to_dev((0.1 * rng.standard_normal([cout])).astype(F), dev)
+    wu6, cpad = nops.pack_conv_weights_wino6(k)
+    wud = torch.from_numpy(wu6.view("int16")).to(dev)
+    torch.cuda.synchronize()
+    res, start = {}, threading.Barrier(2)
+
+    def worker(name, us, phases):
+        st = torch.cuda.Stream()
+        times, outs = [], []
+        with torch.cuda.stream(st):
+            for _ in range(3):                             # warm-up (module load, first-touch)
+                nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1, kernel=1, stagger_us=us, stagger_phases=phases)
+            st.synchronize()
+            start.wait()
+            for _ in range(24):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                outs.append(nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1, kernel=1, stagger_us=us, stagger_phases=phases))
+                e1.record(st)
+                times.append((e0, e1))
+            st.synchronize()
+        res[name] = ([a.elapsed_time(b) * 1e3 for a, b in times], outs)
+
+    th = [threading.Thread(target=worker, args=("lock_step", 0, 1)), threading.Thread(target=worker, args=("staggered", 800, 2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    fast, slow = res["lock_step"][0], res["staggered"][0]
+    assert min(slow) >= 380.0, f"a staggered launch lost its delay: {sorted(slow)[:4]} us"
+    assert float(np.median(fast)) < 250.0, f"the lock-step thread's launches carry the other thread's delay: median {np.median(fast):.0f} us"
+    for o in res["lock_step"][1] + res["staggered"][1]:
+        assert torch.equal(o, res["lock_step"][1][0])
 
 
 @pytest.mark.parametrize("cin,cout", [(128, 128), (32, 128), (16, 128), (128, 96)])
@@ -636,35 +681,6 @@ def test_latency_conv_vs_oracle(M, dev, b, h, w, cin, cout, slope):
     cfg = nops.lat_config(b, h, w, cin, cout, final=True)
     assert cfg[2] == 1 and torch.equal(default, same_order[(cfg[1], 1)])
     assert torch.equal(default, nops.conv3x3_lat(xd, wd, bd, cout, slope, final=True))     # deterministic
-
-
-@pytest.mark.parametrize("b,h,w,cin0", [(1, 6, 20, 472), (1, 12, 40, 240), (1, 24, 80, 240), (2, 7, 9, 128), (1, 3, 5, 64)])
-@pytest.mark.parametrize("wgs", [16, 2])
-def test_latency_conv_chain_launch_is_bitwise_the_separate_launches(M, dev, b, h, w, cin0, wgs, monkeypatch):
-    """m4d_conv3x3_lat_chain (round 5: the refiner layers 1-5 of a coarse level in ONE launch -- resident workgroups on one XCD draw
-    the separate launches' work items from a ticket counter, a layer's items wait for the completion counter of the layer before)
-    against the five m4d_conv3x3_lat launches it replaces: the same bits, for every level geometry, with many and with very few
-    workers (2 per XCD: every worker walks dozens of items through every layer), repeated 20 times behind warm caches (the consumer's
-    L1 holds the previous repetition's slabs: a missing acquire reads those), the control block left clean, no expired wait."""
-    from m4depth_amd import network_ops as nops
-    monkeypatch.setattr(nops, "lat_chain_workgroups", wgs)
-    rng = np.random.default_rng(cin0 + h)
-    chans = [cin0, 128, 128, 96, 64, 32]
-    ks = [(rng.standard_normal([3, 3, ci, co]) * np.sqrt(2.0 / (9 * ci))).astype(F) for ci, co in zip(chans[:-1], chans[1:])]
-    wds = [torch.from_numpy(nops.pack_conv_weights_lat(k).view(np.int16)).to(dev) for k in ks]
-    bds = [to_dev((0.1 * rng.standard_normal([co])).astype(F), dev) for co in chans[1:]]
-    cfgs = [nops.lat_config(b, h, w, ci, co, final=(i == 4)) for i, (ci, co) in enumerate(zip(chans[:-1], chans[1:]))]
-    assert all(c[0] == 1 for c in cfgs)
-    layers = [(wds[i], bds[i], chans[i + 1], 0.1, cfgs[i]) for i in range(5)]
-    for rep in range(20):
-        x = to_dev(rng.standard_normal([b, h, w, cin0]).astype(F), dev)
-        ref = x
-        for i in range(5):
-            ref = nops.conv3x3_lat(ref, wds[i], bds[i], chans[i + 1], 0.1, config=cfgs[i])
-        got, ctrl = nops.conv3x3_lat_chain(x, layers, key=("test", cin0, h))
-        torch.cuda.synchronize()
-        assert torch.equal(got, ref), f"repetition {rep}"
-        assert not npy(ctrl).view(np.uint32).any(), f"repetition {rep}: control block {npy(ctrl).view(np.uint32)[:10]}"
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout", [(2, 48, 160, 96, 96), (2, 24, 80, 128, 128), (1, 12, 40, 192, 192), (1, 96, 320, 64, 64),

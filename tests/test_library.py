@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for s in syms:
         assert hasattr(raw, s), f"{s} declared in include/m4depth_hip.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == syms, "ctypes binding and header disagree"
-    assert _lib.lib.m4d_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib.m4d_abi_version() == _lib.ABI_VERSION == 6
     assert "gfx950" in _lib.build_info()
     # the experiments header: its symbols are exported by an EXPERIMENTS=1 build and ONLY by it, and the binding knows them all
     exp = header_symbols("m4depth_hip_experiments.h")
@@ -57,6 +57,9 @@ def test_argument_validation_without_gpu():
     assert lib.m4d_sncv_fwd(None, None, 1, 4, 4, 4, 1, 1, 1, None, 9, None) == 1
     assert lib.m4d_normalize_cuts(None, 1, 4, 4, 4, 1, None, None) == 1
     assert lib.m4d_bias_act(None, None, 4, 4, 0.1, None, None) == 1
+    # the staggered first round is a validated per-launch argument (ABI 6), not library state
+    assert lib.m4d_conv3x3_wino6_bias_act_ks(None, None, None, 1, 16, 16, 32, 64, 64, 0.1, None, 0, 0, 0, None) == 1
+    assert not hasattr(ctypes.CDLL(__import__("m4depth_amd")._lib.LIB_PATH), "m4d_wino6_set_stagger")
     fake = ctypes.c_void_p(4096)           # never dereferenced: validation fails first
     assert lib.m4d_dense_image_warp(fake, fake, 1, 1, 4, 1, fake, None, None) == 1          # H < 2
     assert lib.m4d_sncv_fwd(fake, fake, 1, 4, 4, 6, 1, 1, 4, fake, 36, None) == 1            # cuts do not divide C

@@ -1,7 +1,6 @@
 """Random-shape check of m4d_conv3x3_lat / m4d_conv3x3s_lat (csrc/m4d_convlat.hip): random maps, channel counts (Cin % 4 == 0, any
 Cout), strides, batch, (mt, kw, s_out) and 1-4 input slabs against the float64 convolution (tolerance of the tests); equal (kw, s_out)
-give equal bits whatever mt; a partial-slab input gives the bits of its finished tensor; repeated launches identical; chains through
-m4d_conv3x3_lat_chain against the separate launches."""
+give equal bits whatever mt; a partial-slab input gives the bits of its finished tensor; repeated launches identical."""
 import argparse, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,25 +53,5 @@ for case in range(a.cases):
     bad += 0 if ok else 1
     print(f"case {case:3d}: b={b} {h}x{w} {cin}->{cout} stride {stride} s_in {s_in} (kw {kw}, s_out {s_out}) mts {mts}: max rel err {err:.2e}  "
           f"{'ok' if ok else 'MISMATCH'}", flush=True)
-# chains
-for case in range(max(a.cases // 8, 4)):
-    b = int(rng.integers(1, 3)); h = int(rng.integers(3, 26)); w = int(rng.integers(3, 40))
-    n = int(rng.integers(2, 6))
-    chans = [4 * int(rng.integers(4, 100))] + [int(rng.choice([32, 64, 96, 128])) for _ in range(n)]
-    ws = [torch.from_numpy(nops.pack_conv_weights_lat((rng.standard_normal([3, 3, ci, co]) * np.sqrt(2.0 / (9 * ci))).astype(np.float32)).view(np.int16)).to(dev)
-          for ci, co in zip(chans[:-1], chans[1:])]
-    bs = [torch.from_numpy((0.1 * rng.standard_normal([co])).astype(np.float32)).to(dev) for co in chans[1:]]
-    cfgs = [nops.lat_config(b, h, w, ci, co, final=(i == n - 1)) for i, (ci, co) in enumerate(zip(chans[:-1], chans[1:]))]
-    if any(c[0] != 1 for c in cfgs):
-        continue
-    x = torch.from_numpy(rng.standard_normal([b, h, w, chans[0]]).astype(np.float32)).to(dev)
-    ref = x
-    for i in range(n):
-        ref = nops.conv3x3_lat(ref, ws[i], bs[i], chans[i + 1], 0.1, config=cfgs[i])
-    got, ctrl = nops.conv3x3_lat_chain(x, [(ws[i], bs[i], chans[i + 1], 0.1, cfgs[i]) for i in range(n)], key=("fuzz", case))
-    torch.cuda.synchronize()
-    ok = torch.equal(got, ref) and not ctrl.cpu().numpy().view(np.uint32).any()
-    bad += 0 if ok else 1
-    print(f"chain {case}: b={b} {h}x{w} {chans}: {'ok' if ok else 'MISMATCH'}", flush=True)
 print(f"{bad} cases failed")
 sys.exit(1 if bad else 0)
