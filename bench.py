@@ -53,7 +53,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity), MI355X_MIC
 # pseudo-random operands against 13.7-15.0 ns on all-ones -- the nominal rate is only reached on trivial data)
 BF16_MFMA_SUSTAINED_TFLOPS = round(1024 * 32768 / 20.5e-9 / 1e12, 0)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-HOT_KERNELS = ("pre", "front", "dscv", "sncv", "dscv_sncv", "tail", "post", "resize")     # network._timed names of the hot path
+HOT_KERNELS = ("pre", "norm", "front", "dscv", "sncv", "dscv_sncv", "tail", "post", "resize")     # network._timed names of the hot path
 
 
 def parse():

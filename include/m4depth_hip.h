@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define M4D_ABI_VERSION 6   /* 6 (round 6): + m4d_conv3x3_wino6_bias_act_ks (the staggered first round as a per-launch argument), - m4d_wino6_set_stagger (process-wide state on the launch path), - m4d_conv3x3_lat_chain (measured 12.5 us per hand-over, never dispatched: deleted); 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain, m4d_pyramid_reset(_supported), m4d_enc_level0_stats / _apply, m4d_wino6_set_stagger; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
+#define M4D_ABI_VERSION 6   /* 6 (round 6): + m4d_normalize_levels, m4d_level_front_small(_supported) (a coarse level opens with ONE launch), m4d_conv3x3_wino6_bias_act_ks (the staggered first round as a per-launch argument), - m4d_wino6_set_stagger (process-wide state on the launch path), - m4d_conv3x3_lat_chain (measured 12.5 us per hand-over, never dispatched: deleted); 5 (round 5): + m4d_depth_metrics_strided, m4d_launch_count, m4d_conv3x3_lat, m4d_conv3x3s_lat, m4d_partial_finish, m4d_level_front_r, m4d_wino6_persistent_min_units, m4d_pack_conv_weights_lat, m4d_conv3x3_lat_chain, m4d_pyramid_reset(_supported), m4d_enc_level0_stats / _apply, m4d_wino6_set_stagger; 4 (round 4): + m4d_conv3x3_wino6_bias_act_k; the wino6 kernel selectors and the launch tape moved to m4depth_hip_experiments.h */
 
 /* Library / device introspection (no GPU work). */
 int m4d_abi_version(void);
@@ -343,6 +343,29 @@ typedef struct m4d_reset_level {
 } m4d_reset_level;
 int m4d_pyramid_reset_supported(int C, int nbre_cuts);      /* C / nbre_cuts in {8, 16, 24, 32} */
 int m4d_pyramid_reset(const m4d_reset_level* levels, int n_levels, int b, void* stream);
+
+/* The per-cut normalisation (tf.linalg.normalize per cut, m4depth_network.py:179-189) of up to 8 feature maps in ONE launch: the
+ * normalised features of a frame depend on the encoder alone, so the coarse levels' maps of all frames of an encoder batch are
+ * normalised right behind it, off the levels' latency chains (round 6).  x / out [pixels, C], pixels = frames * b * h * w; C /
+ * nbre_cuts in {8, 16, 24, 32}.  The same bits as m4d_normalize_cuts. */
+typedef struct { const float* x; float* out; long long pixels; int C, nbre_cuts; } m4d_norm_level;
+int m4d_normalize_levels(const m4d_norm_level* levels, int n_levels, void* stream);
+/* The opening of a COARSE level (maps <= 6000 pixels: levels 4-6 of the 384x1280 pyramid at batch 1) in ONE launch (round 6):
+ * level_pre's glue + DSCV + SNCV of m4depth_network.py:196-242 on features that arrive per-cut normalised (norm_f [b,h,w,C]:
+ * m4d_normalize_levels; it becomes prev_f_maps after the level, :211/:259).  [DSCV | SNCV | glue] workgroups of one grid, nothing
+ * inside the launch depends on anything else in it: the DSCV evaluates the two maps the glue kernel would have written where it
+ * needs them (para_prev_l = 2 x the x2 upsampling of the coarser level's parallax at its own pixel, prev_d2para of depth_prev_t
+ * at the centre hypothesis' four corners), the glue workgroups write the log / memory features.  f_input [b,h,w,f_stride]:
+ * channel order of m4d_level_front, padding channels untouched (the caller keeps them zero).  prev_l_parallax / prev_l_other
+ * [b,ph,pw,1] / [b,ph,pw,4]: both NULL at the coarsest level.  Bit-identical to m4d_level_pre_normalize + m4d_dscv_sncv_fwd
+ * (tests/test_gpu_ops.py::test_level_front_small_is_bitwise_the_separate_launches).  _supported: the pyramid's (C, cuts)
+ * pairs, DSCV range 4 or 2. */
+int m4d_level_front_small_supported(int C, int nbre_cuts, int dscv_range, int sncv_range);
+int m4d_level_front_small(const float* norm_f, const float* prev_f, const float* depth_prev_t,
+                          const float* prev_l_parallax, const float* prev_l_other, int ph, int pw,
+                          const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
+                          int b, int h, int w, int C, int nbre_cuts, int dscv_range, int sncv_range, int cv_accum,
+                          float* f_input, int f_stride, float log_scale, void* stream);
 
 /* The fused level front (m4depth_network.py:179-242 in one launch, default settings: all ablation blocks on, DSCV range 4,
  * SNCV range 3): per-cut normalisation of raw_f [b,h,w,C] -> norm_out (the buffer that becomes prev_f_maps, :211/:259);

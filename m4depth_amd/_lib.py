@@ -23,6 +23,12 @@ _c_fp = ctypes.c_void_p       # device pointers travel as void*
 _c_int = ctypes.c_int
 _c_f = ctypes.c_float
 
+class NormLevel(ctypes.Structure):
+    """m4d_norm_level of include/m4depth_hip.h (one map of m4d_normalize_levels)."""
+    _fields_ = [("x", ctypes.c_void_p), ("out", ctypes.c_void_p), ("pixels", ctypes.c_longlong), ("C", ctypes.c_int),
+                ("nbre_cuts", ctypes.c_int)]
+
+
 class ResetLevel(ctypes.Structure):
     """m4d_reset_level of include/m4depth_hip.h (one level of m4d_pyramid_reset)."""
     _fields_ = [("features", ctypes.c_void_p), ("state_features", ctypes.c_void_p), ("depth_state", ctypes.c_void_p),
@@ -118,6 +124,10 @@ _SIGNATURES = {
     "m4d_level_front_supported": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "m4d_pyramid_reset_supported": [_c_int, _c_int],
     "m4d_pyramid_reset": [ctypes.POINTER(ResetLevel), _c_int, _c_int, _c_fp],
+    "m4d_normalize_levels": [ctypes.POINTER(NormLevel), _c_int, _c_fp],
+    "m4d_level_front_small_supported": [_c_int, _c_int, _c_int, _c_int],
+    "m4d_level_front_small": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
+                              _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_f, _c_fp],
     "m4d_level_front": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,
                         _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_fp, _c_int, _c_f, _c_fp],
     "m4d_level_front_r": [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_fp, _c_int, _c_fp, _c_fp, _c_fp,

@@ -18,6 +18,7 @@
 // XCD's own 4 MiB L2.
 #include "m4d_common.h"
 #include "m4d_sncv_small.h"
+#include "m4d_level_pre.h"
 #include "../../include/m4depth_hip.h"
 
 namespace {
@@ -32,6 +33,10 @@ struct DscvArgs {
   float* cv; int cv_stride; float* prev_disp; float* log_center; int log_stride; float log_scale;
   int32_t* index_out;
   int ablate;            // profiling only (m4d_dscv_set_ablation): 1 = no cv stores, 2 = no corner loads, 4 = no centre feature
+  // ONFLY instantiations only (m4d_level_front_small: the level's opening glue is not a launch of its own, so its two maps do
+  // not exist): disp = 2 x the x2 upsampling of the coarser level's parallax (pl_para [b,ph,pw], NULL at the coarsest level: 1),
+  // disp_prev_t at a corner = prev_d2para of the depth memory there -- the expressions of level_pre_body, evaluated in place
+  const float* pl_para = nullptr; int ph = 0, pw = 0; const float* depth_prev_t = nullptr;
 };
 
 __device__ __forceinline__ void dscv_query(const M4dPixel& px, float start_x, float start_y, float disp,
@@ -80,7 +85,7 @@ struct DscvLdsFetch {
 // the channel-order cross-lane sums of those HB hypotheses run as G-1 rounds of HB
 // independent shuffles.  A compiler memory barrier closes each batch so that the loads of
 // later batches are not hoisted (which costs >190 VGPRs and the occupancy with it).
-template <int LP, int G, int NCP, class Fetch>
+template <int LP, int G, int NCP, class Fetch, bool ONFLY = false>
 __device__ __forceinline__ void dscv_pixel(const DscvArgs& a, const M4dMotion& m, int bi, int i, int j, bool active,
                                            int q, int g, int kk, int base_lane, const Fetch& fetch) {
   constexpr int J = (NCP + LP - 1) / LP;       // hypotheses computed by each lane
@@ -93,7 +98,16 @@ __device__ __forceinline__ void dscv_pixel(const DscvArgs& a, const M4dMotion& m
   const M4dPixel px = m4d_pixel_factors(m, i, j);
   const float start_x = px.x * m.fx;           // :256
   const float start_y = px.y * m.fy;
-  const float disp = a.disp[gp];
+  float disp;
+  if (ONFLY) {                                  // para_prev_l of level_pre_body (m4depth_network.py:198, 203), same expressions
+    disp = 1.0f;
+    if (a.pl_para != nullptr) {
+      const ResizeAxis ya = resize_axis(j, (float)a.ph / (float)a.h, a.ph), xa = resize_axis(i, (float)a.pw / (float)a.w, a.pw);
+      disp = resize_sample(a.pl_para + (long long)bi * a.ph * a.pw, a.pw, 1, 0, ya, xa) * 2.0f;
+    }
+  } else {
+    disp = a.disp[gp];
+  }
   float oqy[J], oqx[J];
 #pragma unroll
   for (int jj = 0; jj < J; ++jj) {
@@ -104,7 +118,7 @@ __device__ __forceinline__ void dscv_pixel(const DscvArgs& a, const M4dMotion& m
   const float4 c1v = *reinterpret_cast<const float4*>(a.c1 + gp * C + 4 * q);
   const float c1a = m4d_round_half(c1v.x), c1b = m4d_round_half(c1v.y);
   const float c1c = m4d_round_half(c1v.z), c1d = m4d_round_half(c1v.w);
-  const float* dpt = a.disp_prev_t + (long long)bi * hw;
+  const float* dpt = (ONFLY ? a.depth_prev_t : a.disp_prev_t) + (long long)bi * hw;
   const bool seq16 = a.cv_accum != 0;
   float* o = a.cv + gp * a.cv_stride + kk * NCP;
 
@@ -143,7 +157,12 @@ __device__ __forceinline__ void dscv_pixel(const DscvArgs& a, const M4dMotion& m
           const bool centre = (t == r) && a.log_center != nullptr;
           if (a.prev_disp != nullptr || centre) {
             const float* d0 = dpt + (long long)y0[u] * a.w + x0[u];                 // the extra channel of :268
-            const float wd = m4d_lerp2(d0[0], d0[1], d0[a.w], d0[a.w + 1], ax[u], ay[u]);
+            float c00 = d0[0], c01 = d0[1], c10 = d0[a.w], c11 = d0[a.w + 1];
+            if (ONFLY) {                                                            // prev_d2para (:218) at the four corners
+              c00 = m4d_prev_d2para_px(m, c00, x0[u], y0[u]);     c01 = m4d_prev_d2para_px(m, c01, x0[u] + 1, y0[u]);
+              c10 = m4d_prev_d2para_px(m, c10, x0[u], y0[u] + 1); c11 = m4d_prev_d2para_px(m, c11, x0[u] + 1, y0[u] + 1);
+            }
+            const float wd = m4d_lerp2(c00, c01, c10, c11, ax[u], ay[u]);
             if (a.prev_disp) a.prev_disp[gp * NCP + t] = wd;
             if (centre) a.log_center[gp * a.log_stride] = logf(wd * a.log_scale);   // m4depth_network.py:238
           }
@@ -174,7 +193,7 @@ __device__ __forceinline__ void dscv_pixel(const DscvArgs& a, const M4dMotion& m
 }
 
 // Wave kernel: pixels in raster order, 64/LP per wave, corners gathered through L2/L1.
-template <int LP, int G, int NCP>
+template <int LP, int G, int NCP, bool ONFLY = false>
 __device__ __forceinline__ void dscv_wave_body(const DscvArgs& a, int blk, int nb, int bi) {
   constexpr int PPW = 64 / LP;                 // pixels per wave
   constexpr int C = 4 * LP;
@@ -192,7 +211,7 @@ __device__ __forceinline__ void dscv_wave_body(const DscvArgs& a, int blk, int n
   DscvGlobalFetch fetch;
   fetch.base = a.c2 + (long long)bi * hw * C + 4 * q;
   fetch.w = a.w; fetch.C = C; fetch.rs = (long long)a.w * C;
-  dscv_pixel<LP, G, NCP>(a, m, bi, pix % a.w, pix / a.w, active, q, q % G, q / G, slot * LP, fetch);
+  dscv_pixel<LP, G, NCP, DscvGlobalFetch, ONFLY>(a, m, bi, pix % a.w, pix / a.w, active, q, q % G, q / G, slot * LP, fetch);
 }
 
 template <int LP, int G, int NCP>
@@ -208,6 +227,20 @@ dscv_sncv_small_kernel(const DscvArgs a, int nb, int b, const m4d_sncv::SncvArgs
   const int blk = blockIdx.x;
   if (blk < nb * b) dscv_wave_body<LP, G, NCP>(a, blk % nb, nb, blk / nb);
   else m4d_sncv::sncv_small_body<4 * G>(sa, total_px, blk - nb * b, nb_sncv);
+}
+
+// ... and with the level's opening glue as well (m4d_level_front_small): [DSCV | SNCV | level_pre] workgroups in ONE launch.  The
+// features arrive per-cut normalised (m4d_normalize_levels, off the level's latency chain), the DSCV evaluates the two maps
+// level_pre would have written (para_prev_l, para_prev_t) where it needs them, level_pre's workgroups write the log / memory
+// features of the refiner input.  Nothing depends on anything else inside the launch.
+template <int LP, int G, int NCP>
+__global__ void __launch_bounds__(256)
+level_front_small_kernel(const DscvArgs a, int nb, int b, const m4d_sncv::SncvArgs sa, int total_px, int nb_sncv,
+                         const m4d_level::LevelPreArgs pa, int pre_gx) {
+  const int blk = blockIdx.x;
+  if (blk < nb * b) dscv_wave_body<LP, G, NCP, true>(a, blk % nb, nb, blk / nb);
+  else if (blk < nb * b + nb_sncv) m4d_sncv::sncv_small_body<4 * G>(sa, total_px, blk - nb * b, nb_sncv);
+  else m4d_level::level_pre_body(pa, (blk - nb * b - nb_sncv) % pre_gx, (blk - nb * b - nb_sncv) / pre_gx, pre_gx);
 }
 
 // Stage a WH x WW window of an NHWC image into LDS (pixel stride C+4 floats).  A window
@@ -765,6 +798,78 @@ bool launch_wave_sncv(const DscvArgs& a, int b, const m4d_sncv::SncvArgs& sa, hi
   else if (a.r == 2) m4d_launch((dscv_sncv_small_kernel<LP, G, 5>), grid, dim3(256), 0, s, a, nb, b, sa, total_px, nb_sncv);
   else return false;
   return true;
+}
+
+template <int LP, int G>
+bool launch_front_small(const DscvArgs& a, int b, const m4d_sncv::SncvArgs& sa, const m4d_level::LevelPreArgs& pa, hipStream_t s) {
+  constexpr int PPW = 64 / LP;
+  const int hw = a.h * a.w;
+  const int nb = (hw + 4 * PPW - 1) / (4 * PPW);
+  const int nb_sncv = (int)m4d_sncv::sncv_small_blocks(sa, b);
+  int pre_gx = m4d_blocks((long long)hw, 256);
+  if (pre_gx > 4096) pre_gx = 4096;
+  const dim3 grid((unsigned)(nb * b + nb_sncv + pre_gx * b));
+  const int total_px = b * hw;
+  if (a.r == 4) m4d_launch((level_front_small_kernel<LP, G, 9>), grid, dim3(256), 0, s, a, nb, b, sa, total_px, nb_sncv, pa, pre_gx);
+  else if (a.r == 2) m4d_launch((level_front_small_kernel<LP, G, 5>), grid, dim3(256), 0, s, a, nb, b, sa, total_px, nb_sncv, pa, pre_gx);
+  else return false;
+  return true;
+}
+
+static bool front_small_shape(int C, int nbre_cuts, int dscv_range, int sncv_range) {
+  if (C <= 0 || nbre_cuts <= 0 || C % nbre_cuts != 0 || (C / nbre_cuts) % 4 != 0) return false;
+  if (!(dscv_range == 4 || dscv_range == 2) || sncv_range < 0) return false;
+  const int lp = C / 4, g = C / nbre_cuts / 4;
+  return (lp == 24 && g == 6) || (lp == 32 && g == 8) || (lp == 48 && g == 6) || (lp == 16 && g == 8) || (lp == 8 && g == 4) ||
+         (lp == 4 && g == 4);
+}
+
+extern "C" int m4d_level_front_small_supported(int C, int nbre_cuts, int dscv_range, int sncv_range) {
+  return (front_small_shape(C, nbre_cuts, dscv_range, sncv_range) && g_dscv_variant == 1) ? 1 : 0;
+}
+
+extern "C" int m4d_level_front_small(const float* norm_f, const float* prev_f, const float* depth_prev_t,
+                                     const float* prev_l_parallax, const float* prev_l_other, int ph, int pw,
+                                     const float* rot, int rot_c, const float* trans, const float* cam_f, const float* cam_c,
+                                     int b, int h, int w, int C, int nbre_cuts, int dscv_range, int sncv_range, int cv_accum,
+                                     float* f_input, int f_stride, float log_scale, void* stream) {
+  M4D_CHECK_ARG(norm_f && prev_f && depth_prev_t && rot && trans && cam_f && cam_c && f_input);
+  M4D_CHECK_ARG(b > 0 && h >= 2 && w >= 2 && (rot_c == 3 || rot_c == 4) && (cv_accum == 0 || cv_accum == 1));
+  M4D_CHECK_ARG(front_small_shape(C, nbre_cuts, dscv_range, sncv_range) && g_dscv_variant == 1);
+  M4D_CHECK_ARG((prev_l_parallax == nullptr) == (prev_l_other == nullptr));
+  if (prev_l_parallax) M4D_CHECK_ARG(ph > 0 && pw > 0);
+  M4D_CHECK_ARG(((((uintptr_t)norm_f | (uintptr_t)prev_f)) & 15u) == 0);
+  const int k = nbre_cuts, ncp = 2 * dscv_range + 1, mo = 2 * sncv_range + 1;
+  const int f_in = ncp * k + 1 + 4 + mo * mo * k + 1;            // cv | log para_l | other(4) | sncv | log para_t
+  M4D_CHECK_ARG(f_stride >= f_in);
+  const int log_off = ncp * k, other_off = log_off + 1, sncv_off = log_off + 5;
+  DscvArgs a;
+  a.c1 = norm_f; a.c2 = prev_f; a.disp_prev_t = nullptr; a.disp = nullptr;
+  a.rot = rot; a.rot_c = rot_c; a.trans = trans; a.cam_f = cam_f; a.cam_c = cam_c;
+  a.h = h; a.w = w; a.C = C; a.r = dscv_range; a.k = k; a.nc = C / k; a.cv_accum = cv_accum;
+  a.cv = f_input; a.cv_stride = f_stride; a.prev_disp = nullptr; a.log_center = f_input + (f_in - 1);
+  a.log_stride = f_stride; a.log_scale = log_scale; a.index_out = nullptr; a.ablate = g_dscv_ablate;
+  a.pl_para = prev_l_parallax; a.ph = ph; a.pw = pw; a.depth_prev_t = depth_prev_t;
+  m4d_sncv::SncvArgs sa;
+  sa.c1 = norm_f; sa.c2 = norm_f; sa.h = h; sa.w = w; sa.C = C; sa.r = sncv_range; sa.d = 1; sa.k = k; sa.nc = C / k;
+  sa.out = f_input + sncv_off; sa.out_stride = f_stride; sa.th = sa.tw = sa.tiles_x = 0;
+  m4d_level::LevelPreArgs pa;
+  pa.pl_depth = nullptr; pa.pl_para = prev_l_parallax; pa.pl_other = prev_l_other; pa.ph = ph; pa.pw = pw;
+  pa.depth_prev_t = nullptr; pa.trans = trans; pa.cam_f = cam_f; pa.cam_c = cam_c; pa.h = h; pa.w = w;
+  pa.para_prev_l = nullptr; pa.depth_prev_l = nullptr; pa.other_prev_l = nullptr; pa.para_prev_t = nullptr;
+  pa.f_input = f_input; pa.f_stride = f_stride; pa.log_off = log_off; pa.other_off = other_off; pa.log_scale = log_scale;
+  pa.depth_state_reset = nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  const int lp = C / 4, g = C / k / 4;
+  bool done = false;
+  if (lp == 24 && g == 6) done = launch_front_small<24, 6>(a, b, sa, pa, s);        // C=96  k=4
+  else if (lp == 32 && g == 8) done = launch_front_small<32, 8>(a, b, sa, pa, s);   // C=128 k=4
+  else if (lp == 48 && g == 6) done = launch_front_small<48, 6>(a, b, sa, pa, s);   // C=192 k=8
+  else if (lp == 16 && g == 8) done = launch_front_small<16, 8>(a, b, sa, pa, s);   // C=64  k=2
+  else if (lp == 8 && g == 4) done = launch_front_small<8, 4>(a, b, sa, pa, s);     // C=32  k=2
+  else if (lp == 4 && g == 4) done = launch_front_small<4, 4>(a, b, sa, pa, s);     // C=16  k=1
+  if (!done) return (int)hipErrorInvalidValue;
+  return M4D_LAUNCH_RESULT();
 }
 
 // m4d_dscv_fwd followed by m4d_sncv_fwd(c1, c1, ...) of the same level; on small maps (<= 6000 pixels, the pyramid's

@@ -162,6 +162,11 @@ lat_conv_mw_max_pixels = int(_os.environ.get("M4D_LAT_CONV_MW_PX", "0"))
 
 # DSCV and SNCV of a small level (<= 6000 pixels) in one launch (m4d_dscv_sncv_fwd).  0 = two launches.
 fused_cost_volumes = _os.environ.get("M4D_FUSED_COST_VOLUMES", "1") == "1"
+# ... and the level's opening glue (level_pre) in that launch too (m4d_level_front_small, round 6): a coarse level opens with ONE
+# launch.  Its features arrive per-cut normalised: the normalisation depends on the encoder alone, so the coarse levels' maps of all
+# frames of an encoder batch are normalised in one launch right behind the encoder (m4d_normalize_levels), off the levels'
+# coarse-to-fine latency chains.  0 = level_pre_normalize + dscv_sncv (two dependent launches per level).  Same bits.
+small_level_front = _os.environ.get("M4D_SMALL_LEVEL_FRONT", "1") == "1"
 # level_pre and the per-cut normalisation of a level in one launch (m4d_level_pre_normalize).  0 = two launches.
 fused_level_front = _os.environ.get("M4D_FUSED_LEVEL_FRONT", "1") == "1"
 
@@ -734,7 +739,29 @@ class DepthEstimatorLevel(torch.nn.Module):
             return out
         return f_map
 
-    def forward(self, curr_f_maps, prev_l_est, rot, trans, camera, new_traj, prev_f_maps=None, prev_t_depth=None):
+    def _front_by_size(self, b, h, w, c):
+        """Does a [b,h,w,c] map of this level take the big-tile fused front (``m4d_level_front_r``)?  (size and shape part of
+        ``forward``'s decision)"""
+        k = self.nbre_cuts
+        F_st = (self.f_in + 7) // 8 * 8 if pad_refiner_input else self.f_in
+        return (fused_front and b * h * w > (fused_front_min_pixels if k <= 2 else max(fused_front_min_pixels, fused_front_coarse_min_pixels))
+                and bool(lib.m4d_level_front_supported(c, k, self.dscv_range, self.sncv_range, F_st)))
+
+    def wants_prenormalized(self, b, h, w, c):
+        """Would a full (non-reset) inference step of this level on a [b,h,w,c] map open with ``m4d_level_front_small`` -- i.e.
+        should the caller hand it per-cut normalised features (``forward(..., curr_f_normalized=...)``,
+        ``network_ops.normalize_levels``)?"""
+        ab = self.ablation
+        return (small_level_front and fused_cost_volumes and fused_level_front and not self.is_training
+                and ab.SNCV and ab.time_recurr and ab.normalize_features and ab.level_memory
+                and b * h * w <= 6000 and not self._front_by_size(b, h, w, c)
+                and bool(lib.m4d_pyramid_reset_supported(c, self.nbre_cuts))
+                and bool(lib.m4d_level_front_small_supported(c, self.nbre_cuts, self.dscv_range, self.sncv_range)))
+
+    def forward(self, curr_f_maps, prev_l_est, rot, trans, camera, new_traj, prev_f_maps=None, prev_t_depth=None,
+                curr_f_normalized=None):
+        """``curr_f_normalized`` (inference, optional): the per-cut normalised ``curr_f_maps`` computed ahead of the level
+        (``wants_prenormalized``): the level then opens with ONE launch and the tensor becomes its ``prev_f_maps``."""
         curr_f_maps = as_f32(curr_f_maps, "curr_f_maps")
         b, h, w, c = curr_f_maps.shape
         dev = curr_f_maps.device
@@ -755,6 +782,10 @@ class DepthEstimatorLevel(torch.nn.Module):
                      and ab.SNCV and ab.time_recurr and ab.normalize_features and ab.level_memory
                      and b * h * w > (fused_front_min_pixels if k <= 2 else max(fused_front_min_pixels, fused_front_coarse_min_pixels))
                      and bool(lib.m4d_level_front_supported(c, k, self.dscv_range, self.sncv_range, F_st)))
+        # a coarse level whose features arrive normalised: level_pre + DSCV + SNCV in one launch (m4d_level_front_small)
+        use_small = (curr_f_normalized is not None and not use_front and use_state and not nt and dev.type == "cuda"
+                     and kernel_timer_allows_small_front() and self.wants_prenormalized(b, h, w, c)
+                     and tuple(curr_f_normalized.shape) == (b, h, w, c))
         # normalised current features land in the spare state buffer: after the level
         # ran they ARE the new prev_f_maps (:211, :259) -- a pointer swap, not a copy.
         # (inference, state mode) the normalisation shares a launch with level_pre below: both open the level, neither
@@ -762,6 +793,8 @@ class DepthEstimatorLevel(torch.nn.Module):
         norm_job = None
         if use_front:
             curr_f = self._spare_f
+        elif use_small:
+            curr_f = as_f32(curr_f_normalized, "curr_f_normalized")
         elif (fused_level_front and self.ablation.normalize_features and dev.type == "cuda" and not self.is_training
                 and prev_f_maps is None and self._spare_f is not None and c % self.nbre_cuts == 0):
             curr_f = self._spare_f
@@ -794,7 +827,7 @@ class DepthEstimatorLevel(torch.nn.Module):
         sncv_off = log_off + 1 + (4 if self.ablation.level_memory else 0)
         scale = float(2.0 ** self.lvl_mul)
         # "preprocessor" (:216-242): upsample coarser estimate, prev_d2para, log / memory features
-        if not use_front:
+        if not use_front and not use_small:
             para_prev_l, depth_prev_l, other_prev_l, para_prev_t = _timed("pre", self.lvl_depth, lambda: nops.level_pre(
                 prev_l_est, as_f32(prev_t_depth, "prev_t_depth"), trans, camera, b, h, w, dev,
                 f_input=f_input, log_off=log_off, other_off=other_off, log_scale=scale, normalize=norm_job))
@@ -822,6 +855,19 @@ class DepthEstimatorLevel(torch.nn.Module):
                 dptr(pp), dptr(po), ph, pw, dptr(rot_t), rot_t.shape[1], dptr(tr), dptr(cf), dptr(cc),
                 b, h, w, c, k, self.dscv_range, self.sncv_range, _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr), F_st, scale,
                 stream_ptr())), "m4d_level_front_r")
+            para_prev_t = para_prev_l = None
+        elif use_small:
+            pp = po = None
+            ph = pw = 0
+            if prev_l_est is not None:
+                pp = as_f32(prev_l_est["parallax"], "prev_l_est['parallax']")
+                po = as_f32(prev_l_est["other"], "prev_l_est['other']")
+                ph, pw = pp.shape[1:3]
+            # (timed as "dscv_sncv" by bench.py: the launch that opens the level in the graph)
+            check(_timed("dscv_sncv", self.lvl_depth, lambda: lib.m4d_level_front_small(
+                dptr(curr_f), dptr(prev_f), dptr(as_f32(prev_t_depth, "prev_t_depth")), dptr(pp), dptr(po), ph, pw,
+                dptr(rot_t), rot_t.shape[1], dptr(tr), dptr(cf), dptr(cc), b, h, w, c, k, self.dscv_range, self.sncv_range,
+                _CV_ACCUM[self.cv_accum], ctypes.c_void_p(fin_ptr), F_st, scale, stream_ptr())), "m4d_level_front_small")
             para_prev_t = para_prev_l = None
         elif fused_cost_volumes and self.ablation.SNCV and dev.type == "cuda" and b * h * w <= 6000:
             # small maps: both (independent) cost volumes in one launch (timed as "dscv_sncv" by bench.py: the launch the graph replays)
@@ -865,8 +911,19 @@ class DepthEstimatorLevel(torch.nn.Module):
             para_curr_l, depth, other = _timed("post", self.lvl_depth, lambda: nops.level_post(
                 prev_out[0], rot_t, tr, {"f": cf, "c": cc}, scale, depth_state=self.depth_prev_t if not self.is_training else None))
         if not self.is_training:
-            self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
+            if use_small:
+                # the caller's normalised tensor IS the new prev_f_maps (:211, :259); the level's own spare buffer stays the spare
+                # (when the old prev_f_maps was the level's own second buffer it is simply dropped: _ensure_state keeps the shape)
+                self.prev_f_maps = curr_f
+            else:
+                self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
         return {"other": other, "depth": depth, "parallax": para_curr_l}
+
+
+def kernel_timer_allows_small_front():
+    """(bench.py's per-kernel timer brackets the launches the graph replays: nothing to switch off -- kept as the one place
+    where a measurement mode could ask for the separate kernels)"""
+    return True
 
 
 class DepthEstimatorPyramid(torch.nn.Module):
@@ -881,6 +938,28 @@ class DepthEstimatorPyramid(torch.nn.Module):
         self.is_training = settings["is_training"]
         self.is_unsupervised = False
 
+    def prenormalize(self, pyr, bsz):
+        """The per-cut normalised feature maps of the levels that open with ``m4d_level_front_small`` (``wants_prenormalized``),
+        for a feature pyramid ``pyr`` (one tensor per level, possibly several frames stacked along the batch axis; ``bsz`` = the
+        sequence batch) in ONE launch: [normalised tensor or None per level], or None when no level wants them.  Issued right
+        behind the encoder: the normalisation does not depend on the decoder's state, so it leaves the levels' latency chains."""
+        if self.is_training or pyr is None or not isinstance(pyr[0], torch.Tensor) or not pyr[0].is_cuda:
+            return None
+        jobs = [(lvl, t) for lvl, t in enumerate(pyr[:len(self.levels)])
+                if t.dim() == 4 and self.levels[lvl].wants_prenormalized(bsz, t.shape[1], t.shape[2], t.shape[3])]
+        if not jobs:
+            return None
+        outs = _timed("norm", "levels", lambda: nops.normalize_levels([(t, self.levels[lvl].nbre_cuts) for lvl, t in jobs]))
+        res = [None] * len(pyr)
+        for (lvl, _), o in zip(jobs, outs):
+            res[lvl] = o
+        return res
+
+    @staticmethod
+    def _frame_slice(npyr, j, bsz):
+        """Frame ``j``'s slices of a stacked ``prenormalize`` result (None stays None)."""
+        return None if npyr is None else [None if t is None else t[j * bsz:(j + 1) * bsz] for t in npyr]
+
     def pipeline_streams_for(self, traj_samples, dev):
         """Number of HIP streams the (frame, level) wavefront would use for this call; 0 = single stream."""
         n_streams = level_pipeline_streams if (dev.type == "cuda" and not self.is_training and len(traj_samples) > 1
@@ -892,9 +971,10 @@ class DepthEstimatorPyramid(torch.nn.Module):
             return frames
         return 0 if torch.cuda.is_current_stream_capturing() else n_streams      # eager: streams reused round-robin
 
-    def forward(self, f_maps_pyrs, traj_samples, camera, training=False, encoder=None):
+    def forward(self, f_maps_pyrs, traj_samples, camera, training=False, encoder=None, n_maps_pyrs=None):
         """``f_maps_pyrs`` = per-frame feature pyramids, or None with ``encoder`` given: the pipelined path then
-        encodes every frame on that frame's stream (overlapping with the decoder of the frames before it)."""
+        encodes every frame on that frame's stream (overlapping with the decoder of the frames before it).
+        ``n_maps_pyrs`` (optional) = per frame the ``prenormalize``d maps of that frame's pyramid (None entries allowed)."""
         d_est_seq = []
         n_lvls = len(self.levels)
         # level-local intrinsics camera / 2**depth (:300-302): the same for every sequence step
@@ -906,9 +986,11 @@ class DepthEstimatorPyramid(torch.nn.Module):
                              for lvl in range(n_lvls)]
         n_pipe = self.pipeline_streams_for(traj_samples, dev)
         if n_pipe >= 2:
-            return self._forward_pipelined(f_maps_pyrs, traj_samples, local_cameras, n_pipe, encoder)
+            return self._forward_pipelined(f_maps_pyrs, traj_samples, local_cameras, n_pipe, encoder, n_maps_pyrs)
         if f_maps_pyrs is None:
             f_maps_pyrs = [encoder(sample['RGB_im']) for sample in traj_samples]
+        if n_maps_pyrs is None:
+            n_maps_pyrs = [None] * len(f_maps_pyrs)
         for seq_i, (f_pyr_curr, sample) in enumerate(zip(f_maps_pyrs, traj_samples)):
             rot = sample['rot']
             trans = sample['trans']
@@ -928,9 +1010,11 @@ class DepthEstimatorPyramid(torch.nn.Module):
                     d_est_prev = d_est_seq[-1][-l - 1]["depth"]
                 local_camera = local_cameras[lvl]
                 d_est = None if d_est_curr is None else dict(d_est_curr[-1])
-                level.sequence_position = seq_i
+                if l == 0 and n_maps_pyrs[seq_i] is None and not self.is_training:
+                    n_maps_pyrs[seq_i] = self.prenormalize(f_pyr_curr, f_pyr_curr[0].shape[0])   # (a frame that arrived without)
+                n_curr = None if n_maps_pyrs[seq_i] is None else n_maps_pyrs[seq_i][lvl]
                 est = level(f_maps_curr, d_est, rot, trans, local_camera, sample["new_traj"],
-                            prev_f_maps=f_maps_prev, prev_t_depth=d_est_prev)
+                            prev_f_maps=f_maps_prev, prev_t_depth=d_est_prev, curr_f_normalized=n_curr)
                 d_est_curr = [est] if d_est_curr is None else d_est_curr + [est]
                 cnter -= 1.
             d_est_seq.append(d_est_curr[::-1])
@@ -957,7 +1041,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
             self.levels[lvl].reset_commit()
         return ests
 
-    def _forward_pipelined(self, f_maps_pyrs, traj_samples, local_cameras, n_streams, encoder=None):
+    def _forward_pipelined(self, f_maps_pyrs, traj_samples, local_cameras, n_streams, encoder=None, n_maps_pyrs=None):
         """The same loop as a wavefront over (frame, level) on ``n_streams`` HIP streams: frame t runs on
         stream t % n; before level l of frame t it waits for the event recorded after level l of frame
         t-1 (the level's temporal memory).  Inside a stream the levels stay in coarse-to-fine order.
@@ -1005,6 +1089,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
                 st.wait_event(fork)                   # encoder outputs / inputs are produced on the main stream
         done = {}
         late_encoder = None
+        n_pyrs = list(n_maps_pyrs) if n_maps_pyrs is not None else [None] * n_fr
         f_pyrs = [None] * n_fr
         d_est = [None] * n_fr                         # per frame: estimates so far, coarse -> fine
         # (Measured, tools/step_profile.py + tools/ab_bench.sh: the late encoder batch below is independent of the first
@@ -1035,14 +1120,17 @@ class DepthEstimatorPyramid(torch.nn.Module):
                 if l == 0:
                     if f_maps_pyrs is None:          # per-frame encoder on the frame's own stream
                         f_pyrs[seq_i] = encoder(sample['RGB_im'])
+                        n_pyrs[seq_i] = self.prenormalize(f_pyrs[seq_i], sample['RGB_im'].shape[0])
                     elif f_maps_pyrs[seq_i] is not None:
                         f_pyrs[seq_i] = f_maps_pyrs[seq_i]
                     elif f_pyrs[seq_i] is None:      # first frame of the late encoder batch: encode all remaining frames here
                         rest = [i for i in range(seq_i, n_fr) if f_maps_pyrs[i] is None]
                         bsz = sample['RGB_im'].shape[0]
                         tail = encoder(_stack_frames([traj_samples[i] for i in rest]))
+                        ntail = self.prenormalize(tail, bsz)     # the coarse levels' normalised maps of the whole batch: one launch
                         for j, i in enumerate(rest):
                             f_pyrs[i] = [lvl[j * bsz:(j + 1) * bsz] for lvl in tail]
+                            n_pyrs[i] = self._frame_slice(ntail, j, bsz)
                         enc_done = torch.cuda.Event()
                         enc_done.record(st)
                         keep.append(enc_done)
@@ -1069,7 +1157,8 @@ class DepthEstimatorPyramid(torch.nn.Module):
                     continue
                 prev = None if d_est[seq_i] is None else dict(d_est[seq_i][-1])
                 est = self.levels[lvl](f_pyrs[seq_i][lvl], prev, sample['rot'], sample['trans'], local_cameras[lvl],
-                                       sample["new_traj"])
+                                       sample["new_traj"],
+                                       curr_f_normalized=None if n_pyrs[seq_i] is None else n_pyrs[seq_i][lvl])
                 ev = torch.cuda.Event()
                 ev.record(st)
                 done[(seq_i, lvl)] = ev
@@ -1264,6 +1353,7 @@ class M4Depth(torch.nn.Module):
         n_fr = len(traj_samples)
         dev = camera["f"].device
         late_encoder_fn = self.encoder
+        n_maps_pyrs = None
         same_shape = all(s['RGB_im'].shape == traj_samples[0]['RGB_im'].shape for s in traj_samples)
         self.encoder.set_sequence_batch(traj_samples[0]['RGB_im'].shape[0])
         if pipeline_encoder_per_frame and self.d_estimator.pipeline_streams_for(traj_samples, dev) >= 2:
@@ -1284,13 +1374,18 @@ class M4Depth(torch.nn.Module):
             else:
                 head = self.encoder(_stack_frames(traj_samples[:k]))
             f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in head] for t in range(k)] + [None] * (n_fr - k)
+            nhead = None if training else self.d_estimator.prenormalize(head, bsz)
+            n_maps_pyrs = [self.d_estimator._frame_slice(nhead, t, bsz) for t in range(k)] + [None] * (n_fr - k)
         elif n_fr > 1 and same_shape:
             bsz = traj_samples[0]['RGB_im'].shape[0]
             stacked = self.encoder(_stack_frames(traj_samples))
             f_maps_pyrs = [[lvl[t * bsz:(t + 1) * bsz] for lvl in stacked] for t in range(n_fr)]
+            nst = None if training else self.d_estimator.prenormalize(stacked, bsz)
+            n_maps_pyrs = [self.d_estimator._frame_slice(nst, t, bsz) for t in range(n_fr)]
         else:
             f_maps_pyrs = [self.encoder(sample['RGB_im']) for sample in traj_samples]
-        d_maps_pyrs = self.d_estimator(f_maps_pyrs, traj_samples, camera, training, encoder=late_encoder_fn)
+        d_maps_pyrs = self.d_estimator(f_maps_pyrs, traj_samples, camera, training, encoder=late_encoder_fn,
+                                       n_maps_pyrs=n_maps_pyrs)
         self.last_estimates = d_maps_pyrs          # per step, per level {depth, parallax, other} (fine -> coarse)
         if training:
             return d_maps_pyrs

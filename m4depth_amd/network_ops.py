@@ -113,6 +113,22 @@ def pyramid_reset(levels, b):
     return ests
 
 
+def normalize_levels(maps):
+    """The per-cut normalisation of several feature maps in ONE launch (m4d_normalize_levels; the bits of ``normalize_cuts``).
+    ``maps`` = [(tensor [n,h,w,C], cuts), ...] (at most 8); returns the normalised tensors in the same order."""
+    from ._lib import NormLevel
+    n = len(maps)
+    arr = (NormLevel * n)()
+    outs = []
+    for i, (x, cuts) in enumerate(maps):
+        x = as_f32(x, "features")
+        out = torch.empty_like(x)
+        arr[i] = NormLevel(dptr(x, "features").value, dptr(out).value, int(x.shape[0] * x.shape[1] * x.shape[2]), int(x.shape[3]), int(cuts))
+        outs.append(out)
+    check(lib.m4d_normalize_levels(arr, n, stream_ptr()), "m4d_normalize_levels")
+    return outs
+
+
 def level_post(refiner_out, rot, trans, camera, scale, depth_state=None):
     """Fused tail of a level (m4depth_network.py:247-260): returns (parallax,
     depth, other); ``depth_state`` (optional) receives the depth as well."""

@@ -51,15 +51,18 @@ def _build(dev, L, rd, rs, weights):
 
 
 @pytest.mark.parametrize("depth,h,w,coarse_front", [(1, 32, 48, False), (2, 16, 24, False), (3, 16, 24, False), (4, 8, 12, False),
-                                                     (6, 6, 10, False), (4, 8, 12, True), (5, 8, 12, True), (6, 6, 10, True)])
+                                                     (6, 6, 10, False), (4, 8, 12, True), (5, 8, 12, True), (6, 6, 10, True),
+                                                     (4, 8, 12, "small"), (5, 8, 12, "small"), (6, 6, 10, "small")])
 def test_level_step_teacher_forced(dev, depth, h, w, coarse_front, monkeypatch):
     """One full DepthEstimatorLevel step per level geometry with identical inputs on
     both sides; compares the assembled refiner input and the state handling.  Levels 1-3 go through the fused level front;
     levels 4-6 through the small-map kernels (their default at this size) and, with ``coarse_front``, through the fused
-    front instantiations of their geometries (the default from batch >= 4 at 384x1280)."""
+    front instantiations of their geometries (the default from batch >= 4 at 384x1280); ``"small"`` = the one-launch opening of a
+    coarse level on features normalised ahead of it (m4d_normalize_levels + m4d_level_front_small: what the batch-1 bench path
+    runs on levels 4-6 since round 6), against the oracle directly."""
     import m4depth_amd as M
-    from m4depth_amd import network as net
-    if coarse_front:
+    from m4depth_amd import network as net, network_ops as nops
+    if coarse_front is True:
         monkeypatch.setattr(net, "fused_front_coarse_min_pixels", 0)
     rng = np.random.default_rng(200 + depth)
     b = 2
@@ -82,7 +85,14 @@ def test_level_step_teacher_forced(dev, depth, h, w, coarse_front, monkeypatch):
         f = rng.standard_normal([b, h, w, C]).astype(F)
         nt = np.full([b], step == 0)
         eo = ol(f, prev, rot, trans, cam, nt)
-        eg = gl(to_dev(f, dev), to_dev(prev, dev), to_dev(rot, dev), to_dev(trans, dev), to_dev(cam, dev), nt)
+        nf = None
+        if coarse_front == "small":
+            assert gl.wants_prenormalized(b, h, w, C)
+            nf = nops.normalize_levels([(to_dev(f, dev), gl.nbre_cuts)])[0]
+        n0 = int(net.lib.m4d_launch_count())
+        eg = gl(to_dev(f, dev), to_dev(prev, dev), to_dev(rot, dev), to_dev(trans, dev), to_dev(cam, dev), nt, curr_f_normalized=nf)
+        if coarse_front == "small" and step > 0:
+            assert int(net.lib.m4d_launch_count()) - n0 == 7, "a coarse level = front + 5 convolutions + tail"
         assert_bits_equal(npy(gl.prev_f_maps), ol.prev_f_maps, "state: normalised features")
         if step == 0:
             for key in ("depth", "parallax", "other"):
