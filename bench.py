@@ -183,15 +183,16 @@ def _sha(paths):
     return hsh.hexdigest()[:16]
 
 
-def load_traffic(batch):
-    """{name: {"bytes": n, "kernel": "..."}} of profiles/pmc_traffic.json for this batch size, only entries whose kernel
-    sources are unchanged since the counters were collected (tools/pmc_traffic.py stamps a hash of them); + a note."""
+def load_traffic(batch, prefix=""):
+    """{name: {"bytes": n, "kernel": "..."}} of profiles/pmc_traffic.json for this batch size (``prefix`` "config4_": the
+    BASELINE configs[4] geometry), only entries whose kernel sources are unchanged since the counters were collected
+    (tools/pmc_traffic.py stamps a hash of them); + a note."""
     try:
         tj = json.load(open(TRAFFIC_JSON))
     except Exception:
         return {}, "no profiles/pmc_traffic.json"
     out, stale = {}, []
-    for name, ent in tj.get(f"batch{batch}", {}).items():
+    for name, ent in tj.get(f"{prefix}batch{batch}", {}).items():
         try:
             fresh = _sha(ent["sources"]) == ent["sources_sha"]
         except Exception:
@@ -251,8 +252,10 @@ def kernel_rooflines(args, batch, timer, net, eager_steps):
     summ = timer.summary()
     if (args.height, args.width, args.levels, args.dscv_range, args.sncv_range) == (384, 1280, 6, 4, 3):
         traffic, traffic_note = load_traffic(batch)
-    else:                                   # the PMC passes are collected at the level-1 geometry of the 384x1280 pyramid only
-        traffic, traffic_note = {}, "no PMC traffic for this geometry (tools/pmc_traffic.py measures the 384x1280 / ranges 4,3 pyramid)"
+    elif (args.height, args.width, args.levels, args.dscv_range, args.sncv_range) == (768, 2560, 6, 6, 6):
+        traffic, traffic_note = load_traffic(batch, "config4_")          # BASELINE configs[4]: tools/pmc_traffic.py --config4
+    else:                                   # the PMC passes are collected at the level-1 geometry of these two pyramids only
+        traffic, traffic_note = {}, "no PMC traffic for this geometry (tools/pmc_traffic.py measures the 384x1280 / ranges 4,3 and the 768x2560 / ranges 6,6 pyramids)"
     rep["traffic_note"] = traffic_note
 
     def tr(name):

@@ -19,6 +19,13 @@ products accumulated in float32, divided, rounded to float16 once; tf.norm = sqr
 bit-for-bit match here says "the restatement wires the same operands through the same operations in the same order as the
 reference's source", nothing about TF's kernels.  A stand-in library pins nothing; DESIGN.md section 2 says so.
 
+Round 6 extension: `m4depth_network.py` (FeaturePyramid incl. DomainNormalization, DispRefiner, DepthEstimatorLevel.call with its
+temporal memory, DepthEstimatorPyramid.call, M4Depth.call) and `metrics.py` run the same way, with a dozen more ops and a
+three-class stand-in for `tensorflow.keras` (Layer = build-once-then-call with add_weight; Conv2D = the oracle's own
+conv2d_same, so the convolution ARITHMETIC is shared and what is compared is everything around it; metrics.Mean = total / count):
+a 3-level model steps through a reset frame and two full frames with the oracle's weights, every level's depth / parallax /
+other of every frame, the final depth and the seven metrics compared with oracle.M4Depth / oracle.metrics_batch.
+
 Nothing of this travels: the script reads /root/reference (absent on the GPU box), is not imported by any `-m gpu` test, by
 smoke() or by bench.py; `tests/test_oracle.py::test_reference_wiring_crosscheck` runs it when /root/reference exists and
 skips otherwise.  Run by hand:  python tests/golden/crosscheck_reference_wiring.py  -> prints the report (also kept as
@@ -154,6 +161,27 @@ class T:
     def __matmul__(self, o):
         return _matmul(self, o)
 
+    def __bool__(self):
+        return bool(self.a)
+
+    def copy(self):
+        return T(self.a.copy())
+
+
+class _Var(T):
+    """tf.Variable / Layer.add_weight: a tensor with assign()."""
+
+    def __init__(self, a):
+        self.a = np.array(_np(a))
+
+    def assign(self, v):
+        self.a = np.array(_np(v), dtype=self.a.dtype).reshape(self.a.shape)
+        return self
+
+    def assign_add(self, v):
+        self.a = self.a + np.asarray(_np(v), self.a.dtype)
+        return self
+
 
 def _reduce_mean(x, axis=None):
     a = _np(x)
@@ -213,6 +241,130 @@ def _scope(*_a, **_k):
     yield
 
 
+def _axes(axis, ndim):
+    if axis is None:
+        return tuple(range(ndim))
+    return tuple(a % ndim for a in (axis if isinstance(axis, (list, tuple)) else [axis]))
+
+
+def _mean_axes(x, axis=None, keepdims=False, name=None):
+    """tf.math.reduce_mean over several axes (DomainNormalization): numpy's float32 mean -- the oracle's [UNPINNED] choice."""
+    a = _np(x)
+    return T(a.mean(axis=_axes(axis, a.ndim), keepdims=keepdims, dtype=F))
+
+
+def _variance(x, axis=None, keepdims=False, name=None):
+    a = _np(x)
+    m = a.mean(axis=_axes(axis, a.ndim), keepdims=True, dtype=F)
+    return T(((a - m) * (a - m)).mean(axis=_axes(axis, a.ndim), keepdims=keepdims, dtype=F))
+
+
+def _l2_normalize(x, axis=-1, epsilon=1e-12):
+    a = _np(x)
+    ss = (a * a).sum(axis=axis, keepdims=True, dtype=F)
+    return T(a * (F(1.0) / np.sqrt(np.maximum(ss, F(epsilon)))))        # x * rsqrt(max(sum x^2, eps))
+
+
+def _linalg_normalize(x, axis=-1):
+    """(x / norm, norm), norm = sqrt of the SEQUENTIAL sum of squares along ``axis`` (the oracle's [UNPINNED] choice)."""
+    a = _np(x)
+    nrm = np.expand_dims(_norm(a, axis).a, axis)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return T(a / nrm), T(nrm)
+
+
+def _resize_bilinear_v1(x, size, align_corners=False):
+    """tf.compat.v1.image.resize_bilinear, legacy coordinates: src = dst * (in / out), lower = floor, upper = min(ceil, in - 1),
+    top + (bottom - top) * ylerp with top = tl + (tr - tl) * xlerp -- the legacy kernel's expressions, float32."""
+    a = _np(x)
+    b, ih, iw, c = a.shape
+    oh, ow = int(size[0]), int(size[1])
+
+    def axis(o_n, i_n):
+        src = np.arange(o_n, dtype=F) * F(F(i_n) / F(o_n))
+        lo = np.floor(src)
+        return lo.astype(np.int64), np.minimum(np.ceil(src).astype(np.int64), i_n - 1), (src - lo).astype(F)
+    ylo, yhi, yl = axis(oh, ih)
+    xlo, xhi, xl = axis(ow, iw)
+    tl, tr = a[:, ylo][:, :, xlo], a[:, ylo][:, :, xhi]
+    bl, br = a[:, yhi][:, :, xlo], a[:, yhi][:, :, xhi]
+    xl4, yl4 = xl.reshape(1, 1, -1, 1), yl.reshape(1, -1, 1, 1)
+    top = tl + (tr - tl) * xl4
+    bot = bl + (br - bl) * xl4
+    return T((top + (bot - top) * yl4).astype(F))
+
+
+def _resize_nearest(x, size, method=None):
+    """tf.image.resize(..., NEAREST_NEIGHBOR) of TF2 (half-pixel centres): src = min(floor((dst + 0.5) * in / out), in - 1)."""
+    a = _np(x)
+    ih, iw = a.shape[1:3]
+    oh, ow = int(size[0]), int(size[1])
+    iy = np.minimum(np.floor((np.arange(oh, dtype=F) + F(0.5)) * F(F(ih) / F(oh))).astype(np.int64), ih - 1)
+    ix = np.minimum(np.floor((np.arange(ow, dtype=F) + F(0.5)) * F(F(iw) / F(ow))).astype(np.int64), iw - 1)
+    return T(a[:, iy][:, :, ix])
+
+
+def _sum_all(x, axis=None):
+    """tf.reduce_sum over everything (metrics.py): float64 accumulation, one rounding (the oracle's [UNPINNED] choice)."""
+    if axis is not None:
+        raise NotImplementedError
+    return T(F(_np(x).astype(np.float64).sum()))
+
+
+class _Layer:
+    """tensorflow.keras.layers.Layer: build(input shape) once, then call()."""
+
+    def __init__(self, trainable=True, name=None, **_k):
+        self._built = False
+        self.trainable = trainable
+
+    def add_weight(self, name=None, shape=None, dtype="float32", initializer=None, trainable=True, **_k):
+        return _Var(initializer(list(shape), np.dtype(dtype)))
+
+    def add_loss(self, *_a, **_k):
+        pass
+
+    def build(self, input_shape):
+        pass
+
+    def __call__(self, *args, **kw):
+        if not self._built:
+            self.build(list(args[0].shape) if args and isinstance(args[0], T) else None)
+            self._built = True
+        return self.call(*args, **kw)
+
+
+class _Conv2D(_Layer):
+    """tensorflow.keras.layers.Conv2D(filters, 3, strides, padding='same'): kernel [3,3,Cin,Cout] / bias assigned from the
+    oracle's weight dict; the arithmetic IS the oracle's conv2d_same (shared on purpose: the convolution's summation order is
+    not what this script checks)."""
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding="valid", **_k):
+        super().__init__()
+        assert kernel_size == 3 and padding == "same"
+        self.filters, self.stride = filters, int(strides[0])
+        self.kernel = self.bias = None
+
+    def call(self, x):
+        from oracle import m4depth_oracle as O
+        return T(O.conv2d_same(_np(x), self.kernel, self.bias, self.stride))
+
+
+class _Mean(_Layer):
+    """tensorflow.keras.metrics.Mean."""
+
+    def __init__(self, name=None, **_k):
+        super().__init__()
+        self.name, self.total, self.count = name, F(0.0), 0
+
+    def update_state(self, value, sample_weight=None):
+        self.total = F(self.total + F(_np(value)))
+        self.count += 1
+
+    def result(self):
+        return T(F(self.total / F(max(self.count, 1))))
+
+
 def build_tensorflow_stub():
     tf = types.ModuleType("tensorflow")
     tf.float16 = tf.half = np.float16
@@ -251,7 +403,34 @@ def build_tensorflow_stub():
     tf.linalg = types.SimpleNamespace(matmul=_matmul)
     tf.nn = types.SimpleNamespace(leaky_relu=lambda x, alpha=0.2, name=None: T(np.where(_np(x) > 0, _np(x), _np(x) * _np(x).dtype.type(alpha))))
     tf.image = types.SimpleNamespace()                # (resize_bilinear: wrap_feature_block is dead code in the reference)
-    tf.compat = types.SimpleNamespace(v1=types.SimpleNamespace(name_scope=_scope))
+    tf.compat = types.SimpleNamespace(v1=types.SimpleNamespace(name_scope=_scope, image=types.SimpleNamespace(resize_bilinear=_resize_bilinear_v1)))
+    # ---- m4depth_network.py / metrics.py
+    tf.zeros = lambda shape, dtype=np.float32: T(np.zeros(_shape_arg(shape), np.dtype(dtype)))
+    tf.zeros_initializer = lambda: (lambda shape, dtype=np.float32: np.zeros(shape, np.dtype(dtype)))
+    tf.ones_initializer = lambda: (lambda shape, dtype=np.float32: np.ones(shape, np.dtype(dtype)))
+    tf.Variable = lambda initial_value=None, trainable=False, **_k: _Var(initial_value)
+    tf.exp = lambda x: T(np.exp(_np(x)))
+    tf.square = lambda x: T(_np(x) * _np(x))
+    tf.maximum = lambda a, b: T(np.maximum(_np(a), _like(_np(a), b)))
+    tf.greater = lambda a, b: T(_np(a) > _like(_np(a), b))
+    tf.reduce_sum = _sum_all
+    tf.math = types.SimpleNamespace(
+        reduce_mean=_mean_axes, reduce_variance=_variance, l2_normalize=_l2_normalize, log=lambda x: T(np.log(_np(x))),
+        abs=lambda x: T(np.abs(_np(x))), squared_difference=lambda a, b: T((_np(a) - _np(b)) * (_np(a) - _np(b))),
+        multiply_no_nan=lambda x, y: T(np.where(_np(y) != 0, _np(x), F(0.0)).astype(F)),
+        less=lambda a, b: T(_np(a) < _like(_np(a), b)))
+    tf.linalg.normalize = _linalg_normalize
+    tf.image.resize = _resize_nearest
+    tf.image.ResizeMethod = types.SimpleNamespace(NEAREST_NEIGHBOR="nearest")
+    tf.GradientTape = _scope
+    tf.summary = types.SimpleNamespace(image=lambda *a, **k: None)
+    keras = types.ModuleType("tensorflow.keras")
+    keras.layers = types.SimpleNamespace(Layer=_Layer, Conv2D=_Conv2D)
+    keras.models = types.SimpleNamespace(Model=_Layer)
+    keras.metrics = types.SimpleNamespace(Mean=_Mean)
+    keras.initializers = types.SimpleNamespace(HeNormal=lambda: None)
+    keras.regularizers = types.SimpleNamespace(L1=lambda l1=0.0: None, L2=lambda l2=0.0: (lambda w: 0.0))
+    tf.keras = keras
 
     # tensorflow.python.{framework,ops}.* as dense_image_warp.py imports them (the TF-addons origin of that file)
     ops = types.ModuleType("tensorflow.python.framework.ops")
@@ -285,18 +464,20 @@ def build_tensorflow_stub():
     opsmod.array_ops, opsmod.check_ops, opsmod.math_ops = array_ops, check_ops, math_ops
     python.framework, python.ops = framework, opsmod
     tf.python = python
-    return {"tensorflow": tf, "tensorflow.python": python, "tensorflow.python.framework": framework,
+    return {"tensorflow": tf, "tensorflow.keras": keras, "tensorflow.python": python, "tensorflow.python.framework": framework,
             "tensorflow.python.framework.constant_op": constant_op, "tensorflow.python.framework.dtypes": dtypes,
             "tensorflow.python.framework.ops": ops, "tensorflow.python.ops": opsmod,
             "tensorflow.python.ops.array_ops": array_ops, "tensorflow.python.ops.check_ops": check_ops,
             "tensorflow.python.ops.math_ops": math_ops}
 
 
-def load_reference():
-    """(depth_operations module, dense_image_warp module) of the reference, imported unmodified under the stand-in."""
+def load_reference(network=False):
+    """(depth_operations module, dense_image_warp module[, m4depth_network module, metrics module]) of the reference, imported
+    unmodified under the stand-in."""
     if not os.path.isfile(os.path.join(REF, "utils", "depth_operations.py")):
         raise FileNotFoundError(REF)
-    saved = {k: sys.modules.get(k) for k in list(build_tensorflow_stub()) + ["utils", "utils.dense_image_warp", "utils.depth_operations"]}
+    saved = {k: sys.modules.get(k) for k in list(build_tensorflow_stub()) + ["utils", "utils.dense_image_warp", "utils.depth_operations",
+                                                                          "m4depth_network", "metrics"]}
     sys.modules.update(build_tensorflow_stub())
     try:
         pkg = types.ModuleType("utils")
@@ -312,6 +493,16 @@ def load_reference():
             if name == "dense_image_warp":
                 pkg.dense_image_warp = m.dense_image_warp                # `from utils import dense_image_warp` = the function
             mods.append(m)
+        for name in ("depth_operations",):                               # `from utils.depth_operations import *` of the network file
+            pkg.__dict__.update({k: v for k, v in mods[1].__dict__.items() if not k.startswith("_")})
+        if network:
+            for name in ("m4depth_network", "metrics"):
+                spec = importlib.util.spec_from_file_location(name, os.path.join(REF, f"{name}.py"))
+                m = importlib.util.module_from_spec(spec)
+                sys.modules[name] = m
+                spec.loader.exec_module(m)
+                mods.append(m)
+            return mods[1], mods[0], mods[2], mods[3]
         return mods[1], mods[0]
     finally:
         for k, v in saved.items():
@@ -345,6 +536,68 @@ def _cmp(name, got, want, rows, tol=0.0):
     err[both_nan] = 0.0
     mx = float(np.nanmax(err))
     rows.append((name, mx <= tol, f"max rel. difference {mx:.3e} over {int((err > 0).sum())} of {err.size} elements (tolerance {tol:g})"))
+
+
+def run_network(rows):
+    """m4depth_network.py + metrics.py of the reference under the stand-in against oracle.M4Depth / oracle.metrics_batch: a
+    3-level model, batch 2, one reset frame + two full frames, the oracle's He-normal weights."""
+    sys.path.insert(0, ROOT)
+    from oracle import m4depth_oracle as O
+    from m4depth_amd import synthetic as S
+    with contextlib.redirect_stdout(open(os.devnull, "w")):              # (the reference prints "Seq sample ..." while tracing)
+        _, _, N, MT = load_reference(network=True)
+        L, b, Tn, H, Wd = 3, 2, 3, 32, 48
+        Wts = S.init_weights(L, seed=77)
+        samples, cam = S.make_sequence(b, Tn, H, Wd, seed=78)
+        model = N.M4Depth(nbre_levels=L)
+        enc = model.encoder
+        for i in range(L):
+            enc.conv_layers_s1[i].kernel, enc.conv_layers_s1[i].bias = Wts[f"enc.s1.{i}.kernel"], Wts[f"enc.s1.{i}.bias"]
+            enc.conv_layers_s2[i].kernel, enc.conv_layers_s2[i].bias = Wts[f"enc.s2.{i}.kernel"], Wts[f"enc.s2.{i}.bias"]
+        for i, lvl in enumerate(model.d_estimator.levels):
+            convs = list(lvl.disp_refiner.prep_conv_layers) + list(lvl.disp_refiner.est_d_conv_layers)
+            for j, cv in enumerate(convs):
+                cv.kernel, cv.bias = Wts[f"lvl.{i + 1}.conv.{j}.kernel"], Wts[f"lvl.{i + 1}.conv.{j}.bias"]
+        # DomainNormalization's scale / bias are created by its build(): run the encoder once, then overwrite them
+        tsamples = [{k: T(v) for k, v in s.items()} for s in samples]
+        tcam = {k: T(v) for k, v in cam.items()}
+        enc(tsamples[0]["RGB_im"])
+        enc.dn_layers[0].scale.assign(Wts["enc.dn.0.scale"].reshape(1, 1, 1, -1))
+        enc.dn_layers[0].bias.assign(Wts["enc.dn.0.bias"].reshape(1, 1, 1, -1))
+        # the reference's own sequence handling: M4Depth.call on the list of frames (inference: the levels keep their memory)
+        ref_out = model([tsamples, tcam], training=False)
+        # ... and once more frame by frame through DepthEstimatorPyramid to get at every level's estimate
+        model2 = N.M4Depth(nbre_levels=L)
+        for a_, b_ in zip(model.encoder.conv_layers_s1 + model.encoder.conv_layers_s2, model2.encoder.conv_layers_s1 + model2.encoder.conv_layers_s2):
+            b_.kernel, b_.bias = a_.kernel, a_.bias
+        for la, lb in zip(model.d_estimator.levels, model2.d_estimator.levels):
+            for a_, b_ in zip(list(la.disp_refiner.prep_conv_layers) + list(la.disp_refiner.est_d_conv_layers),
+                              list(lb.disp_refiner.prep_conv_layers) + list(lb.disp_refiner.est_d_conv_layers)):
+                b_.kernel, b_.bias = a_.kernel, a_.bias
+        model2.encoder(tsamples[0]["RGB_im"])
+        model2.encoder.dn_layers[0].scale.assign(Wts["enc.dn.0.scale"].reshape(1, 1, 1, -1))
+        model2.encoder.dn_layers[0].bias.assign(Wts["enc.dn.0.bias"].reshape(1, 1, 1, -1))
+        pyrs = [model2.encoder(s["RGB_im"]) for s in tsamples]
+        ref_seq = model2.d_estimator(pyrs, tsamples, tcam, False)
+        o_out, o_seq = O.M4Depth(Wts, L)(samples, cam)
+        opyr = O.feature_pyramid(samples[1]["RGB_im"], Wts, L)
+    for l in range(L):
+        _cmp(f"FeaturePyramid level {l + 1} (incl. DomainNormalization at level 0)", pyrs[1][l], opyr[l], rows)
+    for t in range(Tn):
+        for l in range(L):
+            for key in ("depth", "parallax", "other"):
+                _cmp(f"DepthEstimatorPyramid frame {t} level {l + 1} {key}", ref_seq[t][l][key], o_seq[t][l][key], rows)
+    _cmp("M4Depth.call depth (nearest x2 of the finest level)", ref_out["depth"], o_out["depth"], rows)
+    # metrics.py through the clipping of test_step (m4depth_network.py:462-470)
+    gt = np.clip(samples[-1]["depth"], 0.0, 80.0).astype(F)
+    est = np.clip(o_out["depth"], 0.001, 80.0).astype(F)
+    mets = [MT.AbsRelError(), MT.SqRelError(), MT.RootMeanSquaredError(), MT.RootMeanSquaredLogError(),
+            MT.ThresholdRelError(1), MT.ThresholdRelError(2), MT.ThresholdRelError(3)]
+    for m in mets:
+        m.update_state(T(gt), T(est))
+    want = O.metrics_batch(samples[-1]["depth"], o_out["depth"])
+    for m, w_ in zip(mets, want):
+        _cmp(f"metrics.py {m.name}", np.asarray(m.result().a, F).reshape(1), np.asarray(w_, F).reshape(1), rows, tol=2e-6)
 
 
 def run(verbose=True):
@@ -416,6 +669,7 @@ def run(verbose=True):
         for dil in (1, 2):
             _cmp(f"SNCV cost_volume  C={C} cuts={k} range=3 dilation={dil}",
                  R.cost_volume(T(c1), T(c2), 3, dilation_rate=dil, nbre_cuts=k), O.cost_volume(c1, c2, 3, dilation_rate=dil, nbre_cuts=k), rows)
+    run_network(rows)
     if verbose:
         for name, ok, msg in rows:
             print(f"{'ok  ' if ok else 'FAIL'}  {name:70s} {msg}")

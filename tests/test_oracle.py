@@ -261,7 +261,12 @@ def test_reference_wiring_crosscheck():
     /root/reference under a minimal numpy-backed module named ``tensorflow`` (tests/golden/crosscheck_reference_wiring.py: ~60
     array ops, each one numpy call), return what oracle/m4depth_oracle.py returns on the golden inputs and on seeded inputs --
     warp, get_rot_mat, get_coords_2d, the converters, prev_d2para, reproject (both aux outputs), recompute_depth, tile_in_batch,
-    the DSCV (1 / 2 / 4 cuts, ranges 4 and 2) and the SNCV (dilation 1 and 2) -- bit for bit.  It checks the restatement's
+    the DSCV (1 / 2 / 4 cuts, ranges 4 and 2) and the SNCV (dilation 1 and 2) -- bit for bit; and the reference's
+    m4depth_network.py (FeaturePyramid with DomainNormalization, DispRefiner, DepthEstimatorLevel.call with its temporal memory,
+    DepthEstimatorPyramid.call, M4Depth.call) stepped through a reset frame and two full frames of a 3-level model with the
+    oracle's weights gives every level's depth / parallax / other of every frame and the final depth of oracle.M4Depth bit for
+    bit (the convolution arithmetic is shared: the stand-in's Conv2D calls the oracle's conv2d_same), its metrics.py the seven
+    metrics of oracle.metrics_batch to float32 rounding.  It checks the restatement's
     WIRING (reshapes, axes, channel order, operand order) against the reference's text; it does not pin TensorFlow's internal
     arithmetic (the stand-in takes the oracle's documented [UNPINNED] choices), so the parity grade stays "unpinned".  Build
     container only: skipped where /root/reference does not exist (the GPU box)."""
@@ -275,6 +280,6 @@ def test_reference_wiring_crosscheck():
         pytest.skip("no /root/reference here (the GPU box): the cross-check is a build-container tool")
     rows = mod.run(verbose=False)
     bad = [(n, m) for n, ok, m in rows if not ok]
-    assert len(rows) >= 35 and not bad, bad
+    assert len(rows) >= 73 and not bad, bad
     import sys
     assert "tensorflow" not in sys.modules, "the stand-in must not stay installed after the check"

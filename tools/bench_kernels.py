@@ -25,11 +25,17 @@ def main():
     ap.add_argument("--which", default="dscv,sncv")
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--smooth", action="store_true", help="replace the parallax maps by smooth fields (coherent gathers)")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--dscv-range", type=int, default=4)
+    ap.add_argument("--sncv-range", type=int, default=3, help="with --height 768 --width 2560 --dscv-range 6 --sncv-range 6: BASELINE configs[4]")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    H, Wd, L = 384, 1280, 6
-    model = M.M4Depth(nbre_levels=L)
-    model.load_numpy_weights(S.init_weights(L, seed=42), dev)
+    H, Wd, L = args.height, args.width, 6
+    RD, RS = args.dscv_range, args.sncv_range
+    NCP, MO2 = 2 * RD + 1, (2 * RS + 1) ** 2
+    model = M.M4Depth(nbre_levels=L, dscv_range=RD, sncv_range=RS)
+    model.load_numpy_weights(S.init_weights(L, seed=42, dscv_range=RD, sncv_range=RS), dev)
     samples, cam = S.make_sequence(min(args.batch, 2), 3, H, Wd, seed=1235)
     reps = -(-args.batch // min(args.batch, 2))
 
@@ -54,16 +60,16 @@ def main():
     F_in = lvl.f_in
     f_input = torch.empty((b, h, w, F_in), device=dev)
     px = b * h * w
-    bytes_ = {"dscv": 4 * px * (2 * C + 2 + 9 * k + 1), "sncv": 4 * px * (C + 49 * k)}
+    bytes_ = {"dscv": 4 * px * (2 * C + 2 + NCP * k + 1), "sncv": 4 * px * (C + MO2 * k)}
     fin = f_input.data_ptr()
 
     def run_dscv():
         return lib.m4d_dscv_fwd(dptr(c1), dptr(c2), dptr(dpt), dptr(disp), dptr(rot), rot.shape[1], dptr(tr), dptr(cf),
-                                dptr(cc), b, h, w, C, 4, k, 0, ctypes.c_void_p(fin), F_in, None,
+                                dptr(cc), b, h, w, C, RD, k, 0, ctypes.c_void_p(fin), F_in, None,
                                 ctypes.c_void_p(fin + 4 * (F_in - 1)), F_in, 0.25, None, stream_ptr())
 
     def run_sncv():
-        return lib.m4d_sncv_fwd(dptr(c1), dptr(c1), b, h, w, C, 3, 1, k, ctypes.c_void_p(fin + 4 * (9 * k + 5)), F_in,
+        return lib.m4d_sncv_fwd(dptr(c1), dptr(c1), b, h, w, C, RS, 1, k, ctypes.c_void_p(fin + 4 * (NCP * k + 5)), F_in,
                                 stream_ptr())
 
     raw_f, prev_l, depth_t = lvl.last_front_inputs
@@ -76,9 +82,9 @@ def main():
         pp = prev_l["parallax"] if prev_l is not None else None
         po = prev_l["other"] if prev_l is not None else None
         ph, pw = (pp.shape[1], pp.shape[2]) if pp is not None else (0, 0)
-        return lib.m4d_level_front(dptr(raw_f), dptr(norm_out), dptr(c2), dptr(depth_t), dptr(pp), dptr(po), ph, pw,
-                                   dptr(rot), rot.shape[1], dptr(tr), dptr(cf), dptr(cc), b, h, w, C, k, 0,
-                                   dptr(f_front), F_st, 0.25, stream_ptr())
+        return lib.m4d_level_front_r(dptr(raw_f), dptr(norm_out), dptr(c2), dptr(depth_t), dptr(pp), dptr(po), ph, pw,
+                                     dptr(rot), rot.shape[1], dptr(tr), dptr(cf), dptr(cc), b, h, w, C, k, RD, RS, 0,
+                                     dptr(f_front), F_st, 0.25, stream_ptr())
 
     lib.m4d_dscv_set_ablation(args.ablate)
     counter = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -46,6 +46,17 @@ TARGETS = {
 }
 
 
+# BASELINE configs[4] (768x2560, search ranges 6 / 6, batch 1): the fused level-1 front with 13 hypotheses / a 13x13 window and the
+# level-1 128 -> 128 refiner layer at 384x1280 (3840 units: the persistent kernel) -- `--config4`, stored under "config4_batch1"
+C4_GEO = ["--height", "768", "--width", "2560", "--dscv-range", "6", "--sncv-range", "6"]
+TARGETS_CONFIG4 = {
+    "front": (["tools/bench_kernels.py", "--iters", "5", "--which", "front"] + C4_GEO, ["level_front_kernel"],
+              [CS + "m4d_front.hip", CS + "m4d_common.h"]),
+    "wino6_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "6", "--h", "384", "--w", "1280"],
+                         ["conv3x3_wino6_kernel", "conv3x3_wino6p_kernel"], [CS + "m4d_wino6.hip", CS + "m4d_wino6p.hip"]),
+}
+
+
 def sha(paths):
     h = hashlib.sha256()
     for p in paths:
@@ -79,6 +90,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, action="append")
     ap.add_argument("--only", default="")
+    ap.add_argument("--config4", action="store_true", help="the BASELINE configs[4] geometry (batch 1) -> key config4_batch1")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     args = ap.parse_args()
     try:
@@ -91,9 +103,9 @@ def main():
                     "the kernel's source files when the counters were collected; bench.py refuses entries that no longer match.")
     doc["collected"] = time.strftime("%Y-%m-%d %H:%M:%S")
     raw_lines = []
-    for b in (args.batch or [1]):
-        entries = doc.setdefault(f"batch{b}", {})
-        for name, (cmd, kernels, sources) in TARGETS.items():
+    for b in ([1] if args.config4 else (args.batch or [1])):
+        entries = doc.setdefault(f"config4_batch{b}" if args.config4 else f"batch{b}", {})
+        for name, (cmd, kernels, sources) in (TARGETS_CONFIG4 if args.config4 else TARGETS).items():
             if args.only and name not in args.only.split(","):
                 continue
             if not all(os.path.isfile(os.path.join(ROOT, s)) for s in sources):
