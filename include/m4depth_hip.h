@@ -184,7 +184,10 @@ int m4d_conv3x3_wino6_bias_act(const float* x, const void* wu6, const float* bia
 /* The same call with the kernel named: 0 = chosen from the grid (what m4d_conv3x3_wino6_bias_act does), 1 = one workgroup
  * per (16x16-pixel tile, 64 output channels) (csrc/m4d_wino6.hip), 2 = persistent workgroups, one per CU, each walking a
  * contiguous range of (tile, cout group) units with the DMA stream continuing across unit boundaries (csrc/m4d_wino6p.hip;
- * Cin >= 32).  Bit-identical results; an argument, not process state: tests and A/B timing use it. */
+ * Cin >= 32); 16 + n (1 <= n <= 15, round 6) = persistent workgroups of n CONSECUTIVE units each (n = 2 on a 128-cout layer: a
+ * tile's two cout groups, one halo fetch, one unit boundary with the DMA stream running through it), as many workgroups as that
+ * takes -- the dispatcher places them as CUs free instead of one static range per CU.  Bit-identical results; an argument, not
+ * process state: tests and A/B timing use it. */
 int m4d_conv3x3_wino6_bias_act_k(const float* x, const void* wu6, const float* bias, int b, int h, int w,
                                  int Cin, int Cout, int CoutPad, float slope, float* out, int kernel, void* stream);
 /* Grids of at least this many (16x16-pixel tile, 64-cout) units run on the persistent-workgroup form of the kernel above when

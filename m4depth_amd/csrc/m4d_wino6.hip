@@ -560,7 +560,7 @@ extern "C" void m4d_wino6_set_half_tile_max_workgroups(int max_wg) { g_wino6_hal
 
 // m4d_wino6p.hip: the same arithmetic with persistent workgroups (one per CU) walking (tile, cout group) units; bit-identical
 int m4d_wino6p_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
-                      float slope, float* out, void* stream);
+                      float slope, float* out, int units_per_wg, int stagger_us, int stagger_phases, void* stream);
 
 extern "C" long long m4d_wino6_persistent_min_units(void) {
   static const long long v = [] { const char* e = getenv("M4D_WINO6P_MIN_UNITS"); const long long u = e ? atoll(e) : 0;
@@ -585,7 +585,9 @@ extern "C" int m4d_conv3x3_wino6_bias_act_ks(const float* x, const void* wu6, co
   M4D_CHECK_ARG(CoutPad % 64 == 0 && CoutPad >= Cout && Cin % 16 == 0);
   M4D_CHECK_ARG(((((uintptr_t)x) & 15u) == 0) && ((((uintptr_t)wu6) & 15u) == 0));
   M4D_CHECK_ARG((long long)h * w * Cin * 4 < (1ll << 31));                              // one image = one buffer descriptor
-  M4D_CHECK_ARG(kernel >= 0 && kernel <= 2 && (kernel != 2 || Cin >= 32));
+  // kernel = 16 + n (1 <= n <= 15): persistent workgroups of n consecutive units each, placed by the dispatcher
+  const int units_per_wg = kernel >= 17 && kernel <= 31 ? kernel - 16 : 0;
+  M4D_CHECK_ARG(((kernel >= 0 && kernel <= 2) || units_per_wg > 0) && ((kernel != 2 && units_per_wg == 0) || Cin >= 32));
   M4D_CHECK_ARG(stagger_us >= 0 && stagger_us <= 1000);
   M4D_CHECK_ARG(stagger_us == 0 || (stagger_phases >= 1 && stagger_phases <= 32 && !(stagger_phases & (stagger_phases - 1))));
   {
@@ -593,9 +595,10 @@ extern "C" int m4d_conv3x3_wino6_bias_act_ks(const float* x, const void* wu6, co
     // per-unit prologue, fetches a tile's halo once for its cout groups and stores 256-byte runs; smaller grids keep this
     // file's kernel (a cheaper epilogue, and the dispatcher places its workgroups dynamically beside other frames' kernels)
     const long long units = (long long)b * ((w + kT - 1) / kT) * ((h + kT - 1) / kT) * (CoutPad / 64);
-    const bool persistent = kernel == 2 || (kernel == 0 && Cin >= 32 && units >= m4d_wino6_persistent_min_units());
+    const bool persistent = kernel == 2 || units_per_wg > 0 || (kernel == 0 && Cin >= 32 && units >= m4d_wino6_persistent_min_units());
     if (persistent && g_wino6_stamps == nullptr)
-      return m4d_wino6p_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, stream);
+      return m4d_wino6p_launch(x, wu6, bias, b, h, w, Cin, Cout, CoutPad, slope, out, units_per_wg,
+                               units_per_wg > 0 ? stagger_us : 0, stagger_phases, stream);
   }
 #if M4D_EXPERIMENTS
   {

@@ -49,6 +49,7 @@ struct Wino6PArgs {
   const float* x; const unsigned char* wu; const float* bias; float* out;
   int b, h, w, Cin, Cout, CoutPad, n_chunks, tiles_x, tiles_y, units, team;
   float slope;
+  int stagger, phases;          // > 0: the first 256 workgroups start up to `stagger` 100-MHz ticks apart, in `phases` groups (m4d_wino6.hip)
 };
 
 constexpr int pT = 16, pH = pT + 2;              // output tile, halo (pixels)
@@ -77,6 +78,13 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
   extern __shared__ __align__(16) float lds[];
   unsigned char* const ldsb = reinterpret_cast<unsigned char*>(lds);
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;   // LDS byte address (for M0)
+  if (a.stagger > 0 && blockIdx.x < 256) {
+    // the staggered first round of m4d_wino6.hip (short ranges at batch 1-4: the workgroups of a round would otherwise free their
+    // CUs in lock step): a bounded delay in front of the kernel body, same bits
+    const unsigned phase = (blockIdx.x >> 3) & (unsigned)(a.phases - 1);
+    const unsigned long long t_end = wall_clock64() + (unsigned long long)(phase * (unsigned)a.stagger) / (unsigned)a.phases;
+    for (int spin = 0; spin < 512 && wall_clock64() < t_end; ++spin) __builtin_amdgcn_s_sleep(16);
+  }
 
   const int t = threadIdx.x, lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -519,8 +527,10 @@ conv3x3_wino6p_kernel(const Wino6PArgs a) {
 }  // namespace
 
 // Launch for m4d_conv3x3_wino6_bias_act (m4d_wino6.hip decides when): Cin >= 32.
+// units_per_wg > 0: workgroups of that many consecutive units each (grid = ceil(units / units_per_wg), as many workgroups as
+// that takes: the dispatcher places them as CUs free, one per CU at a time) instead of one static range per CU.
 int m4d_wino6p_launch(const float* x, const void* wu6, const float* bias, int b, int h, int w, int Cin, int Cout, int CoutPad,
-                      float slope, float* out, void* stream) {
+                      float slope, float* out, int units_per_wg, int stagger_us, int stagger_phases, void* stream) {
   M4D_CHECK_ARG(Cin % 16 == 0 && Cin >= 32 && CoutPad % 64 == 0 && CoutPad >= Cout);
   Wino6PArgs a;
   a.x = x; a.wu = reinterpret_cast<const unsigned char*>(wu6); a.bias = bias; a.out = out;
@@ -536,13 +546,15 @@ int m4d_wino6p_launch(const float* x, const void* wu6, const float* bias, int b,
   // more workgroups than the longest range needs -- 960 units on 256 CUs are 4 per workgroup whichever way, so 240 workgroups
   // do it and 16 CUs stay free for the other frames' small kernels.
   const int n_groups = CoutPad / 64;
-  a.team = (n_cu % 8 == 0 && n_cu / 8 >= n_groups && units >= 4ll * n_cu) ? 1 : 0;
+  a.team = (units_per_wg <= 0 && n_cu % 8 == 0 && n_cu / 8 >= n_groups && units >= 4ll * n_cu) ? 1 : 0;
+  a.stagger = stagger_us * 100; a.phases = stagger_us > 0 ? stagger_phases : 1;
   // M4D_WINO6P_MAX_WG (measurement knob): at most this many persistent workgroups -- the other CUs stay free for the kernels of
   // the other frames' coarse levels, whose workgroups otherwise each wait for one of this kernel's ~27-us units to end
   static const int max_wg = [] { const char* e = getenv("M4D_WINO6P_MAX_WG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 30; }();
   const int cu_used = n_cu < max_wg ? n_cu : max_wg;
   const long long per_wg = (units + cu_used - 1) / cu_used;
-  const unsigned grid = a.team ? (unsigned)n_cu : (unsigned)((units + per_wg - 1) / per_wg);
+  const unsigned grid = units_per_wg > 0 ? (unsigned)((units + units_per_wg - 1) / units_per_wg)
+                                         : a.team ? (unsigned)n_cu : (unsigned)((units + per_wg - 1) / per_wg);
   m4d_launch(conv3x3_wino6p_kernel, dim3(grid), dim3(512), (size_t)pLds, (hipStream_t)stream, a);
   return M4D_LAUNCH_RESULT();
 }

@@ -63,6 +63,13 @@ wino6_min_workgroups = int(_os.environ.get("M4D_WINO6_MIN_WG", "30"))
 # from the grid (persistent workgroups, csrc/m4d_wino6p.hip, wherever a CU gets more than one (tile, 64-cout) unit), 1 = one
 # workgroup per unit always (csrc/m4d_wino6.hip), 2 = persistent always.  A/B timing only.
 wino6_kernel = int(_os.environ.get("M4D_WINO6_KERNEL", "0"))
+# Round 6: launches of wino6_pair_min_units ... (persistent threshold - 1) units at a launch batch <= 4 (the level-1 refiner layers
+# at batch 1: 960 / 480 units) on persistent workgroups of wino6_pair_units CONSECUTIVE units each (kernel = 16 + n of
+# m4d_conv3x3_wino6_bias_act_ks): a tile's cout groups share a halo fetch and the DMA stream runs through the unit boundary
+# (4.4 us instead of ~7 for prologue + epilogue), while the dispatcher still places the workgroups as CUs free (the static
+# one-range-per-CU form did not pay inside the frame pipeline).  0 = off (one workgroup per unit).  Same bits.
+wino6_pair_min_units = int(_os.environ.get("M4D_WINO6_PAIR_MIN_UNITS", "0"))
+wino6_pair_units = int(_os.environ.get("M4D_WINO6_PAIR_UNITS", "2"))
 # Narrowest layer the bf16-split Winograd kernels serve: a cout group of <= 32 channels runs as a HALF unit (one N-tile), so the
 # refiner's 64 -> 32 layer is one half unit per tile: 35.7 -> 29.0 us on level 1, 20.8 -> 12.4 on level 2 against the fp32-MFMA
 # Winograd kernel that served it in rounds 2-4 (= 64 here), +0.9 % / +1.1 % frames/s at batch 1 / 32
@@ -493,8 +500,13 @@ class _Conv3x3SameTF(torch.nn.Module):
         if wino == 6:
             wu, cpad = self._packed_weights_wino6(cin_)
             stag = self.launch_stagger_us(b_, h_, w_)
+            kern = wino6_kernel
+            if kern == 0 and wino6_pair_min_units > 0 and b_ <= wino6_stagger_max_batch and cin_ >= 32:
+                units = b_ * (-(-h_ // 16)) * (-(-w_ // 16)) * (cpad // 64)
+                if wino6_pair_min_units <= units < int(lib.m4d_wino6_persistent_min_units()):
+                    kern = 16 + max(1, min(wino6_pair_units, 15))
             return _timed("conv", self.tag, lambda: nops.conv3x3_wino6_bias_act(
-                x_nhwc, wu, self.bias, self.out_channels, cpad, act, kernel=wino6_kernel, stagger_us=stag,
+                x_nhwc, wu, self.bias, self.out_channels, cpad, act, kernel=kern, stagger_us=stag,
                 stagger_phases=wino6_stagger_phases))
         if wino:
             wu, cpad = self._packed_weights_winograd(16 if wino == 1 else 8, cin_)     # cin_ > Cin: zero-padded input

@@ -473,7 +473,8 @@ def test_persistent_winograd_is_bitwise_the_one_tile_kernel(M, dev, b, h, w, cin
     """m4d_wino6p.hip (persistent workgroups walking (tile, cout group) units, the K loop's DMA stream continuing across
     unit boundaries, four-pass epilogue in two ring slots) against m4d_wino6.hip (one workgroup per unit): the same float32
     bits -- same products, same accumulation order, same association in the output transform -- through the explicit
-    kernel argument of m4d_conv3x3_wino6_bias_act_k and through the default dispatch; repeated launches agree."""
+    kernel argument of m4d_conv3x3_wino6_bias_act_k and through the default dispatch; repeated launches agree.  Also the
+    short-range form (kernel = 16 + n: workgroups of n consecutive units, placed by the dispatcher; round 6)."""
     from m4depth_amd import network_ops as nops
     rng = np.random.default_rng(b * 1000 + h + cin + cout)
     x = to_dev(rng.standard_normal([b, h, w, cin]).astype(F), dev)
@@ -483,6 +484,8 @@ def test_persistent_winograd_is_bitwise_the_one_tile_kernel(M, dev, b, h, w, cin
     wud = torch.from_numpy(wu6.view("int16")).to(dev)
     one = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, slope, kernel=1)
     per = [nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, slope, kernel=2) for _ in range(3)]
+    # round 6: persistent workgroups of n consecutive units each (kernel = 16 + n), with and without the staggered first round
+    per += [nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, slope, kernel=16 + n, stagger_us=us) for n, us in ((2, 0), (2, 9), (3, 0), (5, 13))]
     auto = nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, slope)
     for o in per:
         ne = o.view(torch.int32) != one.view(torch.int32)
@@ -539,7 +542,8 @@ def test_winograd_stagger_is_per_call(M, dev):
                 nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1, kernel=1, stagger_us=us, stagger_phases=phases)
             st.synchronize()
             start.wait()
-            for _ in range(24):
+            torch.cuda._sleep(int(2.0e7))                  # the host queues the timed launches behind a GPU-side spin: an event pair
+            for _ in range(24):                            # then brackets the kernel's execution, not the host's launch gaps
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(st)
                 outs.append(nops.conv3x3_wino6_bias_act(x, wud, bias, cout, cpad, 0.1, kernel=1, stagger_us=us, stagger_phases=phases))
@@ -554,8 +558,10 @@ def test_winograd_stagger_is_per_call(M, dev):
     for t in th:
         t.join()
     fast, slow = res["lock_step"][0], res["staggered"][0]
+    # (relative bounds: the launches of the two threads share the chip, so absolute durations move with the box)
     assert min(slow) >= 180.0, f"a staggered launch lost its delay: {sorted(slow)[:4]} us"
-    assert float(np.median(fast)) < 120.0, f"the lock-step thread's launches carry the other thread's delay: median {np.median(fast):.0f} us"
+    assert float(np.median(fast)) + 100.0 < min(slow) and min(fast) < 100.0, \
+        f"the lock-step thread's launches carry the other thread's delay: median {np.median(fast):.0f} / min {min(fast):.0f} us against {min(slow):.0f}"
     for o in res["lock_step"][1] + res["staggered"][1]:
         assert torch.equal(o, res["lock_step"][1][0])
 
