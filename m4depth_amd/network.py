@@ -687,23 +687,33 @@ class DepthEstimatorLevel(torch.nn.Module):
             conv.tag = f"lvl{depth}.conv{i}"
         self.prev_f_maps = None
         self.depth_prev_t = None
-        self._spare_f = None
+        self._own = None                  # the level's two persistent feature-state buffers (see _spare_f)
         self.last_f_input = None          # kept for inspection / parity tests
         self.last_cv_inputs = None
         self.last_front_inputs = None
 
     # -- temporal memory (build(), :153-165) ------------------------------------------
     def _ensure_state(self, shape, device):
-        if self.prev_f_maps is None or tuple(self.prev_f_maps.shape) != tuple(shape):
+        if self._own is None or tuple(self._own[0].shape) != tuple(shape) or self._own[0].device != device:
             b, h, w, c = shape
-            self.prev_f_maps = torch.zeros(shape, dtype=torch.float32, device=device)
-            self._spare_f = torch.empty(shape, dtype=torch.float32, device=device)
+            self._own = [torch.zeros(shape, dtype=torch.float32, device=device), torch.empty(shape, dtype=torch.float32, device=device)]
+            self.prev_f_maps = self._own[0]
             self.depth_prev_t = torch.ones((b, h, w, 1), dtype=torch.float32, device=device)
+
+    @property
+    def _spare_f(self):
+        """The level's own state buffer that is NOT the current ``prev_f_maps``: where the next normalised features are written
+        (they then become ``prev_f_maps``: a pointer hand-over, :211 / :259).  The level OWNS its two buffers for its lifetime --
+        a captured hipGraph has their addresses baked in, so neither may ever be dropped -- and never writes anywhere else:
+        a ``prev_f_maps`` that came from outside (``forward(..., curr_f_normalized=...)``) is borrowed and only read."""
+        if self._own is None:
+            return None
+        return self._own[1] if self.prev_f_maps is self._own[0] else self._own[0]
 
     def reset_state(self):
         self.prev_f_maps = None
         self.depth_prev_t = None
-        self._spare_f = None
+        self._own = None
 
     def reset_job(self, curr_f_maps):
         """This level's buffers for the one-launch pyramid reset (``nops.pyramid_reset``), or None when its reset branch has to
@@ -720,7 +730,7 @@ class DepthEstimatorLevel(torch.nn.Module):
 
     def reset_commit(self):
         """After ``nops.pyramid_reset``: the normalised features ARE the new prev_f_maps (:211) -- the swap ``forward`` does."""
-        self._spare_f, self.prev_f_maps = self.prev_f_maps, self._spare_f
+        self.prev_f_maps = self._spare_f
 
     def _tail_weights(self, convs, split=False):
         """Packed weights of the fused level tail (conv 32->16, conv 16->5), built once per device: the fp32-MFMA kernel's
@@ -824,7 +834,7 @@ class DepthEstimatorLevel(torch.nn.Module):
                 prev_l_est, None, None, None, b, h, w, dev, normalize=norm_job,
                 depth_state_reset=None if self.is_training else self.depth_prev_t))         # :209, in the same launch
             if not self.is_training:
-                self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
+                self.prev_f_maps = curr_f                      # (curr_f is the spare buffer: the other one becomes the spare)
             return {"depth": depth_prev_l, "parallax": para_prev_l, "other": other_prev_l}
 
         r = self.dscv_range
@@ -923,12 +933,9 @@ class DepthEstimatorLevel(torch.nn.Module):
             para_curr_l, depth, other = _timed("post", self.lvl_depth, lambda: nops.level_post(
                 prev_out[0], rot_t, tr, {"f": cf, "c": cc}, scale, depth_state=self.depth_prev_t if not self.is_training else None))
         if not self.is_training:
-            if use_small:
-                # the caller's normalised tensor IS the new prev_f_maps (:211, :259); the level's own spare buffer stays the spare
-                # (when the old prev_f_maps was the level's own second buffer it is simply dropped: _ensure_state keeps the shape)
-                self.prev_f_maps = curr_f
-            else:
-                self._spare_f, self.prev_f_maps = self.prev_f_maps, curr_f
+            # the normalised features ARE the new prev_f_maps (:211, :259): the level's spare buffer, or -- the one-launch opening of
+            # a coarse level -- the caller's tensor, borrowed and only read (the level's own two buffers stay its own: _spare_f)
+            self.prev_f_maps = curr_f
         return {"other": other, "depth": depth, "parallax": para_curr_l}
 
 
@@ -1587,12 +1594,15 @@ class GraphedSequence:
         the memory pool of the capture that produced them."""
         lv = self.model.d_estimator.levels
         return (self.model.last_estimates,
-                [(l.last_f_input, l.last_cv_inputs, getattr(l, "last_front_inputs", None)) for l in lv])
+                [(l.last_f_input, l.last_cv_inputs, getattr(l, "last_front_inputs", None), l.prev_f_maps) for l in lv])
 
     def _restore_inspection_state(self, state):
+        """... and each level's ``prev_f_maps``: after a coarse level's one-launch opening it is a tensor of the capture's pool
+        (the state a following eager frame continues from must be the KEPT graph's)."""
         self.model.last_estimates = state[0]
-        for l, (f_in, cv_in, front_in) in zip(self.model.d_estimator.levels, state[1]):
+        for l, (f_in, cv_in, front_in, prev_f) in zip(self.model.d_estimator.levels, state[1]):
             l.last_f_input, l.last_cv_inputs, l.last_front_inputs = f_in, cv_in, front_in
+            l.prev_f_maps = prev_f
 
     def _capture_autotuned(self, stagger_us):
         """Two captures -- the Winograd launches with their first round staggered and without -- timed against each other here,

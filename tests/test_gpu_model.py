@@ -290,6 +290,42 @@ def test_graphed_sequence_matches_eager(dev, keep, monkeypatch):
         runner(bad)
 
 
+@pytest.mark.parametrize("split", [2, 4])
+def test_graph_replay_writes_only_memory_it_owns(dev, split, monkeypatch):
+    """Round 6 regression (a GPU memory fault under M4D_PIPELINE_ENCODER_SPLIT=4, a silent hazard otherwise): a captured step has the
+    addresses of the levels' state buffers baked in.  With a coarse level opening on features normalised ahead of it, the
+    normalised tensor becomes ``prev_f_maps`` -- and the level's own buffer it replaced was DROPPED, returned to the caching
+    allocator and handed to the next eager allocation of that size, which every replay (frame 0's reset writes that address) then
+    overwrote.  The level now owns its two buffers for life and only borrows the caller's tensor.  Here: capture (both Winograd
+    forms, the loser freed), then allocate many eager tensors of exactly the levels' state sizes, fill them with a sentinel,
+    replay, and require every sentinel intact and the replay equal to the eager forward."""
+    import m4depth_amd as M
+    from m4depth_amd import network as net
+    monkeypatch.setattr(net, "pipeline_encoder_split", split)
+    L, H, Wd, T, b = 6, 192, 320, 4, 1                     # levels 3-6 open with m4d_level_front_small at this size
+    W = S.init_weights(L, seed=11)
+    model = _build(dev, L, 4, 3, W)
+    samples, cam = S.make_sequence(b, T, H, Wd, seed=12)
+    d = {k: torch.stack([to_dev(s[k], dev) for s in samples], dim=1) for k in ("depth", "RGB_im", "rot", "trans")}
+    d["new_traj"] = torch.stack([torch.from_numpy(s["new_traj"]) for s in samples], dim=1)
+    d["camera"] = to_dev(cam, dev)
+    frames = [{k: d[k][:, t] for k in ("RGB_im", "rot", "trans", "new_traj")} for t in range(T)]
+    ref = model([frames, d["camera"]])["depth"].clone()
+    assert any(lv.wants_prenormalized(b, H >> (i + 1), Wd >> (i + 1), S.ENCODER_CHANNELS[i]) for i, lv in enumerate(model.d_estimator.levels))
+    runner = net.GraphedSequence(model, d)
+    shapes = [tuple(lv._own[0].shape) for lv in model.d_estimator.levels] + [(b, H >> (i + 1), Wd >> (i + 1), 1) for i in range(L)]
+    guards = [torch.full(sh, 12345.0, device=dev) for _ in range(6) for sh in shapes]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        out = runner(d)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    for g in guards:
+        assert bool((g == 12345.0).all()), f"a replay wrote into an eager tensor of shape {tuple(g.shape)}"
+    for lv in model.d_estimator.levels:                    # the level still owns two distinct buffers, neither of them the borrowed one
+        assert lv._own is not None and lv._spare_f is not lv.prev_f_maps and any(lv._spare_f is o for o in lv._own)
+
+
 def test_two_models_two_threads_keep_their_own_stagger(dev, monkeypatch):
     """two models with different staggered-first-round settings, each driven from its own host thread at the
     same time, each hand THEIR OWN value to every Winograd launch (the argument of m4d_conv3x3_wino6_bias_act_ks; round 5 kept it
