@@ -7,7 +7,7 @@
 #   of the roofline kernel.
 # usage (GPU box, repo root): bash tools/collect_round_profiles.sh r04   -> gpurun_out/<tag>/ ; copy what is cited into profiles/
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -18,6 +18,7 @@ need() { for f in "$@"; do if [ ! -s "$f" ]; then echo "[collect] EMPTY OR MISSI
 # kernel's issue / matrix-core counters
 timeout 1800 python tools/pmc_traffic.py --batch 1 > $OUT/pmc.log 2>&1
 timeout 1500 python tools/pmc_traffic.py --batch 32 --only front,wino6_l1_128_128,front_l4,dscv_l4,sncv_l4 >> $OUT/pmc.log 2>&1
+timeout 900 python tools/pmc_traffic.py --config4 >> $OUT/pmc.log 2>&1          # BASELINE configs[4] geometry (round 6): front + the roofline layer
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json; cp gpurun_out/pmc_traffic_rows.txt $OUT/pmc_traffic_rows.txt
 need $OUT/pmc_traffic.json $OUT/pmc_traffic_rows.txt
 timeout 1200 bash tools/pmc_wino6.sh > /dev/null 2>&1; cp gpurun_out/pmc/wino6.txt $OUT/wino6_pmc.txt; need $OUT/wino6_pmc.txt
