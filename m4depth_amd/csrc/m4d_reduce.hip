@@ -291,8 +291,28 @@ __device__ __forceinline__ f32x4 enc0_conv1(const float* window_base, const int 
 constexpr int kE0TW = 128, kE0TH = 8;              // statistics tile (pixels)
 constexpr int kE0RS = (kE0TW + 2) * 3;             // floats per staged RGB row (390)
 
+// The shift of the single-pass statistics (PASS 2 below): conv1 + bias at the image's centre pixel -- one sample of the very
+// distribution whose moments are taken, so (mean - K)^2 is of the order of the variance and sum (y - K)^2 - (sum (y - K))^2 / n
+// cancels nothing to speak of.  Evaluated with the same expression by the statistics kernel and by its finalisation.
+__device__ __forceinline__ float enc0_shift(const float* __restrict__ ib, const float* __restrict__ w27, const float* __restrict__ bias,
+                                            int h, int w, int j) {
+  const int cy = h / 2, cx = w / 2;
+  float y = bias[j];
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      const int gy = cy + ky - 1, gx = cx + kx - 1;
+      if (gy < 0 || gy >= h || gx < 0 || gx >= w) continue;
+      for (int ch = 0; ch < 3; ++ch) y = y + w27[((ky * 3 + kx) * 3 + ch) * 16 + j] * ib[((long long)gy * w + gx) * 3 + ch];
+    }
+  return y;
+}
+
 // PASS 0: per-channel sums of conv1 + bias; PASS 1: sums of squared deviations from `mean` -- partials in the layout of
 // dinl_partial_kernel ([image][block][16]), finished by dinl_finalize_kernel.  A workgroup walks tiles blockIdx.x, + gridDim.x, ...
+// PASS 2 (round 6): BOTH moments in one pass -- S1 = sum (y - K), S2 = sum (y - K)^2 with the per-image, per-channel shift K of
+// enc0_shift -- partials [image][block][32] (16 x S1, 16 x S2), finished by enc0_moments_finalize_kernel: the level-0 statistics are
+// then TWO dependent launches instead of four (RGB totals, analytic mean, squared deviations, finalisation), 20 us less at the head
+// of a batch-1 step's critical path.
 template <int PASS>
 __global__ void __launch_bounds__(256)
 enc0_stats_kernel(const float* __restrict__ img, const float* __restrict__ w27, const float* __restrict__ bias,
@@ -307,8 +327,8 @@ enc0_stats_kernel(const float* __restrict__ img, const float* __restrict__ w27, 
   int koff[7]; float wb[7];
   enc0_lane_setup(w27, lane, kE0RS, koff, wb);
   const float bias_j = bias[j];
-  const float mean_j = PASS ? mean[bi * 16 + j] : 0.f;
-  float csum = 0.f;
+  const float mean_j = PASS == 1 ? mean[bi * 16 + j] : (PASS == 2 ? enc0_shift(ib, w27, bias, h, w, j) : 0.f);
+  float csum = 0.f, csum2 = 0.f;
   for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
     const int y0 = (ti / tiles_x) * kE0TH, x0 = (ti % tiles_x) * kE0TW;
     __syncthreads();                               // the previous tile has been consumed
@@ -329,7 +349,8 @@ enc0_stats_kernel(const float* __restrict__ img, const float* __restrict__ w27, 
         for (int r = 0; r < 4; ++r) {
           const bool valid = y0 + yl < h && x0 + 16 * ct + 4 * g + r < w;
           float v = acc[r] + bias_j;
-          if (PASS) { v = v - mean_j; v = v * v; }
+          if (PASS == 1) { v = v - mean_j; v = v * v; }
+          if (PASS == 2) { v = v - mean_j; csum2 += valid ? v * v : 0.f; }
           csum += valid ? v : 0.f;
         }
       }
@@ -337,9 +358,49 @@ enc0_stats_kernel(const float* __restrict__ img, const float* __restrict__ w27, 
   }
   csum += __shfl_xor(csum, 16);                    // the four pixel groups of a channel: fixed butterfly
   csum += __shfl_xor(csum, 32);
+  if (PASS == 2) {
+    __shared__ float sh2[4][16];
+    csum2 += __shfl_xor(csum2, 16);
+    csum2 += __shfl_xor(csum2, 32);
+    if (lane < 16) { sh[wv][lane] = csum; sh2[wv][lane] = csum2; }
+    __syncthreads();
+    float* po = partial + ((long long)bi * gridDim.x + blockIdx.x) * 32;
+    if (t < 16) po[t] = ((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t];
+    else if (t < 32) po[t] = ((sh2[0][t - 16] + sh2[1][t - 16]) + sh2[2][t - 16]) + sh2[3][t - 16];
+    return;
+  }
   if (lane < 16) sh[wv][lane] = csum;
   __syncthreads();
   if (t < 16) partial[((long long)bi * gridDim.x + blockIdx.x) * 16 + t] = ((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t];
+}
+
+// mean = K + S1 / n, var = S2 / n - (S1 / n)^2 (the biased variance of tf.math.reduce_variance) from the PASS-2 partials, in
+// double, partials added in block order by a fixed tree: run-to-run identical.  One workgroup per image; thread (c, j): channel c
+// (32 columns: 16 x S1, 16 x S2), every 8th block from j.
+__global__ void __launch_bounds__(256)
+enc0_moments_finalize_kernel(const float* __restrict__ img, const float* __restrict__ partial, int nblk, const float* __restrict__ w27,
+                             const float* __restrict__ bias, int h, int w, int bsz, long long stride_b, long long stride_t,
+                             float* __restrict__ mean, float* __restrict__ var) {
+  __shared__ double sh[256];
+  const int bi = blockIdx.x, t = threadIdx.x;
+  const int c = t & 31, j = t >> 5;
+  double s = 0.0;
+  for (int k = j; k < nblk; k += 8) s += (double)partial[((long long)bi * nblk + k) * 32 + c];
+  sh[t] = s;
+  __syncthreads();
+  if (t < 32) {
+    for (int r = 1; r < 8; ++r) s += sh[r * 32 + t];
+    sh[t] = s;
+  }
+  __syncthreads();
+  if (t < 16) {
+    const float* ib = img + (long long)(bi % bsz) * stride_b + (long long)(bi / bsz) * stride_t;
+    const double n = (double)h * (double)w;
+    const double m1 = sh[t] / n, m2 = sh[16 + t] / n;
+    mean[bi * 16 + t] = (float)((double)enc0_shift(ib, w27, bias, h, w, t) + m1);
+    const double v = m2 - m1 * m1;
+    var[bi * 16 + t] = (float)(v > 0.0 ? v : 0.0);
+  }
 }
 
 // The MEAN of the first convolution's output needs no convolution: the layer is linear, so
@@ -599,6 +660,16 @@ extern "C" int m4d_enc_level0_stats(const float* images, int bsz, long long stri
   const int tiles_x = (w + kE0TW - 1) / kE0TW, n_tiles = tiles_x * ((h + kE0TH - 1) / kE0TH);
   const int nblk = n_tiles < kDinlMaxBlocks ? n_tiles : kDinlMaxBlocks;
   float* partial = workspace;
+  static int single_pass = -1;                     // M4D_ENC0_SINGLE_PASS=0: round 5's four launches (A/B timing)
+  if (single_pass < 0) { const char* e = getenv("M4D_ENC0_SINGLE_PASS"); single_pass = e ? atoi(e) : 1; }
+  if (single_pass) {
+    const int nb2 = nblk < kDinlMaxBlocks / 2 ? nblk : kDinlMaxBlocks / 2;          // 32 floats per block in the same workspace
+    m4d_launch(enc0_stats_kernel<2>, dim3(nb2, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)nullptr, h, w, bsz,
+               stride_b, stride_t, tiles_x, n_tiles, partial);
+    m4d_launch(enc0_moments_finalize_kernel, dim3(b), dim3(256), 0, s, images, (const float*)partial, nb2, w1_hwio, bias1, h, w, bsz,
+               stride_b, stride_t, mean, var);
+    return M4D_LAUNCH_RESULT();
+  }
   static int analytic_mean = -1;                   // M4D_ENC0_ANALYTIC_MEAN=0: the mean from a convolution pass instead
   if (analytic_mean < 0) { const char* e = getenv("M4D_ENC0_ANALYTIC_MEAN"); analytic_mean = e ? atoi(e) : 1; }
   if (analytic_mean && (h == 1 || w == 1)) analytic_mean = 0;      // (one border row / column would be excluded twice)

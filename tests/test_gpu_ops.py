@@ -899,6 +899,27 @@ def test_encoder_level0_without_intermediate(M, dev, weights, b, h, w):
         assert torch.equal(got, nops.encoder_level0(nops.FrameStack(seq), *args))
 
 
+@pytest.mark.parametrize("b,h,w,offset,spread", [(2, 96, 272, 0.0, 1.0), (1, 384, 1280, 0.0, 1.0), (3, 37, 53, 0.9, 0.01), (1, 130, 260, 50.0, 0.5)])
+def test_encoder_level0_statistics_single_pass(M, dev, b, h, w, offset, spread):
+    """m4d_enc_level0_stats, round 6: mean and variance of the (never written) 3 -> 16 convolution output from ONE pass over the
+    image -- shifted moments sum (y - K), sum (y - K)^2 with K = the convolution at the centre pixel, merged in double -- instead
+    of four launches (RGB totals, analytic mean, squared deviations, finalisation).  Against the float64 moments of the oracle's
+    convolution, also on images whose mean dwarfs their spread (where an unshifted E[y^2] - E[y]^2 loses every digit)."""
+    from m4depth_amd import network_ops as nops
+    rng = np.random.default_rng(h + w)
+    img = (offset + spread * rng.random([b, h, w, 3])).astype(F)
+    k1 = (rng.standard_normal([3, 3, 3, 16]) * np.sqrt(2.0 / 27)).astype(F)
+    b1 = (0.1 * rng.standard_normal([16])).astype(F)
+    y = O.conv2d_same(img, k1, b1, 1).astype(np.float64)
+    mean_ref, var_ref = y.mean(axis=(1, 2)), y.var(axis=(1, 2))
+    mean, var = nops.encoder_level0_stats(to_dev(img, dev), to_dev(k1.copy(), dev), to_dev(b1, dev))
+    m, v = npy(mean).astype(np.float64), npy(var).astype(np.float64)
+    assert np.max(np.abs(m - mean_ref) / (np.abs(mean_ref) + np.sqrt(var_ref))) < 2e-6
+    assert np.max(np.abs(v - var_ref) / var_ref) < 2e-5, np.max(np.abs(v - var_ref) / var_ref)
+    m2, v2 = nops.encoder_level0_stats(to_dev(img, dev), to_dev(k1.copy(), dev), to_dev(b1, dev))
+    assert torch.equal(mean, m2) and torch.equal(var, v2)                      # deterministic
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout", [(2, 48, 160, 96, 96), (1, 24, 80, 128, 128), (2, 12, 40, 192, 192), (1, 13, 21, 32, 40),
                                             (1, 9, 10, 100, 64)])
 def test_small_map_conv_stride2(M, dev, b, h, w, cin, cout):
