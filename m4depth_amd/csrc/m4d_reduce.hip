@@ -663,7 +663,10 @@ extern "C" int m4d_enc_level0_stats(const float* images, int bsz, long long stri
   static int single_pass = -1;                     // M4D_ENC0_SINGLE_PASS=0: round 5's four launches (A/B timing)
   if (single_pass < 0) { const char* e = getenv("M4D_ENC0_SINGLE_PASS"); single_pass = e ? atoi(e) : 1; }
   if (single_pass) {
-    const int nb2 = nblk < kDinlMaxBlocks / 2 ? nblk : kDinlMaxBlocks / 2;          // 32 floats per block in the same workspace
+    // 32 floats per block in the same workspace -> at most 256 blocks per image; BALANCED: every workgroup the same number of tiles
+    // (384x1280: 480 tiles -> 240 workgroups of exactly two, not 224 of two + 32 of one)
+    const int cap = kDinlMaxBlocks / 2, per = (n_tiles + cap - 1) / cap;
+    const int nb2 = (n_tiles + per - 1) / per;
     m4d_launch(enc0_stats_kernel<2>, dim3(nb2, b), dim3(256), 0, s, images, w1_hwio, bias1, (const float*)nullptr, h, w, bsz,
                stride_b, stride_t, tiles_x, n_tiles, partial);
     m4d_launch(enc0_moments_finalize_kernel, dim3(b), dim3(256), 0, s, images, (const float*)partial, nb2, w1_hwio, bias1, h, w, bsz,

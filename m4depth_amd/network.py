@@ -1575,13 +1575,20 @@ class GraphedSequence:
         batch = int(self.static["RGB_im"].shape[0])
         model_us = getattr(model, "wino6_stagger_us", None)
         base_us = wino6_stagger_us if model_us is None else model_us
-        want = wino6_stagger_autotune if autotune is None else bool(autotune)
-        if want and base_us > 0 and batch <= wino6_stagger_max_batch:
+        if self.wants_autotune(batch, base_us, autotune):
             self._capture_autotuned(base_us)
         else:
             self.graph, self.depth = self._capture()
             self.stagger_us = base_us if batch <= wino6_stagger_max_batch else 0    # what the captured Winograd launches carry
         self.weights_stamp = model.weights_stamp()
+
+    @staticmethod
+    def wants_autotune(batch, stagger_us, autotune=None):
+        """Is the sequence captured twice (staggered / lock-step Winograd first round) and the faster graph kept?  Only where the
+        stagger applies at all: batch <= ``wino6_stagger_max_batch`` -- never at BASELINE configs[2] / configs[3]'s 32 sequences per
+        rank, so the ranks of an 8-GPU run all replay the same graph form and none spends the 1.4 s."""
+        want = wino6_stagger_autotune if autotune is None else bool(autotune)
+        return bool(want and stagger_us > 0 and batch <= wino6_stagger_max_batch)
 
     def _capture(self):
         graph = torch.cuda.CUDAGraph()

@@ -266,3 +266,15 @@ def test_convolution_dispatch_at_the_bench_pyramid():
     with pytest.raises(ValueError):
         with N.conv_arithmetic("fp16"):
             pass
+
+
+def test_graph_autotune_only_at_small_batch():
+    """``bench.py --gpus 8`` (configs[3]: 32 sequences per rank) must not run GraphedSequence's two-capture
+    choice on every rank (8 x 1.4 s, a rank-dependent graph): the choice exists only where the staggered Winograd first round
+    applies, batch <= 4."""
+    from m4depth_amd import network as net
+    assert net.GraphedSequence.wants_autotune(1, 9) == net.wino6_stagger_autotune
+    assert net.GraphedSequence.wants_autotune(4, 9, autotune=True)
+    assert not net.GraphedSequence.wants_autotune(32, 9) and not net.GraphedSequence.wants_autotune(32, 9, autotune=True)
+    assert not net.GraphedSequence.wants_autotune(8, 9, autotune=True)
+    assert not net.GraphedSequence.wants_autotune(1, 0, autotune=True) and not net.GraphedSequence.wants_autotune(1, 9, autotune=False)

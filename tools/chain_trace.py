@@ -3,7 +3,7 @@ duration, workgroups, kernel -- for the small kernels of the coarse-level chains
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-heads = [i for i, r in enumerate(rows) if "enc0_rgb_total_kernel" in r["Kernel_Name"] or "enc_head_conv_kernel" in r["Kernel_Name"]]
+heads = [i for i, r in enumerate(rows) if "enc0_stats_kernel" in r["Kernel_Name"] or "enc0_rgb_total_kernel" in r["Kernel_Name"] or "enc_head_conv_kernel" in r["Kernel_Name"]]
 # a step = two encoder batches; take the third-last complete step
 n_fin = sum(1 for r in rows if "metrics_finalize_kernel" in r["Kernel_Name"])
 per_step = max(1, round(len(heads) / n_fin)) if n_fin else 2          # head kernels per step (1 with the statistics up front)

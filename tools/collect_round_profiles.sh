@@ -37,7 +37,7 @@ for B in 1 32; do
   if [ -z "$STATS" ] || [ -z "$TRACE" ]; then echo "[collect] rocprofv3 wrote no kernel stats / trace for batch $B" >&2; FAILED="$FAILED rocprof_b$B"; continue; fi
   python tools/summarize_rocprof.py "$STATS" 45 > $OUT/bench_b${B}_kernel_stats_summary.txt
   python tools/trace_table.py "$TRACE" 0.3 > $OUT/bench_b${B}_launch_durations_by_grid.txt
-  [ $B = 1 ] && python tools/step_profile.py "$TRACE" 128 > $OUT/step_profile_b1.txt
+  [ $B = 1 ] && python tools/step_profile.py "$TRACE" 128 1 > $OUT/step_profile_b1.txt
   [ $B = 1 ] && python tools/chain_trace.py "$TRACE" 4000 > $OUT/step_timeline_b1.txt
   need $OUT/bench_b${B}_kernel_stats_summary.txt $OUT/bench_b${B}_launch_durations_by_grid.txt
 done

@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 thr = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
              int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, int(r["Workgroup_Size_X"])), r["Kernel_Name"]) for r in rows)
-heads = [e[0] for e in ev if "enc0_rgb_total_kernel" in e[3]] or [e[0] for e in ev if "enc_head_conv_kernel" in e[3]]   # first kernel of an encoder batch
+heads = [e[0] for e in ev if "enc0_stats_kernel" in e[3]] or [e[0] for e in ev if "enc0_rgb_total_kernel" in e[3]] or [e[0] for e in ev if "enc_head_conv_kernel" in e[3]]   # first kernel of an encoder batch
 if len(heads) < 4:
     sys.exit("step_profile: no encoder-batch head kernels (enc0_rgb_total_kernel / enc_head_conv_kernel) in the trace -- nothing to profile")
 # steps = consecutive head launches with a regular spacing (the timed graph replays): keep gaps within 20 % of the median
