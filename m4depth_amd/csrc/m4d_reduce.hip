@@ -384,8 +384,20 @@ enc0_moments_finalize_kernel(const float* __restrict__ img, const float* __restr
   __shared__ double sh[256];
   const int bi = blockIdx.x, t = threadIdx.x;
   const int c = t & 31, j = t >> 5;
+  // (the kernel is a latency chain on the head of the step: all of a thread's partials are requested before the first add, and
+  //  the shift -- 27 dependent scalar loads + multiply-adds -- is evaluated by 16 other threads meanwhile)
+  float pv[32];
+  const int cnt = (nblk - j + 7) / 8;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) pv[i] = i < cnt ? partial[((long long)bi * nblk + j + 8 * i) * 32 + c] : 0.f;
+  __shared__ float s_shift[16];
+  if (t >= 240) {
+    const float* ib0 = img + (long long)(bi % bsz) * stride_b + (long long)(bi / bsz) * stride_t;
+    s_shift[t - 240] = enc0_shift(ib0, w27, bias, h, w, t - 240);
+  }
   double s = 0.0;
-  for (int k = j; k < nblk; k += 8) s += (double)partial[((long long)bi * nblk + k) * 32 + c];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) s += (double)pv[i];                 // block order j, j + 8, ...: fixed
   sh[t] = s;
   __syncthreads();
   if (t < 32) {
@@ -394,10 +406,9 @@ enc0_moments_finalize_kernel(const float* __restrict__ img, const float* __restr
   }
   __syncthreads();
   if (t < 16) {
-    const float* ib = img + (long long)(bi % bsz) * stride_b + (long long)(bi / bsz) * stride_t;
     const double n = (double)h * (double)w;
     const double m1 = sh[t] / n, m2 = sh[16 + t] / n;
-    mean[bi * 16 + t] = (float)((double)enc0_shift(ib, w27, bias, h, w, t) + m1);
+    mean[bi * 16 + t] = (float)((double)s_shift[t] + m1);
     const double v = m2 - m1 * m1;
     var[bi * 16 + t] = (float)(v > 0.0 ? v : 0.0);
   }

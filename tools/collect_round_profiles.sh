@@ -16,12 +16,14 @@ need() { for f in "$@"; do if [ ! -s "$f" ]; then echo "[collect] EMPTY OR MISSI
 
 # PMC first: HBM traffic (stamped json: bench.py refuses entries whose kernel sources changed since) and the roofline
 # kernel's issue / matrix-core counters
+if [ "${SKIP_PMC:-0}" != 1 ]; then   # (SKIP_PMC=1: the counters of this checkout are already in profiles/pmc_traffic.json -- stamped by source hash)
 timeout 1800 python tools/pmc_traffic.py --batch 1 > $OUT/pmc.log 2>&1
 timeout 1500 python tools/pmc_traffic.py --batch 32 --only front,wino6_l1_128_128,front_l4,dscv_l4,sncv_l4 >> $OUT/pmc.log 2>&1
 timeout 900 python tools/pmc_traffic.py --config4 >> $OUT/pmc.log 2>&1          # BASELINE configs[4] geometry (round 6): front + the roofline layer
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json; cp gpurun_out/pmc_traffic_rows.txt $OUT/pmc_traffic_rows.txt
 need $OUT/pmc_traffic.json $OUT/pmc_traffic_rows.txt
 timeout 1200 bash tools/pmc_wino6.sh > /dev/null 2>&1; cp gpurun_out/pmc/wino6.txt $OUT/wino6_pmc.txt; need $OUT/wino6_pmc.txt
+fi
 
 
 timeout 600 python bench.py --steps 20 --host-input > $OUT/bench_b1.json 2> $OUT/bench_b1.err;                      need $OUT/bench_b1.json
