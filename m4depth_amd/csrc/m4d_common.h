@@ -104,15 +104,19 @@ __device__ __forceinline__ void m4d_store16(float* p, float v0, float v1, float 
 }
 
 // ---- exact 3-way bf16 split of a pair of float32 values (m4d_wino6*.hip) ---------------------------------------------------
-// Default (M4D_SPLIT_RN = 1): round to nearest -- hi = bf16(v), mid = bf16(v - hi), lo = (v - hi) - mid (exact, 8 significant
-// bits left: its upper half IS the conversion); 13 VALU instructions per pair, two of them v_cvt_pk_bf16_f32 (8 issue
-// cycles each beside MFMAs, tools/micro/valu_cost.hip); dropped term products <= 2^-26 |a b|.
-// -DM4D_SPLIT_RN=0 builds the split by TRUNCATION: hi = the upper 16 bits of v, r = v - hi exact, mid = the upper 16 bits of
-// r, lo = r - mid exact: 11 plain VALU instructions per pair (-23 % of the operand-generation issue slots); mid / lo are up
-// to 2x / 4x larger, dropped products <= 2^-24 |a b| (weights stay split round-to-nearest on the host, so the dropped terms
-// stay unbiased); every accuracy test passes with it.  Measured (round 3, profiles/r03_split_truncation_ab.txt): the level-1
-// layers 1-2 % faster alone (144.2 -> 140.7 us), end to end nothing (1354 vs 1355 frames/s, 5 interleaved runs each) -- the
-// Winograd kernel is not bound by VALU issue slots alone -- so the more accurate split stays.  Packed words: element 0 in
+// M4D_SPLIT_RN = 1 (this header's default: the latency-first / tail kernels): round to nearest -- hi = bf16(v), mid = bf16(v - hi),
+// lo = (v - hi) - mid (exact, 8 significant bits left: its upper half IS the conversion); 13 VALU instructions per pair, two of
+// them v_cvt_pk_bf16_f32 (8 issue cycles each beside MFMAs, tools/micro/valu_cost.hip); dropped term products <= 2^-26 |a b|.
+// M4D_SPLIT_RN = 0 (the Winograd kernels m4d_wino6*.hip since round 6: csrc/Makefile W6FLAGS): the split by TRUNCATION -- hi = the
+// upper 16 bits of v, r = v - hi exact, mid = the upper 16 bits of r, lo = r - mid exact: 11 plain VALU instructions per pair
+// (-23 % of the operand-generation issue slots); mid / lo are up to 2x / 4x larger, dropped products <= 2^-25 + 2^-26 of |a b|
+// (the weights stay split round-to-nearest on the host, so the dropped terms stay unbiased) -- still below float32's own product
+// rounding (2^-24).  History: round 3 measured the level-1 layers 1-2 % faster alone and nothing end to end (1354 vs 1355
+// frames/s) and kept round-to-nearest; round 6, on the kernel as it is now (operand generation = 14.6 % of the launch by
+// ablation, profiles/r06_wino6_ablations.txt): **+1.0 % at batch 1 (1663 -> 1678 frames/s, three interleaved pairs), +1.5 % at
+// batch 32 (2175 -> 2207)**, all 283 GPU tests green, error to float64 of the kernel still BELOW the fp32-MFMA kernel's (0.097-0.100
+// against 0.118-0.124 of a float32 ulp-scale, tools/bench_wino6.py), the end-to-end float64 comparison unchanged to three digits
+// (GPU median 7.87e-7, 99.997 % within 1e-4; profiles/r06_split_truncation_ab.txt).  Packed words: element 0 in
 // the low half.  A non-finite value has no split (Inf - Inf): the products it enters come out NaN, where float32 arithmetic
 // would have kept an Inf -- the host-side weight splitter refuses non-finite weights (network_ops.split_bf16x3).
 #ifndef M4D_SPLIT_RN

@@ -40,7 +40,7 @@ TARGETS = {
     "wino_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "2"], ["conv3x3_wino4_kernel"],
                         [CS + "m4d_wino.hip"]),
     "wino6_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "6"], ["conv3x3_wino6_kernel", "conv3x3_wino6p_kernel"],
-                         [CS + "m4d_wino6.hip", CS + "m4d_wino6p.hip"]),
+                         [CS + "m4d_wino6.hip", CS + "m4d_wino6p.hip", CS + "Makefile"]),      # (the Makefile: W6FLAGS picks the split)
     "conv_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "0"], ["conv3x3_mfma_kernel"],
                         [CS + "m4d_conv.hip"]),
 }
@@ -53,7 +53,7 @@ TARGETS_CONFIG4 = {
     "front": (["tools/bench_kernels.py", "--iters", "5", "--which", "front"] + C4_GEO, ["level_front_kernel"],
               [CS + "m4d_front.hip", CS + "m4d_common.h"]),
     "wino6_l1_128_128": (["tools/bench_conv_one.py", "--iters", "5", "--winograd", "6", "--h", "384", "--w", "1280"],
-                         ["conv3x3_wino6_kernel", "conv3x3_wino6p_kernel"], [CS + "m4d_wino6.hip", CS + "m4d_wino6p.hip"]),
+                         ["conv3x3_wino6_kernel", "conv3x3_wino6p_kernel"], [CS + "m4d_wino6.hip", CS + "m4d_wino6p.hip", CS + "Makefile"]),
 }
 
 
