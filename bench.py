@@ -573,7 +573,7 @@ def main():
             runner = net.TapedSequence(model, data)
         else:
             n0 = int(_lib.lib.m4d_launch_count())
-            runner = net.GraphedSequence(model, data, warmup=1)
+            runner = net.make_runner(model, data, warmup=1)
             launches_per_step = (int(_lib.lib.m4d_launch_count()) - n0) // (1 + runner.capture_passes)   # one eager warm-up pass + the capture pass(es)
         # the batch lives in the graph's own input buffers (inputs resident in HBM before the timed region: no hand-over copy)
         data.update({k: v for k, v in runner.input_buffers().items()})

@@ -227,6 +227,10 @@ wino6_stagger_phases = int(_os.environ.get("M4D_WINO6_STAGGER_PHASES", "16"))
 wino6_stagger_min_wg = int(_os.environ.get("M4D_WINO6_STAGGER_MIN_WG", "200"))
 wino6_stagger_max_batch = int(_os.environ.get("M4D_WINO6_STAGGER_MAX_BATCH", "4"))
 wino6_stagger_autotune = _os.environ.get("M4D_STAGGER_AUTOTUNE", "1") == "1"
+# The sequence step as four hipGraphs on two real streams (SegmentedSequence) where the sequence allows it: make_runner().
+segmented_step = _os.environ.get("M4D_SEGMENTED", "0") == "1"
+segmented_resumed_first = _os.environ.get("M4D_SEG_RESUMED_FIRST", "1") == "1"
+segmented_resumed_on_main = _os.environ.get("M4D_SEG_RESUMED_ON_MAIN", "0") == "1"
 wino6_stagger_force = _os.environ.get("M4D_STAGGER_FORCE", "")           # "staggered" / "lock_step": keep that graph whatever the timing
 # The reset frame of all levels in ONE launch (m4d_pyramid_reset) instead of one state-seeding launch per level: the six launches
 # depend on each other only through the upsampling of constant maps, and they sit on the critical path of a batch-1 step.
@@ -1060,12 +1064,18 @@ class DepthEstimatorPyramid(torch.nn.Module):
             self.levels[lvl].reset_commit()
         return ests
 
-    def _forward_pipelined(self, f_maps_pyrs, traj_samples, local_cameras, n_streams, encoder=None, n_maps_pyrs=None):
+    def _forward_pipelined(self, f_maps_pyrs, traj_samples, local_cameras, n_streams, encoder=None, n_maps_pyrs=None,
+                           resume=None):
         """The same loop as a wavefront over (frame, level) on ``n_streams`` HIP streams: frame t runs on
         stream t % n; before level l of frame t it waits for the event recorded after level l of frame
         t-1 (the level's temporal memory).  Inside a stream the levels stay in coarse-to-fine order.
         Works eagerly and under hipGraph capture (the side streams fork from / join the capturing one;
-        under capture the caller guarantees one stream per frame)."""
+        under capture the caller guarantees one stream per frame).
+
+        ``resume`` = {frame: its estimates so far, coarse -> fine}: those (frame, level) cells ran BEFORE this call, ordered ahead
+        of it on the calling stream (``SegmentedSequence``: the reset frame and the first full frame's coarse levels are graphs of
+        their own); the wavefront continues from there -- every feature pyramid is given, only the streams with work left fork
+        and join, and a wait for a cell that ran earlier is dropped (the calling stream orders it)."""
         n_lvls = len(self.levels)
         main = torch.cuda.current_stream()
         if getattr(self, "_streams", None) is None or len(self._streams) < n_streams:
@@ -1076,13 +1086,17 @@ class DepthEstimatorPyramid(torch.nn.Module):
         fork.record(main)
         keep.append(fork)
         n_fr = len(traj_samples)
+        ran = set() if resume is None else {(f, l) for f, ests in resume.items() for l in range(len(ests))}
 
         def is_reset(f):
             nt = traj_samples[f]["new_traj"]
             return bool(nt.reshape(-1)[0].item()) if isinstance(nt, torch.Tensor) else bool(np.asarray(nt).reshape(-1)[0])
         # frame -> stream: one per frame; with pipeline_merge_reset_frame a reset frame rides on the next frame's stream
         stream_of = list(range(n_fr))
-        if pipeline_merge_reset_frame:
+        if resume is not None and segmented_resumed_on_main:
+            # a frame under way continues on the CALLING stream (-1), the others fork
+            stream_of = [-1 if 0 < len(resume.get(f, [])) < n_lvls else f for f in range(n_fr)]
+        if pipeline_merge_reset_frame and resume is None:
             for f in range(n_fr - 1):
                 if is_reset(f) and not is_reset(f + 1):
                     stream_of[f] = f + 1
@@ -1098,19 +1112,28 @@ class DepthEstimatorPyramid(torch.nn.Module):
             neutral: ROCm 7.2's hipGraph executor assigns nodes to its four streams from the edges it sees.
             ``pipeline_fork_frames`` = the streams (= frames, one stream per frame under capture) that keep the explicit wait."""
             hosted = [f for f in range(n_fr) if stream_of[f] % n_streams == i_st]
+            if resume is not None:                    # nothing but the fork orders a resumed frame behind the calling stream
+                return True
             if i_st == 0 or i_st >= n_fr or f_maps_pyrs is None:
                 return True
             if any(f == 0 or launches_encoder(f) for f in hosted):
                 return True
             return pipeline_fork_frames is None or i_st in pipeline_fork_frames
-        for i_st, st in enumerate(streams):
+        # the streams that host a (frame, level) cell of this call (all of them unless the call resumes a sequence)
+        active = [i_st for i_st in range(len(streams))
+                  if resume is None or any((f, l) not in ran for f in range(n_fr)
+                                           if stream_of[f] >= 0 and stream_of[f] % n_streams == i_st for l in range(n_lvls))]
+        for i_st in active:
             if needs_fork(i_st):
-                st.wait_event(fork)                   # encoder outputs / inputs are produced on the main stream
+                streams[i_st].wait_event(fork)        # encoder outputs / inputs are produced on the main stream
         done = {}
         late_encoder = None
         n_pyrs = list(n_maps_pyrs) if n_maps_pyrs is not None else [None] * n_fr
-        f_pyrs = [None] * n_fr
+        f_pyrs = [None] * n_fr if resume is None else list(f_maps_pyrs)
         d_est = [None] * n_fr                         # per frame: estimates so far, coarse -> fine
+        if resume is not None:
+            for f, ests in resume.items():
+                d_est[f] = list(ests)
         # (Measured, tools/step_profile.py + tools/ab_bench.sh: the late encoder batch below is independent of the first
         # frames' decoder, yet issuing it FIRST so that it runs beside their coarse-level chain costs 4.5 % -- chip-filling
         # kernels delay the chain's small ones; where it is issued now it overlaps the first level-1 pass instead.)
@@ -1131,10 +1154,16 @@ class DepthEstimatorPyramid(torch.nn.Module):
             merged = [f for f in range(n_fr) if stream_of[f] != f and f == 0]
             order = [(f, l) for f in merged for l in range(n_lvls)] + [(f, l) for (f, l) in order if f not in merged]
         fused_reset_frames = set()
+        order = [cell for cell in order if cell not in ran]
+        if resume is not None and segmented_resumed_first:
+            # the cells of a frame that was under way when the call resumed go FIRST: they depend on nothing inside this call, and
+            # the hipGraph executor lays a graph out in capture order
+            part = {f for f in resume if 0 < len(resume[f]) < n_lvls}
+            order = [c for c in order if c[0] in part] + [c for c in order if c[0] not in part]
         for seq_i, l in order:
             lvl = n_lvls - 1 - l
             sample = traj_samples[seq_i]
-            st = streams[stream_of[seq_i] % n_streams]
+            st = main if stream_of[seq_i] < 0 else streams[stream_of[seq_i] % n_streams]
             with torch.cuda.stream(st):
                 if l == 0:
                     if f_maps_pyrs is None:          # per-frame encoder on the frame's own stream
@@ -1158,7 +1187,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
                         # a later frame of that batch: its features come from another stream (implied by the wait on the
                         # previous frame's level below when that frame is of the same encoder batch)
                         st.wait_event(late_encoder[1])
-                if seq_i > 0 and stream_of[seq_i - 1] != stream_of[seq_i]:
+                if seq_i > 0 and stream_of[seq_i - 1] != stream_of[seq_i] and (seq_i - 1, l) not in ran:
                     st.wait_event(done[(seq_i - 1, lvl)])           # (same stream: ordered by the stream itself)
                 if l == 0 and seq_i == 0:
                     # a reset frame that opens the sequence: ONE launch seeds every level (a later reset frame would have to wait
@@ -1183,7 +1212,7 @@ class DepthEstimatorPyramid(torch.nn.Module):
                 done[(seq_i, lvl)] = ev
                 d_est[seq_i] = [est] if d_est[seq_i] is None else d_est[seq_i] + [est]
         d_est_seq = [ests[::-1] for ests in d_est]
-        for st in streams:                            # join
+        for st in (streams[i_st] for i_st in active):  # join
             ev = torch.cuda.Event()
             ev.record(st)
             main.wait_event(ev)
@@ -1557,8 +1586,10 @@ class GraphedSequence:
         # batch-major tensor is non-contiguous from batch 2 on and every level wrapper would copy it with a framework kernel
         # INSIDE the graph (round 4, batch 32: ~43 copy nodes per step on the latency chain).  The batch-major [b,T,k] views of
         # the same memory are what input_buffers() hands out and what __call__ copies new batches into.
-        self._rot = as_f32(example["rot"], "rot").transpose(0, 1).contiguous()
-        self._trans = as_f32(example["trans"], "trans").transpose(0, 1).contiguous()
+        # (clone, not .contiguous(): at batch 1 the transposed view already counts as dense and would ALIAS the example's own
+        # tensors -- a later batch copied into the static buffers then overwrote the caller's example)
+        self._rot = as_f32(example["rot"], "rot").transpose(0, 1).clone(memory_format=torch.contiguous_format)
+        self._trans = as_f32(example["trans"], "trans").transpose(0, 1).clone(memory_format=torch.contiguous_format)
         self.static = {"RGB_im": example["RGB_im"].clone(), "rot": self._rot.transpose(0, 1), "trans": self._trans.transpose(0, 1)}
         self.camera = {k: as_f32(v, f"camera[{k}]").clone() for k, v in example["camera"].items()}
         self.seq_len = self.static["RGB_im"].shape[1]
@@ -1635,12 +1666,13 @@ class GraphedSequence:
         with torch.cuda.stream(self.stream):
             for rnd in range(2):
                 for c in cands:
+                    self.graph = c[1]
                     for _ in range(settle):
-                        c[1].replay()
+                        self._replay()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(reps):
-                        c[1].replay()
+                        self._replay()
                     e1.record()
                     e1.synchronize()
                     c[3].append(e0.elapsed_time(e1))
@@ -1657,7 +1689,12 @@ class GraphedSequence:
         for c in cands:
             if c is not best:
                 c[4] = None
-                c[1].reset()                            # the loser's graph and its memory pool
+                self._reset_graph(c[1])                 # the loser's graph and its memory pool
+
+    @staticmethod
+    def _reset_graph(graph):
+        for g in (graph.values() if isinstance(graph, dict) else [graph]):
+            g.reset()
 
     def _samples(self):
         nt = torch.unbind(self.new_traj, dim=1)
@@ -1700,8 +1737,146 @@ class GraphedSequence:
                                    "graph still reads the old buffers -- update weights in place or build a new GraphedSequence")
             self.model.prepack()                        # packed copies in place -- the graph reads the same addresses
             self.weights_stamp = stamp
-        self.graph.replay()
+        self._replay()
         return self.depth
+
+    def _replay(self):
+        self.graph.replay()
+
+
+class SegmentedSequence(GraphedSequence):
+    """The same sequence forward as FOUR hipGraphs replayed on two real HIP streams, for the one overlap ROCm 7.2's hipGraph
+    executor does not give a single captured graph (inside one graph the second encoder batch starts only
+    when the first full frame's coarse-to-fine chain has run -- ~350 us of a nearly idle chip per batch-1 step):
+
+        calling stream:  [a: encoder batch a (reset frame + first full frame), statistics of all frames, pyramid reset]
+                         [c: first full frame, levels n..2 -- a latency chain of small kernels] -> wait(b) ->
+                         [d: that frame's level 1 + the remaining frames as the (frame, level) wavefront, final upsampling]
+        side stream:     wait(a) -> [b: encoder batch b (the remaining frames) + their normalised coarse maps]
+
+    so that b's chip-filling kernels run BESIDE c's small ones.  Same kernels, same arguments, same order per buffer as
+    ``GraphedSequence`` (bit-identical results: tests/test_gpu_model.py).  Needs a sequence that opens with a reset frame followed
+    by at least two full frames (``eligible``); every other shape of work stays with ``GraphedSequence``."""
+
+    @staticmethod
+    def eligible(model, example):
+        nt = example["new_traj"]
+        nt = nt if isinstance(nt, torch.Tensor) else torch.as_tensor(np.asarray(nt))
+        pat = [bool(v) for v in nt[0].reshape(-1).tolist()]
+        return bool(example["RGB_im"].is_cuda and not model.model_settings["is_training"] and fused_pyramid_reset
+                    and len(pat) >= 3 and pat[0] and not any(pat[1:]) and level_pipeline_streams >= len(pat))
+
+    def __init__(self, model, example, warmup=2, autotune=None):
+        if not self.eligible(model, example):
+            raise ValueError("SegmentedSequence: needs a CUDA inference sequence [reset frame, >= 2 full frames]")
+        self.stream_b = torch.cuda.Stream()
+        self._ev_a, self._ev_b = torch.cuda.Event(), torch.cuda.Event()
+        self.graphs = None
+        super().__init__(model, example, warmup=warmup, autotune=autotune)
+
+    # -- the forward, cut into its four segments; ``run(name, fn)`` issues one --------------------------------------------
+    def _segments(self, run):
+        model, enc, dest = self.model, self.model.encoder, self.model.d_estimator
+        samples = self._samples()
+        n_fr, n_lvls, k = self.seq_len, len(dest.levels), 2
+        bsz = int(self.static["RGB_im"].shape[0])
+        S = {}
+
+        def split(pyr, n):
+            return [[lvl[t * bsz:(t + 1) * bsz] for lvl in pyr] for t in range(n)]
+
+        def seg_a():
+            model.step_counter += 1
+            enc.set_sequence_batch(bsz)
+            stats = enc.head_stats(_stack_frames(samples)) if encoder_stats_up_front else None
+            if stats is not None:
+                head = enc(_stack_frames(samples[:k]), head_stats=(stats[0][:k * bsz], stats[1][:k * bsz]))
+                S["late_stats"] = (stats[0][k * bsz:], stats[1][k * bsz:])
+            else:
+                head = enc(_stack_frames(samples[:k]))
+                S["late_stats"] = None
+            S["f"] = split(head, k)
+            nhead = dest.prenormalize(head, bsz)
+            S["n"] = [dest._frame_slice(nhead, t, bsz) for t in range(k)]
+            S["cams"] = nops.camera_pyramid(self.camera, n_lvls)
+            fused = dest._reset_all_levels(S["f"][0], samples[0]["new_traj"])
+            if fused is None:
+                raise RuntimeError("SegmentedSequence: the one-launch pyramid reset refused this model")
+            S["est"] = {0: fused}
+
+        def seg_b():
+            tail = enc(_stack_frames(samples[k:]), head_stats=S["late_stats"]) if S["late_stats"] is not None \
+                else enc(_stack_frames(samples[k:]))
+            ntail = dest.prenormalize(tail, bsz)
+            S["f"] = S["f"] + split(tail, n_fr - k)
+            S["n"] = S["n"] + [dest._frame_slice(ntail, j, bsz) for j in range(n_fr - k)]
+
+        def seg_c():
+            ests = []
+            smp = samples[1]
+            for l in range(n_lvls - 1):
+                lvl = n_lvls - 1 - l
+                ests.append(dest.levels[lvl](S["f"][1][lvl], dict(ests[-1]) if ests else None, smp["rot"], smp["trans"],
+                                             S["cams"][lvl], smp["new_traj"],
+                                             curr_f_normalized=None if S["n"][1] is None else S["n"][1][lvl]))
+            S["est"][1] = ests
+
+        def seg_d():
+            d_maps = dest._forward_pipelined(S["f"], samples, S["cams"], n_fr, n_maps_pyrs=S["n"], resume=S["est"])
+            model.last_estimates = d_maps
+            h, w = samples[-1]["RGB_im"].shape[1:3]
+            S["depth"] = nops.resize_nearest(d_maps[-1][0]["depth"], h, w)
+
+        for name, fn in (("a", seg_a), ("b", seg_b), ("c", seg_c), ("d", seg_d)):
+            run(name, fn)
+        return S["depth"]
+
+    def _play(self, issue):
+        """The four segments on the current stream and the side stream, with the two cross-stream edges."""
+        cur = torch.cuda.current_stream()
+        issue("a")
+        self._ev_a.record(cur)
+        with torch.cuda.stream(self.stream_b):
+            self.stream_b.wait_event(self._ev_a)
+            issue("b")
+            self._ev_b.record(self.stream_b)
+        issue("c")
+        cur.wait_event(self._ev_b)
+        issue("d")
+
+    def _run(self):
+        """Eager pass (warm-up: allocates the per-stream scratch the captures will reuse)."""
+        fns = {}
+        out = []
+
+        def collect(name, fn):
+            fns[name] = fn
+            if name == "d":                               # all four closures exist: issue them in replay order
+                self._play(lambda n: fns[n]())
+        out = self._segments(collect)
+        return out
+
+    def _capture(self):
+        graphs = {}
+
+        def run(name, fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream_b if name == "b" else self.stream):
+                fn()
+            graphs[name] = g
+        out = self._segments(run)
+        return graphs, out
+
+    def _replay(self):
+        self._play(lambda n: self.graph[n].replay())
+
+
+def make_runner(model, example, warmup=2, autotune=None):
+    """The hipGraph runner of a sequence step: ``SegmentedSequence`` where the module setting asks for it and the sequence is
+    eligible, ``GraphedSequence`` otherwise."""
+    if segmented_step and SegmentedSequence.eligible(model, example):
+        return SegmentedSequence(model, example, warmup=warmup, autotune=autotune)
+    return GraphedSequence(model, example, warmup=warmup, autotune=autotune)
 
 
 class TapedSequence:

@@ -290,6 +290,59 @@ def test_graphed_sequence_matches_eager(dev, keep, monkeypatch):
         runner(bad)
 
 
+@pytest.mark.parametrize("T,b", [(4, 1), (3, 2)])
+def test_segmented_sequence_is_bitwise_the_graphed_sequence(dev, T, b, monkeypatch):
+    """``SegmentedSequence`` (the step as four hipGraphs on two real streams: the second encoder batch beside the first full
+    frame's coarse chain) against the eager forward and ``GraphedSequence``: depth, every level's estimate of every frame and the
+    level-1 refiner input bit for bit, over several replays with the batch changing in between; ineligible sequences refused."""
+    import m4depth_amd as M
+    from m4depth_amd import network as net
+    L, H, Wd = 3, 64, 96
+    W = S.init_weights(L, seed=9)
+    model = _build(dev, L, 4, 3, W)
+    model.compile(metrics=M.default_metrics())
+
+    def batch(seed):
+        samples, cam = S.make_sequence(b, T, H, Wd, seed=seed)
+        d = {k: torch.stack([to_dev(s[k], dev) for s in samples], dim=1) for k in ("depth", "RGB_im", "rot", "trans")}
+        d["new_traj"] = torch.stack([torch.from_numpy(s["new_traj"]) for s in samples], dim=1)
+        d["camera"] = to_dev(cam, dev)
+        return d
+
+    def all_levels():
+        return [npy(est[k]) for frame in model.last_estimates for est in frame for k in ("depth", "parallax")]
+
+    d1, d2 = batch(41), batch(42)
+    assert net.SegmentedSequence.eligible(model, d1)
+    refs = []
+    for d in (d1, d2):
+        model.test_step(d)
+        refs.append((all_levels(), npy(model.d_estimator.levels[0].last_f_input)))
+    seg = net.SegmentedSequence(model, d1, autotune=False)
+    assert sorted(seg.graph) == ["a", "b", "c", "d"] and seg.capture_passes == 1
+    for d, (lv, fin) in ((d1, refs[0]), (d2, refs[1]), (d1, refs[0]), (d1, refs[0])):
+        model.graphed_test_step(d, seg)
+        torch.cuda.synchronize()
+        for got, want in zip(all_levels(), lv):
+            assert_bits_equal(got, want, "segmented replay vs eager, every level of every frame")
+        assert_bits_equal(npy(model.d_estimator.levels[0].last_f_input), fin, "level-1 refiner input")
+    whole = net.GraphedSequence(model, d1, autotune=False)
+    for d in (d2, d1):
+        assert torch.equal(seg(d).clone(), whole(d))
+    # the autotuned double capture serves the four-graph form too
+    monkeypatch.setattr(net, "wino6_stagger_force", "lock_step")
+    seg2 = net.SegmentedSequence(model, d1, autotune=True)
+    assert seg2.capture_passes == 2 and seg2.stagger_us == 0 and torch.equal(seg2(d2).clone(), whole(d2))
+    # make_runner: the module setting decides, an ineligible sequence (no reset frame in front) keeps the one-graph form
+    monkeypatch.setattr(net, "segmented_step", True)
+    assert isinstance(net.make_runner(model, d1, autotune=False), net.SegmentedSequence)
+    plain = dict(d1)
+    plain["new_traj"] = torch.zeros_like(d1["new_traj"])
+    assert not net.SegmentedSequence.eligible(model, plain)
+    with pytest.raises(ValueError):
+        net.SegmentedSequence(model, plain)
+
+
 @pytest.mark.parametrize("split", [2, 4])
 def test_graph_replay_writes_only_memory_it_owns(dev, split, monkeypatch):
     """Round 6 regression (a GPU memory fault under M4D_PIPELINE_ENCODER_SPLIT=4, a silent hazard otherwise): a captured step has the
