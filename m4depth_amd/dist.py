@@ -16,6 +16,16 @@ import torch
 import torch.distributed as dist
 
 
+# A single-rank group skips the collectives (nothing to exchange).  False = issue them anyway: on a 1-GPU box this is the only way
+# to run the very calls an 8-GPU job makes -- RCCL initialisation, all_gather_into_tensor on the metric states, the float64 MAX
+# all-reduce, the device barrier -- on real hardware (tests/test_gpu_dist.py).
+single_rank_shortcut = True
+
+
+def _collectives_on():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or not single_rank_shortcut)
+
+
 def init_from_env(backend=None):
     """One process per GPU, launched by torch.distributed.run.  Returns
     (rank, world_size, local_rank, device).  No-op for a single process."""
@@ -45,7 +55,7 @@ def all_gather_metric_states(metrics, device):
     """All-gather every rank's (total, count) pairs; returns [world, n_metrics, 2].
     One small collective; launched after the last batch."""
     local = torch.stack([m.state(device) for m in metrics]).to(torch.float32).contiguous()   # [n,2]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return local.unsqueeze(0)
     world = dist.get_world_size()
     out = torch.empty((world,) + tuple(local.shape), dtype=torch.float32, device=device)
@@ -64,14 +74,14 @@ def reduce_metric_states(gathered):
 def max_over_ranks(value, device):
     """MAX-reduce a python float over ranks (bench timing contract)."""
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def all_gather_floats(value, device):
     """One python float per rank -> the list over ranks (report only: per-rank frames/s of the scaling bench)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return [float(value)]
     world = dist.get_world_size()
     local = torch.tensor([float(value)], dtype=torch.float32, device=device)
@@ -84,7 +94,7 @@ def all_gather_floats(value, device):
 
 
 def barrier(device):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         if device.type == "cuda":
             dist.barrier(device_ids=[device.index])
         else:
@@ -96,7 +106,7 @@ def all_reduce_gradients(params, average=True):
     all-reduce of every gradient.  The model has ~4.6 M parameters (18 MB), below the size where
     splitting into buckets overlapped with backward would pay on xGMI (a ring step per link is
     latency-bound under ~32 MB), so the whole set travels as a single bucket."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:

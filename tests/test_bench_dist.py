@@ -59,7 +59,7 @@ def _worker(rank, world, port, q):
     mets = MT.default_metrics()
 
     def step():                                            # stands in for model.graphed_test_step: metrics of the last frame
-        time.sleep(0.01 * (r + 1))                         # rank 1 is the slow one
+        time.sleep(0.01 * (4 * r + 1))                     # rank 1 is the slow one (50 ms against 10: a loaded box must not flip it)
         gt = data["depth"][:, -1]
         for m in mets:
             m.update_state(gt, gt * (1.0 + 0.01 * (r + 1)))
@@ -95,7 +95,7 @@ def test_two_rank_bench_leg_over_gloo():
     # regions agree with the first; each rank's own Winograd first-round choice lands in the line; rank 1 never waits for rank 0's tail
     # (timing bounds are one-sided or wide: this runs on loaded CPU boxes with a cold page cache)
     assert len(runs0) == 3 and runs0 == runs1 and all(v < 50 * runs0[0] for v in runs0)
-    assert all(v >= 1e3 * 0.02 for v in runs0)              # >= the slow rank's 20 ms per step
+    assert all(v >= 1e3 * 0.05 for v in runs0)              # >= the slow rank's 50 ms per step
     assert stag0 == stag1 == [9.0, 0.0]
     assert tail1 < 1.5 <= 3.0 <= tail0
     spread = bench.run_spread(runs0)
@@ -103,7 +103,7 @@ def test_two_rank_bench_leg_over_gloo():
     assert shape0 == shape1 == (4, 3, 16, 32, 3)
     assert sum0 != sum1                                     # every rank generates ITS shard (seeded by rank), not a copy
     assert dt0 == dt1 and prs0 == prs1 and len(prs0) == 2   # max over ranks / gathered list: the same on every rank
-    assert dt0 >= max(prs0) >= 3 * 0.02 and prs0[1] > prs0[0]
+    assert dt0 >= max(prs0) >= 3 * 0.05 and prs0[1] > prs0[0]
     for head in (head0, head1):
         assert head["n_gpus"] == 2 and head["scaling"] == "weak" and head["config"]["global_batch"] == 8
         assert head["config"]["parallelism"] == "dp2" and len(head["per_rank_frames_per_s"]) == 2
