@@ -36,10 +36,16 @@ def init_from_env(backend=None):
     device = torch.device(f"cuda:{local_rank}") if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    global single_rank_shortcut
+    lone_collectives = world == 1 and os.environ.get("M4D_DIST_SINGLE_RANK_COLLECTIVES", "0") == "1"
+    if (world > 1 or lone_collectives) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+    if lone_collectives:
+        # one rank of an N-GPU job, alone on a 1-GPU box: the same RCCL calls around the same per-rank workload
+        # (bench.py --batch 32 = BASELINE configs[3]'s per-rank leg)
+        single_rank_shortcut = False
     return rank, world, local_rank, device
 
 
