@@ -49,6 +49,14 @@ def init_from_env(backend=None):
     return rank, world, local_rank, device
 
 
+def shutdown():
+    """Tear the process group down.  bench.py deliberately does NOT call this: its ranks exit right after their last collective
+    (process exit releases everything; torch prints a warning), because a teardown that could wait on a peer is a risk the
+    never-yet-measured 8-GPU run should not carry.  For callers that keep the process alive."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def shard_range(global_batch, rank, world):
     """Contiguous shard of sequences owned by ``rank``."""
     if global_batch % world != 0:
