@@ -29,6 +29,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if (KIND == 6) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(*(double*)&x[2 * (k & 3)]) : "v"(*(double*)&x[2 * ((k + 1) & 3)]), "v"(*(double*)&x[2 * ((k + 2) & 3)]));
         if (KIND == 7) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(u[e]) : "v"(u[(e + 1) & 7]), "v"(u[(e + 2) & 7]), "s"(mask));
         if (KIND == 8) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x[e]) : "v"(x[(e + 1) & 7]), "v"(x[(e + 2) & 7]), "v"(x[(e + 3) & 7]));
+        if (KIND == 9) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x[e]) : "s"(mask), "v"(u[(e + 1) & 7]));   // D += A . B (packed bf16 pairs)
+        if (KIND == 10) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x[e]) : "v"(u[(e + 2) & 7]), "v"(u[(e + 1) & 7]));
       }
     }
   }
@@ -65,5 +67,7 @@ int main() {
   run<6, 3>("v_pk_add_f32"); run<6, 5>("v_pk_add_f32"); run<6, 6>("v_pk_add_f32");
   run<7, 6>("v_perm_b32"); run<7, 10>("v_perm_b32");
   run<8, 6>("v_fma_f32"); run<8, 10>("v_fma_f32");
+  run<9, 6>("v_dot2c_f32_bf16 sgpr, vgpr"); run<9, 10>("v_dot2c_f32_bf16 sgpr, vgpr");
+  run<10, 6>("v_dot2c_f32_bf16 vgpr, vgpr"); run<10, 10>("v_dot2c_f32_bf16 vgpr, vgpr");
   return 0;
 }
