@@ -1771,7 +1771,6 @@ class SegmentedSequence(GraphedSequence):
             raise ValueError("SegmentedSequence: needs a CUDA inference sequence [reset frame, >= 2 full frames]")
         self.stream_b = torch.cuda.Stream()
         self._ev_a, self._ev_b = torch.cuda.Event(), torch.cuda.Event()
-        self.graphs = None
         super().__init__(model, example, warmup=warmup, autotune=autotune)
 
     # -- the forward, cut into its four segments; ``run(name, fn)`` issues one --------------------------------------------
@@ -1847,14 +1846,12 @@ class SegmentedSequence(GraphedSequence):
     def _run(self):
         """Eager pass (warm-up: allocates the per-stream scratch the captures will reuse)."""
         fns = {}
-        out = []
 
         def collect(name, fn):
             fns[name] = fn
             if name == "d":                               # all four closures exist: issue them in replay order
                 self._play(lambda n: fns[n]())
-        out = self._segments(collect)
-        return out
+        return self._segments(collect)
 
     def _capture(self):
         graphs = {}
